@@ -1,0 +1,73 @@
+"""CPU restatement of the mmdet ``IIFLoss`` plugin arithmetic.
+
+TEST INFRASTRUCTURE — see ``oracle/__init__.py``.  The mmdet half of the
+reference is not importable here (mmcv / mmdet absent), so this file is a
+restatement pinned by cross-checks, not by running the reference:
+  * with weight=None, avg_factor=None, class_weight=None, loss_weight=1 it
+    must equal ``oracle.iif_oracle.iif_ce(reduction='mean')`` (golden G4);
+  * the CE known answers of instance_segmentation/tests/test_metrics/
+    test_losses.py:8-32 (table of ones).
+Citations are relative to /root/reference/instance_segmentation/.
+"""
+import csv
+
+import torch
+import torch.nn.functional as F
+
+
+def read_table(path, variant, dtype=torch.float32):
+    """mmdet/models/losses/iif_loss.py:47-50 — CSV column ``variant``, drop the
+    first data row (an all-ones placeholder), append 1.0 for background,
+    cast to float32, shape ``[1, C+1]``.  (The reference parses with pandas;
+    python's ``float()`` parses the same decimal strings to the same doubles.)
+    """
+    with open(path, newline="") as f:
+        rows = list(csv.reader(f))
+    col = rows[0].index(variant)
+    vals = [float(r[col]) for r in rows[1:]]
+    vals = vals[1:] + [1.0]
+    return torch.tensor(vals, dtype=dtype).unsqueeze(0)
+
+
+def weight_reduce_loss(loss, weight=None, reduction="mean", avg_factor=None):
+    """mmdet/models/losses/utils.py:29-55."""
+    if weight is not None:
+        loss = loss * weight
+    if avg_factor is None:
+        if reduction == "mean":
+            return loss.mean()
+        if reduction == "sum":
+            return loss.sum()
+        return loss
+    if reduction == "mean":
+        return loss.sum() / avg_factor
+    if reduction != "none":
+        raise ValueError('avg_factor can not be used with reduction="sum"')
+    return loss
+
+
+def iif_cross_entropy(pred, label, table, weight=None, reduction="mean", avg_factor=None,
+                      class_weight=None, ignore_index=None, loss_weight=1.0):
+    """mmdet/models/losses/iif_loss.py:132-152,184-202."""
+    ignore_index = -100 if ignore_index is None else ignore_index
+    loss = F.cross_entropy(pred * table, label, weight=class_weight, reduction="none",
+                           ignore_index=ignore_index)
+    if weight is not None:
+        weight = weight.float()
+    return loss_weight * weight_reduce_loss(loss, weight=weight, reduction=reduction,
+                                            avg_factor=avg_factor)
+
+
+def get_activation(cls_score, table):
+    """mmdet/models/losses/iif_loss.py:65-78."""
+    return torch.softmax(table * cls_score, dim=-1)
+
+
+def accuracy_top1(pred, target):
+    """mmdet/models/losses/accuracy.py:7-51 with topk=1, thresh=None: a
+    one-element tensor holding the top-1 hit rate in percent (0. for N=0)."""
+    if pred.size(0) == 0:
+        return pred.new_tensor(0.0)
+    _, lbl = pred.topk(1, dim=1)
+    correct = lbl.t().eq(target.view(1, -1))
+    return correct[:1].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / pred.size(0))

@@ -1,0 +1,328 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, read-only).  The
+classification half of the reference is imported as-is on CPU
+(custom, resnet_cifar, resnet_pytorch, utils).  ``imbalanced_dataset`` needs
+torchvision / catalyst / randaugment / PIL for image IO only; empty placeholder
+modules are registered for those names so that its pure-numpy class-count and
+class-map arithmetic (the only part on the hot path) executes from the
+reference's own file.  Nothing from the reference is written to the repo except
+inputs and outputs (data).
+
+While generating, every vector is also compared with the CPU oracle
+(``oracle/``) so a fixture is never written for a case the oracle mis-states.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import os
+import sys
+import tempfile
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/classification"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+torch.set_num_threads(8)
+
+from oracle import iif_oracle as O          # noqa: E402
+from oracle import resnet_oracle as R       # noqa: E402
+
+
+def _placeholder_modules():
+    class _CIFAR10:                                   # stands in for image storage only
+        def __init__(self, root, train=True, transform=None, target_transform=None, download=False):
+            n = self.cls_num * 5000 if self.cls_num == 10 else self.cls_num * 500
+            self.data = np.zeros((n, 1), dtype=np.uint8)
+            self.targets = [i % self.cls_num for i in range(n)]
+    tv = types.ModuleType("torchvision")
+    tv.datasets = types.ModuleType("torchvision.datasets"); tv.datasets.CIFAR10 = _CIFAR10
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    sys.modules.update({"torchvision": tv, "torchvision.datasets": tv.datasets,
+                        "torchvision.transforms": tv.transforms})
+    pil = types.ModuleType("PIL"); pil.Image = types.ModuleType("PIL.Image")
+    sys.modules.update({"PIL": pil, "PIL.Image": pil.Image})
+    cat = types.ModuleType("catalyst"); cat.data = types.ModuleType("catalyst.data")
+    cat.data.BalanceClassSampler = cat.data.DistributedSamplerWrapper = object
+    sys.modules.update({"catalyst": cat, "catalyst.data": cat.data})
+    ra = types.ModuleType("randaugment")
+    ra.CIFAR10Policy = ra.ImageNetPolicy = ra.RandAugment = object
+    sys.modules["randaugment"] = ra
+
+
+_placeholder_modules()
+import custom                 # noqa: E402  (reference)
+import resnet_cifar           # noqa: E402  (reference)
+import resnet_pytorch         # noqa: E402  (reference)
+import utils as ref_utils     # noqa: E402  (reference)
+import imbalanced_dataset     # noqa: E402  (reference; placeholders for image IO only)
+
+
+class _DS:
+    def __init__(self, counts):
+        self.c = list(counts)
+
+    def get_cls_num_list(self):
+        return self.c
+
+
+def close(a, b, tol, what):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    ref = max(b.abs().max().item(), 1e-30) if b.numel() else 1.0
+    assert err <= tol * max(ref, 1.0), "%s: oracle differs from reference by %g" % (what, err)
+
+
+# --------------------------------------------------------------------------- G1
+def g1_class_counts():
+    out = {}
+    for cls, klass in ((10, imbalanced_dataset.IMBALANCECIFAR10), (100, imbalanced_dataset.IMBALANCECIFAR100)):
+        for imb_type in ("exp", "step", "none"):
+            for imb in (0.1, 0.02, 0.01, 0.005):
+                ds = klass("/nonexistent", imb_type=imb_type, imb_factor=imb)
+                got = [int(v) for v in ds.get_cls_num_list()]
+                mine = O.img_num_per_cls(cls, 50000, imb_type, imb)
+                assert got == mine, (cls, imb_type, imb)
+                out["c%d_%s_%g" % (cls, imb_type, imb)] = np.array(got, dtype=np.int64)
+    return out
+
+
+# --------------------------------------------------------------------------- G2
+def g2_class_map():
+    out = {}
+    rng = np.random.RandomState(0)
+    cases = {
+        "distinct8": (8, np.repeat(np.arange(8), [3, 9, 1, 7, 12, 5, 2, 30])),
+        "ties12": (12, np.repeat(np.arange(12), [4, 4, 9, 1, 4, 9, 2, 2, 2, 7, 1, 4])),
+        "lt200": (200, None),
+        "ties40": (40, None),
+    }
+    for name, (C, labels) in cases.items():
+        if labels is None and name == "lt200":
+            # distinct counts 1..200 in scrambled class order: no ties, so the
+            # reference's default (non-stable) argsort is well defined
+            counts = rng.permutation(np.arange(1, C + 1))
+            labels = np.repeat(np.arange(C), counts)
+        elif labels is None:
+            counts = rng.randint(1, 6, size=C)          # many ties
+            labels = np.repeat(np.arange(C), counts)
+        labels = rng.permutation(labels)
+        with tempfile.TemporaryDirectory() as td:
+            txt = os.path.join(td, "l.txt")
+            with open(txt, "w") as f:
+                for i, l in enumerate(labels):
+                    f.write("img_%d.jpg %d\n" % (i, int(l)))
+            ds = imbalanced_dataset.LT_Dataset(td, txt, C)
+            ev = imbalanced_dataset.LT_Dataset_Eval(td, txt, ds.class_map, C)
+        cmap = [int(v) for v in ds.class_map]
+        tgt = [int(v) for v in ds.targets]
+        cnl = [int(v) for v in ds.get_cls_num_list()]
+        assert [int(v) for v in ev.targets] == tgt
+        m_cmap, m_tgt, m_cnl = O.lt_class_map(labels, C, kind=None)
+        assert (m_cmap, m_tgt, m_cnl) == (cmap, tgt, cnl), name
+        s_cmap, _, s_cnl = O.lt_class_map(labels, C, kind="stable")
+        assert s_cnl == cnl, name        # the count profile never depends on the tie rule
+        out[name + "_labels"] = np.asarray(labels, dtype=np.int64)
+        out[name + "_class_map"] = np.array(cmap, dtype=np.int64)
+        out[name + "_targets"] = np.array(tgt, dtype=np.int64)
+        out[name + "_cls_num_list"] = np.array(cnl, dtype=np.int64)
+        out[name + "_stable_is_ref"] = np.array(int(s_cmap == cmap))
+    return out
+
+
+# --------------------------------------------------------------------------- G3
+COUNT_SETS = {
+    "c4": [500, 100, 20, 5],
+    "cifar100_exp100": O.img_num_per_cls(100, 50000, "exp", 0.01),
+    "places365": [int(4980 * (5 / 4980) ** (i / 364.0)) for i in range(365)],
+    "imagenet1000": [int(1280 * (5 / 1280) ** (i / 999.0)) for i in range(1000)],
+    "lvis1204": None,   # filled from the CSV instance_freq column (+1 to avoid zeros)
+}
+
+
+def _lvis_counts():
+    import csv
+    with open("/root/reference/instance_segmentation/lvis_files/idf_1204.csv") as f:
+        rows = list(csv.reader(f))
+    col = rows[0].index("img_freq")
+    return [int(float(r[col])) + 1 for r in rows[1:]]
+
+
+def g3_tables():
+    out = {}
+    COUNT_SETS["lvis1204"] = _lvis_counts()
+    for name, counts in COUNT_SETS.items():
+        out[name + "_counts"] = np.array(counts, dtype=np.int64)
+        for norm in (0, 1, 2):
+            ref = custom.IIFLoss(_DS(counts), iif_norm=norm, device="cpu").iif
+            mine = O.iif_tables(counts, iif_norm=norm)
+            for v in O.VARIANTS:
+                assert ref[v].dtype == torch.float32 and tuple(ref[v].shape) == (1, len(counts))
+                assert torch.equal(ref[v], mine[v]), (name, norm, v)     # bit-exact fp32
+                out["%s_n%d_%s" % (name, norm, v)] = ref[v].numpy()
+    return out
+
+
+# --------------------------------------------------------------------- G4/G5/G6
+def g4_loss():
+    out = {}
+    g = torch.Generator().manual_seed(1234)
+    # small row counts keep the fixtures small; full-size shapes are checked GPU-vs-oracle live
+    shapes = {"c4": 8, "cifar100_exp100": 16, "places365": 8, "imagenet1000": 8, "lvis1204": 8}
+    for name, B in shapes.items():
+        counts = COUNT_SETS[name]
+        C = len(counts)
+        pred = torch.randn(B, C, generator=g) * 3.0
+        prior = torch.tensor(counts, dtype=torch.float64)
+        tgt = torch.multinomial(prior / prior.sum(), B, replacement=True, generator=g)
+        perm = torch.randperm(B, generator=g)
+        out[name + "_pred"] = pred.numpy()
+        out[name + "_targets"] = tgt.numpy()
+        out[name + "_perm"] = perm.numpy()
+        cw = O.deferred_class_weight(counts)
+        ref_cw = torch.tensor(counts); ref_cw = ref_cw.sum() / ref_cw   # initialisers.py:16-19 (cpu)
+        assert torch.equal(cw, ref_cw)
+        out[name + "_class_weight"] = cw.numpy()
+        variants = O.VARIANTS if C <= 1000 else ("raw", "smooth", "base10")
+        for v in variants:
+            for red in ("mean", "sum"):
+                for wname, w in (("nw", None), ("cw", cw)):
+                    crit = custom.IIFLoss(_DS(counts), variant=v, reduction=red, device="cpu", weight=w)
+                    p = pred.clone().requires_grad_(True)
+                    loss = crit(p, tgt)
+                    loss.backward()
+                    key = "%s_%s_%s_%s" % (name, v, red, wname)
+                    out[key + "_loss"] = loss.detach().numpy()
+                    out[key + "_dpred"] = p.grad.numpy()
+                    tb = O.iif_tables(counts)[v]
+                    close(O.iif_ce(pred, tgt, tb, w, red), loss.detach(), 1e-6, key)
+                    l64, d64, _ = O.iif_ce_closed_form(pred, tgt, tb, w, red)
+                    close(l64, loss.detach(), 2e-6, key + " closed-form loss")
+                    close(d64, p.grad, 2e-6, key + " closed-form grad")
+            crit = custom.IIFLoss(_DS(counts), variant=v, device="cpu")
+            scaled = crit(pred, infer=True)
+            assert torch.equal(scaled, O.iif_infer(pred, O.iif_tables(counts)[v]))
+            a1, a5 = ref_utils.accuracy(scaled, tgt, topk=(1, min(5, C)))
+            m1, m5 = O.accuracy(scaled, tgt, topk=(1, min(5, C)))
+            assert a1.item() == m1.item() and a5.item() == m5.item()
+            out["%s_%s_infer_acc" % (name, v)] = np.array([a1.item(), a5.item()], dtype=np.float32)
+            r1, r5 = ref_utils.accuracy(pred, tgt, topk=(1, min(5, C)))
+            out["%s_rawacc" % name] = np.array([r1.item(), r5.item()], dtype=np.float32)
+        # mixup criterion with a fixed lambda / permutation (custom.py:116-117)
+        lam = 0.3
+        crit = custom.IIFLoss(_DS(counts), variant="raw", device="cpu")
+        mix = custom.Mixup(crit, alpha=1.0)
+        p = pred.clone().requires_grad_(True)
+        ml = mix.mixup_criterion(p, tgt, tgt[perm], lam)
+        ml.backward()
+        out[name + "_mixup_loss"] = ml.detach().numpy()
+        out[name + "_mixup_dpred"] = p.grad.numpy()
+        close(O.mixup_criterion(pred, tgt, tgt[perm], lam, O.iif_tables(counts)["raw"]), ml.detach(), 1e-6, "mixup")
+    return out
+
+
+# --------------------------------------------------------------------------- G7
+def _state_checksum(sd):
+    return np.array([float(v.double().sum()) for k, v in sd.items() if v.is_floating_point()])
+
+
+def _net_case(arch, num_classes, counts, B, hw, steps, lr):
+    cifar = arch in R.CIFAR_ARCHS
+    sd = R.init_cifar(arch, num_classes, seed=7) if cifar else R.init_imagenet(arch, num_classes, seed=7)
+    if cifar:
+        model = getattr(resnet_cifar, arch)(num_classes=num_classes, use_norm="None")
+    else:
+        model = getattr(resnet_pytorch, arch)(num_classes=num_classes, use_norm="None", pretrained="None")
+    model.load_state_dict(sd)            # strict: proves the key names / shapes agree
+    model.train()
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, 3, hw, hw, generator=g)
+    prior = torch.tensor(counts, dtype=torch.float64)
+    y = torch.multinomial(prior / prior.sum(), B, replacement=True, generator=g)
+    crit = custom.IIFLoss(_DS(counts), variant="raw", device="cpu")
+    opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    sched = ref_utils.warmup_lr_scheduler(opt, 1000, 1.0 / 1000)
+    table = O.iif_tables(counts)["raw"]
+    out = {"init_checksum": _state_checksum(sd), "x_sum": np.array(float(x.double().sum())), "y": y.numpy()}
+    my_sd = {k: v.clone() for k, v in sd.items()}
+    bufs = {}
+    losses, logits0, gn0 = [], None, None
+    for it in range(steps):
+        cur_lr = opt.param_groups[0]["lr"]
+        logits = model(x)
+        loss = crit(logits, y)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            logits0 = logits.detach().clone()
+            gn0 = {k: float(p.grad.double().norm()) for k, p in model.named_parameters()}
+        opt.step()
+        sched.step()
+        losses.append(float(loss))
+        assert abs(cur_lr - lr * O.warmup_factor(it, 1000)) < 1e-15
+        my_loss, my_logits = R.train_step(my_sd, bufs, x, y, table, arch, cur_lr)
+        close(my_loss, loss.detach(), 1e-5, "%s step %d loss" % (arch, it))
+        if it == 0:
+            close(my_logits, logits0, 1e-5, arch + " logits")
+    final = model.state_dict()
+    for k in final:
+        close(my_sd[k], final[k], 2e-5, arch + " final " + k)
+    out["logits0"] = logits0.numpy()
+    out["losses"] = np.array(losses)
+    out["gradnorm_keys"] = np.array(list(gn0.keys()))
+    out["gradnorm0"] = np.array(list(gn0.values()))
+    out["final_checksum"] = _state_checksum(final)
+    out["final_fc"] = final["linear.weight" if cifar else "fc.weight"][:4].numpy()
+    out["final_bn1_rm"] = final["bn1.running_mean"].numpy()
+    out["lr0"] = np.array(lr)
+    return out
+
+
+def g7_nets():
+    out = {}
+    c100 = O.img_num_per_cls(100, 50000, "exp", 0.01)
+    for k, v in _net_case("resnet32", 100, c100, 8, 32, 4, 0.1).items():
+        out["resnet32_" + k] = v
+    c1000 = COUNT_SETS["imagenet1000"]
+    for k, v in _net_case("resnet50", 1000, c1000, 2, 64, 3, 0.1).items():
+        out["resnet50_" + k] = v
+    c365 = COUNT_SETS["places365"]
+    for k, v in _net_case("resnext50_32x4d", 365, c365, 2, 64, 2, 0.1).items():
+        out["resnext50_" + k] = v
+    return out
+
+
+# --------------------------------------------------------------------------- G8
+def g8_warmup():
+    opt = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=0.1)
+    out = {}
+    for iters in (5, 84, 1000):
+        sch = ref_utils.warmup_lr_scheduler(opt, iters, 1.0 / 1000)
+        fac = np.array([sch.lr_lambdas[0](i) for i in range(iters + 3)], dtype=np.float64)
+        mine = np.array([O.warmup_factor(i, iters) for i in range(iters + 3)], dtype=np.float64)
+        assert np.array_equal(fac, mine)
+        out["warmup_%d" % iters] = fac
+    return out
+
+
+def main():
+    sets = {"g1_class_counts": g1_class_counts, "g2_class_map": g2_class_map, "g3_tables": g3_tables,
+            "g4_loss": g4_loss, "g7_nets": g7_nets, "g8_warmup": g8_warmup}
+    for name, fn in sets.items():
+        data = fn()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **data)
+        print("%-18s %4d arrays  %8.1f KB" % (name, len(data), os.path.getsize(path) / 1024.0))
+
+
+if __name__ == "__main__":
+    main()
