@@ -1,0 +1,87 @@
+"""ctypes binding of libiif_amd.so (the C ABI declared in include/iif_amd.h).
+
+The library is built in-tree (``iif_amd/csrc/libiif_amd.so``) by
+``__graft_entry__.build()`` / ``make -C iif_amd/csrc``.  There is no CPU or
+PyTorch fallback: if the library is missing, or a tensor is not on the GPU,
+the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libiif_amd.so")
+
+IIF_F32, IIF_BF16 = 0, 1
+VARIANT_CODE = {"raw": 0, "smooth": 1, "rel": 2, "normit": 3, "gombit": 4, "base2": 5, "base10": 6}
+_ERR = {-1: "IIF_EINVAL (bad argument)", -2: "IIF_EUNSUPPORTED (shape/alignment)", -3: "IIF_ELAUNCH (HIP error)"}
+
+_c = ctypes
+_P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
+
+# name -> argtypes; must list every symbol of include/iif_amd.h (tests check this)
+SIGNATURES = {
+    "iif_build_table": [_P, _I, _I, _I, _P],
+    "iif_ce_fwd_bwd": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _L, _F, _I, _I, _P, _P, _P, _L, _P, _P],
+    "iif_scale_logits": [_P, _I, _L, _P, _I, _I, _P, _L, _P],
+    "iif_softmax": [_P, _I, _L, _P, _I, _I, _P, _L, _P],
+    "iif_topk_hits": [_P, _I, _L, _P, _P, _I, _I, _P, _I, _P, _P],
+    "iif_scale_by_device_scalar": [_P, _I, _L, _P, _P],
+    "iif_mix_rows": [_P, _I, _P, _F, _I, _L, _P, _P],
+}
+
+_lib = None
+
+
+class IIFNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IIFNativeError(
+                "libiif_amd.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C iif_amd/csrc`; iif_amd has no CPU/PyTorch fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        l.iif_version.restype = _c.c_char_p
+        l.iif_version.argtypes = []
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = _I
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise IIFNativeError("%s failed: %s" % (what, _ERR.get(rc, rc)))
+
+
+def stream_ptr():
+    """The HIP stream torch is currently enqueuing on (works under graph capture)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return IIF_F32
+    if t.dtype == torch.bfloat16:
+        return IIF_BF16
+    raise IIFNativeError("unsupported dtype %s (float32 / bfloat16 only)" % t.dtype)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise IIFNativeError(
+                "iif_amd runs on MI355X only: got a %s tensor on %s (no CPU fallback; the CPU restatement "
+                "lives in oracle/ and is test infrastructure)" % (tuple(t.shape), t.device))
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

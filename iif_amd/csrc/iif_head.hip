@@ -1,0 +1,361 @@
+// Fused IIF classifier-head kernels for gfx950 (MI355X).
+//
+// One 64-lane wavefront owns one row of logits.  For C <= 2048 (every class
+// count on the reference's path: 100 / 365 / 1000 / 1204) the whole row lives
+// in registers: ONE read of the logits, wave-shuffle max / sum-exp, loss and
+// gradient written in the same pass (classification/custom.py:28-36 does the
+// same work as >= 6 elementwise/reduction launches plus autograd).
+// The kernels are HBM/latency-bound; there is no GEMM shape here, so no MFMA.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- element I/O
+template <typename T> struct Io;
+template <> struct Io<float> {
+    static __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+    static __device__ __forceinline__ float load1(const float* p) { return *p; }
+    static __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+    static constexpr int kAlign = 16;
+};
+template <> struct Io<unsigned short> {  // bf16 bits
+    static __device__ __forceinline__ f32x4 load4(const unsigned short* p) {
+        u32x2 w = *reinterpret_cast<const u32x2*>(p);
+        f32x4 r;
+        r.x = bf16_bits_to_f32(w.x & 0xffffu); r.y = __uint_as_float(w.x & 0xffff0000u);
+        r.z = bf16_bits_to_f32(w.y & 0xffffu); r.w = __uint_as_float(w.y & 0xffff0000u);
+        return r;
+    }
+    static __device__ __forceinline__ void store4(unsigned short* p, f32x4 v) {
+        u32x2 w; w.x = pack_bf16x2(v.x, v.y); w.y = pack_bf16x2(v.z, v.w);
+        *reinterpret_cast<u32x2*>(p) = w;
+    }
+    static __device__ __forceinline__ float load1(const unsigned short* p) { return bf16_bits_to_f32(*p); }
+    static __device__ __forceinline__ void store1(unsigned short* p, float v) { *p = f32_to_bf16_bits(v); }
+    static constexpr int kAlign = 8;
+};
+
+struct CeArgs {
+    const void* x; int64_t ldx;
+    const float* tab;
+    const int64_t* ta; const int64_t* tb;
+    float lam;
+    const float* roww; const float* clsw;
+    int64_t ignore; float scale;
+    int B, C;
+    float* loss_row;
+    void* dx; int64_t lddx;
+    int32_t* status;
+};
+
+// Per-row scalars shared by the register and the streaming variants.
+struct RowCoef {
+    int64_t ta, tb;      // -1 when the term is inactive
+    float wa, wb;        // lam * class_weight terms (0 when inactive)
+    float rw;
+};
+
+__device__ __forceinline__ RowCoef row_coef(const CeArgs& a, int row) {
+    RowCoef r;
+    r.rw = a.roww ? a.roww[row] : 1.0f;
+    int64_t ta = a.ta[row];
+    int64_t tb = a.tb ? a.tb[row] : a.ignore;
+    float la = a.tb ? a.lam : 1.0f, lb = a.tb ? 1.0f - a.lam : 0.0f;
+    bool bad = false;
+    if (ta == a.ignore) { ta = -1; } else if (ta < 0 || ta >= a.C) { ta = -1; bad = true; }
+    if (!a.tb || tb == a.ignore) { tb = -1; } else if (tb < 0 || tb >= a.C) { tb = -1; bad = true; }
+    if (bad && a.status && threadIdx.x % IIF_WAVE == 0) atomicExch(a.status, 1);
+    r.ta = ta; r.tb = tb;
+    r.wa = ta >= 0 ? la * (a.clsw ? a.clsw[ta] : 1.0f) : 0.0f;
+    r.wb = tb >= 0 ? lb * (a.clsw ? a.clsw[tb] : 1.0f) : 0.0f;
+    return r;
+}
+
+// ------------------------------------------------ register-resident row (C%4==0)
+// MODE 0: CE loss + gradient, MODE 1: softmax output (fp32)
+template <typename T, int NCH, int MODE>
+__global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, int64_t ld_sm) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= a.B) return;                       // wave-uniform
+    const T* x = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
+    f32x4 z[NCH], t[NCH];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c0 = (j * 64 + lane) * 4;
+        if (c0 < a.C) {
+            t[j] = *reinterpret_cast<const f32x4*>(a.tab + c0);
+            z[j] = Io<T>::load4(x + c0) * t[j];
+            m = fmaxf(m, fmaxf(fmaxf(z[j].x, z[j].y), fmaxf(z[j].z, z[j].w)));
+        } else {
+            t[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            z[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        z[j].x = expf(z[j].x - m); z[j].y = expf(z[j].y - m);
+        z[j].z = expf(z[j].z - m); z[j].w = expf(z[j].w - m);
+        s += (z[j].x + z[j].y) + (z[j].z + z[j].w);
+    }
+    s = wave_sum(s);
+    const float inv_s = 1.0f / s;
+    if (MODE == 1) {
+        float* o = sm_out + (int64_t)row * ld_sm;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c0 = (j * 64 + lane) * 4;
+            if (c0 < a.C) *reinterpret_cast<f32x4*>(o + c0) = z[j] * inv_s;
+        }
+        return;
+    }
+    const float lse = m + logf(s);
+    const RowCoef rc = row_coef(a, row);
+    float r = 0.f;
+    if (rc.ta >= 0) r += rc.wa * (lse - Io<T>::load1(x + rc.ta) * a.tab[rc.ta]);
+    if (rc.tb >= 0) r += rc.wb * (lse - Io<T>::load1(x + rc.tb) * a.tab[rc.tb]);
+    if (lane == 0) a.loss_row[row] = rc.rw * r;
+    if (a.dx == nullptr) return;
+    T* dx = static_cast<T*>(a.dx) + (int64_t)row * a.lddx;
+    const float g = a.scale * rc.rw;
+    const float gs = g * (rc.wa + rc.wb) * inv_s, ga = g * rc.wa, gb = g * rc.wb;
+    const int ia = (int)rc.ta, ib = (int)rc.tb;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c0 = (j * 64 + lane) * 4;
+        if (c0 < a.C) {
+            f32x4 p = z[j] * gs;
+            p.x -= (ia == c0 ? ga : 0.f) + (ib == c0 ? gb : 0.f);
+            p.y -= (ia == c0 + 1 ? ga : 0.f) + (ib == c0 + 1 ? gb : 0.f);
+            p.z -= (ia == c0 + 2 ? ga : 0.f) + (ib == c0 + 2 ? gb : 0.f);
+            p.w -= (ia == c0 + 3 ? ga : 0.f) + (ib == c0 + 3 ? gb : 0.f);
+            Io<T>::store4(dx + c0, p * t[j]);
+        }
+    }
+}
+
+// -------------------------------------------- streaming row (any C / alignment)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) row_stream_kernel(CeArgs a, float* sm_out, int64_t ld_sm) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= a.B) return;
+    const T* x = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
+    float m = -INFINITY;
+    for (int c = lane; c < a.C; c += 64) m = fmaxf(m, Io<T>::load1(x + c) * a.tab[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < a.C; c += 64) s += expf(Io<T>::load1(x + c) * a.tab[c] - m);
+    s = wave_sum(s);
+    const float inv_s = 1.0f / s;
+    if (MODE == 1) {
+        float* o = sm_out + (int64_t)row * ld_sm;
+        for (int c = lane; c < a.C; c += 64) o[c] = expf(Io<T>::load1(x + c) * a.tab[c] - m) * inv_s;
+        return;
+    }
+    const float lse = m + logf(s);
+    const RowCoef rc = row_coef(a, row);
+    float r = 0.f;
+    if (rc.ta >= 0) r += rc.wa * (lse - Io<T>::load1(x + rc.ta) * a.tab[rc.ta]);
+    if (rc.tb >= 0) r += rc.wb * (lse - Io<T>::load1(x + rc.tb) * a.tab[rc.tb]);
+    if (lane == 0) a.loss_row[row] = rc.rw * r;
+    if (a.dx == nullptr) return;
+    T* dx = static_cast<T*>(a.dx) + (int64_t)row * a.lddx;
+    const float g = a.scale * rc.rw;
+    const float gs = g * (rc.wa + rc.wb) * inv_s, ga = g * rc.wa, gb = g * rc.wb;
+    for (int c = lane; c < a.C; c += 64) {
+        const float tc = a.tab[c];
+        float p = expf(Io<T>::load1(x + c) * tc - m) * gs;
+        if (c == rc.ta) p -= ga;
+        if (c == rc.tb) p -= gb;
+        Io<T>::store1(dx + c, p * tc);
+    }
+}
+
+// fixed-order sum of the per-row losses: one 256-thread block, deterministic
+__global__ void __launch_bounds__(256) loss_reduce_kernel(const float* rows, int B, float scale, float* out) {
+    __shared__ float sh[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) acc += rows[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0] * scale;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) scale_rows_kernel(const T* x, int64_t ldx, const float* tab, int B, int C,
+                                                         T* out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const T* xr = x + (int64_t)row * ldx;
+    T* o = out + (int64_t)row * ldo;
+    for (int c = lane; c < C; c += 64) Io<T>::store1(o + c, Io<T>::load1(xr + c) * tab[c]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) topk_hits_kernel(const T* x, int64_t ldx, const float* tab,
+                                                        const int64_t* tgt, int B, int C, int k0, int k1, int k2,
+                                                        int k3, int nk, int32_t* hits) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int64_t t = tgt[row];
+    if (t < 0 || t >= C) return;
+    const T* xr = x + (int64_t)row * ldx;
+    const float zt = Io<T>::load1(xr + t) * (tab ? tab[t] : 1.0f);
+    int cnt = 0;
+    for (int c = lane; c < C; c += 64) {
+        const float z = Io<T>::load1(xr + c) * (tab ? tab[c] : 1.0f);
+        cnt += (z > zt) || (z == zt && c < (int)t);
+    }
+    cnt = wave_sum_i(cnt);
+    if (lane == 0) {
+        const int ks[4] = {k0, k1, k2, k3};
+        for (int j = 0; j < nk; ++j)
+            if (cnt < ks[j]) atomicAdd(&hits[j], 1);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) scale_by_scalar_kernel(T* x, int64_t n, const float* s) {
+    const float f = *s;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        Io<T>::store1(x + i, Io<T>::load1(x + i) * f);
+}
+
+inline bool aligned(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+template <typename T, int MODE>
+int launch_rows(const CeArgs& a, float* sm_out, int64_t ld_sm, hipStream_t st) {
+    const int wpb = a.B <= 4096 ? 1 : 4;
+    const dim3 grid((a.B + wpb - 1) / wpb), block(64 * wpb);
+    bool vec = (a.C % 4 == 0) && (a.C <= 2048) && (a.ldx % 4 == 0) && aligned(a.x, Io<T>::kAlign) &&
+               aligned(a.tab, 16);
+    if (MODE == 0 && a.dx) vec = vec && (a.lddx % 4 == 0) && aligned(a.dx, Io<T>::kAlign);
+    if (MODE == 1) vec = vec && (ld_sm % 4 == 0) && aligned(sm_out, 16);
+    if (vec) {
+        const int nch = (a.C + 255) / 256;
+        if (nch <= 1) hipLaunchKernelGGL((row_reg_kernel<T, 1, MODE>), grid, block, 0, st, a, sm_out, ld_sm);
+        else if (nch <= 2) hipLaunchKernelGGL((row_reg_kernel<T, 2, MODE>), grid, block, 0, st, a, sm_out, ld_sm);
+        else if (nch <= 4) hipLaunchKernelGGL((row_reg_kernel<T, 4, MODE>), grid, block, 0, st, a, sm_out, ld_sm);
+        else hipLaunchKernelGGL((row_reg_kernel<T, 8, MODE>), grid, block, 0, st, a, sm_out, ld_sm);
+    } else {
+        hipLaunchKernelGGL((row_stream_kernel<T, MODE>), grid, block, 0, st, a, sm_out, ld_sm);
+    }
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int iif_ce_fwd_bwd(const void* logits, int dtype, int64_t ld_logits, const float* table,
+                   const int64_t* targets_a, const int64_t* targets_b, float lam,
+                   const float* row_weight, const float* class_weight, int64_t ignore_index,
+                   float scale, int B, int C, float* loss_per_row, float* loss_out, void* dlogits,
+                   int64_t ld_dlogits, int32_t* d_status, void* stream) {
+    if (B < 0 || C <= 0) return IIF_EINVAL;
+    if (dtype != IIF_F32 && dtype != IIF_BF16) return IIF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (B == 0) {  // empty batch: loss 0 (mmdet heads can see zero RoIs)
+        if (loss_out) {
+            if (hipMemsetAsync(loss_out, 0, sizeof(float), st) != hipSuccess) return IIF_ELAUNCH;
+        }
+        return IIF_OK;
+    }
+    if (!logits || !table || !targets_a || !loss_per_row) return IIF_EINVAL;
+    if (ld_logits < C || (dlogits && ld_dlogits < C)) return IIF_EINVAL;
+    CeArgs a{logits, ld_logits, table, targets_a, targets_b, lam, row_weight, class_weight,
+             ignore_index, scale, B, C, loss_per_row, dlogits, ld_dlogits, d_status};
+    int rc = dtype == IIF_F32 ? launch_rows<float, 0>(a, nullptr, 0, st)
+                              : launch_rows<unsigned short, 0>(a, nullptr, 0, st);
+    if (rc != IIF_OK) return rc;
+    if (loss_out) {
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, loss_per_row, B, scale, loss_out);
+        IIF_LAUNCH_CHECK();
+    }
+    return IIF_OK;
+}
+
+int iif_softmax(const void* logits, int dtype, int64_t ld_logits, const float* table, int B, int C,
+                float* out, int64_t ld_out, void* stream) {
+    if (B < 0 || C <= 0) return IIF_EINVAL;
+    if (B == 0) return IIF_OK;
+    if (!logits || !table || !out || ld_logits < C || ld_out < C) return IIF_EINVAL;
+    CeArgs a{};
+    a.x = logits; a.ldx = ld_logits; a.tab = table; a.B = B; a.C = C;
+    if (dtype == IIF_F32) return launch_rows<float, 1>(a, out, ld_out, as_stream(stream));
+    if (dtype == IIF_BF16) return launch_rows<unsigned short, 1>(a, out, ld_out, as_stream(stream));
+    return IIF_EINVAL;
+}
+
+int iif_scale_logits(const void* logits, int dtype, int64_t ld_logits, const float* table, int B, int C,
+                     void* out, int64_t ld_out, void* stream) {
+    if (B < 0 || C <= 0) return IIF_EINVAL;
+    if (B == 0) return IIF_OK;
+    if (!logits || !table || !out || ld_logits < C || ld_out < C) return IIF_EINVAL;
+    const int wpb = 4;
+    const dim3 grid((B + wpb - 1) / wpb), block(64 * wpb);
+    if (dtype == IIF_F32)
+        hipLaunchKernelGGL(scale_rows_kernel<float>, grid, block, 0, as_stream(stream),
+                           (const float*)logits, ld_logits, table, B, C, (float*)out, ld_out);
+    else if (dtype == IIF_BF16)
+        hipLaunchKernelGGL(scale_rows_kernel<unsigned short>, grid, block, 0, as_stream(stream),
+                           (const unsigned short*)logits, ld_logits, table, B, C, (unsigned short*)out, ld_out);
+    else
+        return IIF_EINVAL;
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_topk_hits(const void* logits, int dtype, int64_t ld_logits, const float* table,
+                  const int64_t* targets, int B, int C, const int32_t* k_host, int nk, int32_t* hits,
+                  void* stream) {
+    if (B < 0 || C <= 0 || nk <= 0 || nk > 4 || !k_host) return IIF_EINVAL;
+    if (B == 0) return IIF_OK;
+    if (!logits || !targets || !hits || ld_logits < C) return IIF_EINVAL;
+    int k[4] = {0, 0, 0, 0};
+    for (int j = 0; j < nk; ++j) k[j] = k_host[j];
+    const int wpb = 4;
+    const dim3 grid((B + wpb - 1) / wpb), block(64 * wpb);
+    if (dtype == IIF_F32)
+        hipLaunchKernelGGL(topk_hits_kernel<float>, grid, block, 0, as_stream(stream), (const float*)logits,
+                           ld_logits, table, targets, B, C, k[0], k[1], k[2], k[3], nk, hits);
+    else if (dtype == IIF_BF16)
+        hipLaunchKernelGGL(topk_hits_kernel<unsigned short>, grid, block, 0, as_stream(stream),
+                           (const unsigned short*)logits, ld_logits, table, targets, B, C, k[0], k[1], k[2],
+                           k[3], nk, hits);
+    else
+        return IIF_EINVAL;
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_scale_by_device_scalar(void* x, int dtype, int64_t n, const float* d_scalar, void* stream) {
+    if (n < 0 || !d_scalar) return IIF_EINVAL;
+    if (n == 0) return IIF_OK;
+    if (!x) return IIF_EINVAL;
+    const int blocks = (int)(cdiv64(n, 256) < 2048 ? cdiv64(n, 256) : 2048);
+    if (dtype == IIF_F32)
+        hipLaunchKernelGGL(scale_by_scalar_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream),
+                           (float*)x, n, d_scalar);
+    else if (dtype == IIF_BF16)
+        hipLaunchKernelGGL(scale_by_scalar_kernel<unsigned short>, dim3(blocks), dim3(256), 0, as_stream(stream),
+                           (unsigned short*)x, n, d_scalar);
+    else
+        return IIF_EINVAL;
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+/*
+ * iif_amd.h — C ABI of libiif_amd.so: the MI355X (gfx950) kernels behind the IIF
+ * training hot path.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Conventions
+ *   - every `d_*` / device pointer is BORROWED: owned by the caller, must stay
+ *     alive until the work enqueued on `stream` has completed; nothing is
+ *     allocated or freed inside the library and no call synchronises.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     All work is enqueued on it; calls are re-entrant across streams and keep
+ *     no global or thread-local state, so they may be captured into a hipGraph.
+ *   - return value: IIF_OK (0) or a negative IIF_E* code; nothing throws.
+ *   - dtype codes: IIF_F32 / IIF_BF16.  Activations are NHWC ("channels last"),
+ *     weights KRSC ([Cout][R][S][Cin/groups]); this is the layout the kernels
+ *     are tiled for (16-byte channel vectors feed the MFMA K dimension).
+ *
+ * Each entry point names the reference interface it replaces (file:line under
+ * kostas1515/iif).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ */
+#ifndef IIF_AMD_H
+#define IIF_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IIF_OK 0
+#define IIF_EINVAL (-1)       /* bad argument (null pointer, size <= 0, bad enum) */
+#define IIF_EUNSUPPORTED (-2) /* shape / alignment the kernels are not built for */
+#define IIF_ELAUNCH (-3)      /* hipLaunch / hip runtime error */
+
+#define IIF_F32 0
+#define IIF_BF16 1
+
+/* table variants: classification/custom.py:16-23 */
+#define IIF_RAW 0
+#define IIF_SMOOTH 1
+#define IIF_REL 2
+#define IIF_NORMIT 3
+#define IIF_GOMBIT 4
+#define IIF_BASE2 5
+#define IIF_BASE10 6
+
+/* library / build info: "iif_amd <version> gfx950" */
+const char* iif_version(void);
+
+/* ------------------------------------------------------------------ IIF head */
+
+/* HOST.  Per-class IIF weights from class counts.
+ * Replaces the table construction of classification/custom.py:14-26
+ * (float64 arithmetic, one cast to float32, optional division by the p-norm
+ * of the float32 vector when norm_p > 0).  out_host: float[C]. */
+int iif_build_table(const int64_t* counts_host, int C, int variant, int norm_p, float* out_host);
+
+/* Fused IIF softmax cross-entropy, forward + gradient in ONE pass over logits.
+ * Replaces classification/custom.py:28-36 (pred*iif -> CrossEntropyLoss('none',
+ * weight) -> mean/sum), custom.py:116-117 (mixup criterion: pass targets_b and
+ * lam) and mmdet/models/losses/iif_loss.py:184-202 + losses/utils.py:42-55
+ * (row weights, ignore_index, avg_factor folded into `scale`).
+ *
+ *   z_i      = logits_i * table                               (row i, C classes)
+ *   nll(i,t) = logsumexp(z_i) - z_i[t]   (0 if t == ignore_index)
+ *   r_i      = row_weight_i * ( lam*cw[ta_i]*nll(i,ta_i) + (1-lam)*cw[tb_i]*nll(i,tb_i) )
+ *   loss     = scale * sum_i r_i            (scale = 1/B for 'mean', 1 for 'sum',
+ *                                            loss_weight/avg_factor for mmdet)
+ *   dlogits[i,c] = scale * d r_i / d logits[i,c]
+ *
+ * logits/dlogits: [B, C] row-major with leading dimensions ld_logits / ld_dlogits
+ * (elements), dtype IIF_F32 or IIF_BF16 (math is fp32 either way).
+ * targets_b == NULL means no mixup (lam ignored).  row_weight / class_weight may
+ * be NULL (= ones).  loss_per_row: float[B] (required; receives r_i, the
+ * reduction='none' value).  loss_out: float[1] or NULL.  dlogits may be NULL
+ * (loss only).  d_status: int32[1] or NULL; set to 1 if any target is outside
+ * [0,C) and != ignore_index (such rows contribute 0).
+ * Deterministic: the row sum is a fixed-order tree, no float atomics. */
+int iif_ce_fwd_bwd(const void* logits, int dtype, int64_t ld_logits,
+                   const float* table, const int64_t* targets_a, const int64_t* targets_b,
+                   float lam, const float* row_weight, const float* class_weight,
+                   int64_t ignore_index, float scale, int B, int C,
+                   float* loss_per_row, float* loss_out,
+                   void* dlogits, int64_t ld_dlogits, int32_t* d_status, void* stream);
+
+/* out = logits * table.  Replaces classification/custom.py:37-39 (infer=True). */
+int iif_scale_logits(const void* logits, int dtype, int64_t ld_logits, const float* table,
+                     int B, int C, void* out, int64_t ld_out, void* stream);
+
+/* out = softmax(logits * table, dim=-1), fp32 out.
+ * Replaces mmdet/models/losses/iif_loss.py:65-78 (get_activation). */
+int iif_softmax(const void* logits, int dtype, int64_t ld_logits, const float* table,
+                int B, int C, float* out, int64_t ld_out, void* stream);
+
+/* Top-k hit counts.  hits[j] += #rows whose target ranks < k[j] in
+ * logits*table (table NULL = raw logits); rank = #greater + #equal-with-lower-index.
+ * Replaces classification/utils.py:165-179 and mmdet/models/losses/accuracy.py:7-51
+ * (callers turn counts into percent).  hits: int32[nk], zeroed by the caller;
+ * integer atomics => exact and order independent.  nk <= 4. */
+int iif_topk_hits(const void* logits, int dtype, int64_t ld_logits, const float* table,
+                  const int64_t* targets, int B, int C, const int32_t* k_host, int nk,
+                  int32_t* hits, void* stream);
+
+/* x[i] *= *d_scalar (device scalar).  Used by the autograd bridge to apply the
+ * upstream gradient of the scalar loss without a host sync. */
+int iif_scale_by_device_scalar(void* x, int dtype, int64_t n, const float* d_scalar, void* stream);
+
+/* out[b,:] = lam*x[b,:] + (1-lam)*x[perm[b],:], rows of n elements.
+ * Replaces the image blend of classification/custom.py:112 (Mixup.__call__). */
+int iif_mix_rows(const void* x, int dtype, const int64_t* perm, float lam, int B, int64_t n,
+                 void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IIF_AMD_H */

@@ -1,0 +1,124 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol the
+header declares, the ctypes table covers them all, and the HOST entry point
+(iif_build_table) agrees with the golden tables.  No device work."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from iif_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "iif_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(iif_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    names = header_symbols()
+    assert "iif_ce_fwd_bwd" in names and "iif_version" in names
+    for n in names:
+        assert hasattr(lib, n), "libiif_amd.so does not export %s" % n
+    assert lib.iif_version().decode().startswith("iif_amd")
+
+
+def test_ctypes_table_covers_header():
+    assert sorted(list(_lib.SIGNATURES) + ["iif_version"]) == header_symbols()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libiif_amd.so")
+    with pytest.raises(_lib.IIFNativeError):
+        _lib.lib()
+
+
+def test_cpu_tensor_is_rejected_not_emulated():
+    import torch
+    from iif_amd.custom import IIFLoss
+
+    class DS:
+        def get_cls_num_list(self):
+            return [500, 100, 20, 5]
+    crit = IIFLoss(DS(), device="cpu")
+    with pytest.raises(_lib.IIFNativeError):
+        crit(torch.randn(2, 4), torch.tensor([0, 1]))
+
+
+@pytest.mark.parametrize("name", ["c4", "cifar100_exp100", "places365", "imagenet1000", "lvis1204"])
+def test_host_build_table_matches_golden(golden, name):
+    g = golden("g3_tables")
+    counts = np.ascontiguousarray(g[name + "_counts"], dtype=np.int64)
+    C = len(counts)
+    lib = _lib.lib()
+    worst = 0
+    for norm in (0, 1, 2):
+        for v, code in _lib.VARIANT_CODE.items():
+            out = np.empty(C, dtype=np.float32)
+            rc = lib.iif_build_table(counts.ctypes.data, C, code, norm, out.ctypes.data)
+            assert rc == 0
+            ref = g["%s_n%d_%s" % (name, norm, v)].reshape(-1)
+            ulp = np.abs(out.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)).max()
+            if norm == 0:
+                # libm vs numpy/scipy differ by at most the last float32 bit
+                worst = max(worst, int(ulp))
+                assert ulp <= 1, (name, norm, v, int(ulp))
+            else:
+                # the divisor is torch's float32 p-norm (custom.py:25-26); its CPU accumulation
+                # order is not reproduced in C (double accumulation here) -> relative 2e-6
+                np.testing.assert_allclose(out, ref, rtol=2e-6, atol=2e-6 * float(np.abs(ref).max()))
+    assert worst <= 1
+
+
+def test_host_build_table_rejects_bad_arguments():
+    lib = _lib.lib()
+    out = np.empty(4, dtype=np.float32)
+    counts = np.array([1, 2, 3, 4], dtype=np.int64)
+    assert lib.iif_build_table(0, 4, 0, 0, out.ctypes.data) == -1
+    assert lib.iif_build_table(counts.ctypes.data, 0, 0, 0, out.ctypes.data) == -1
+    assert lib.iif_build_table(counts.ctypes.data, 4, 9, 0, out.ctypes.data) == -1
+
+
+def test_python_tables_bit_exact_with_golden(golden):
+    import torch
+    from iif_amd.custom import build_tables
+    g = golden("g3_tables")
+    for name in ("c4", "cifar100_exp100", "imagenet1000", "lvis1204"):
+        counts = g[name + "_counts"].tolist()
+        for norm in (0, 1, 2):
+            tabs = build_tables(counts, norm)
+            for v in tabs:
+                assert torch.equal(tabs[v], torch.from_numpy(g["%s_n%d_%s" % (name, norm, v)])), (name, norm, v)
+
+
+def test_c_oracle_matches_golden(golden):
+    """The plain-C restatement (oracle/iif_oracle.c) against the reference's vectors."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libiif_oracle.so"))
+    lib.iif_oracle_ce.restype = ctypes.c_double
+    P, D, I, L = ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_int64
+    lib.iif_oracle_ce.argtypes = [P, P, P, P, D, P, P, L, D, I, I, P, P]
+    g, t = golden("g4_loss"), golden("g3_tables")
+    for name in ("c4", "cifar100_exp100", "imagenet1000"):
+        pred = np.ascontiguousarray(g[name + "_pred"]); tgt = np.ascontiguousarray(g[name + "_targets"])
+        cw = np.ascontiguousarray(g[name + "_class_weight"], dtype=np.float32)
+        B, C = pred.shape
+        for v in ("raw", "gombit"):
+            tab = np.ascontiguousarray(t["%s_n0_%s" % (name, v)].reshape(-1))
+            for red, scale in (("mean", 1.0 / B), ("sum", 1.0)):
+                for wname, w in (("nw", None), ("cw", cw)):
+                    rows = np.empty(B); d = np.empty((B, C))
+                    loss = lib.iif_oracle_ce(pred.ctypes.data, tab.ctypes.data, tgt.ctypes.data, None, 1.0, None,
+                                             None if w is None else w.ctypes.data, -100, scale, B, C,
+                                             rows.ctypes.data, d.ctypes.data)
+                    key = "%s_%s_%s_%s" % (name, v, red, wname)
+                    ref_l, ref_d = float(g[key + "_loss"]), g[key + "_dpred"]
+                    assert abs(loss - ref_l) <= 2e-6 * max(1.0, abs(ref_l)), key
+                    assert np.abs(d - ref_d).max() <= 2e-6 * max(1.0, np.abs(ref_d).max()), key
