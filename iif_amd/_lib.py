@@ -29,7 +29,16 @@ SIGNATURES = {
     "iif_topk_hits": [_P, _I, _L, _P, _P, _I, _I, _P, _I, _P, _P],
     "iif_scale_by_device_scalar": [_P, _I, _L, _P, _P],
     "iif_mix_rows": [_P, _I, _P, _F, _I, _L, _P, _P],
+    "iif_conv_igemm": [_P, _P, _P, _P, _P, _P, _P],
 }
+
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``iif_conv_desc`` (include/iif_amd.h)."""
+    _fields_ = [(k, ctypes.c_int32) for k in ("n", "hs", "ws", "cs", "hd", "wd", "cd", "r", "s", "stride", "pad",
+                                               "transposed", "ldw", "dtype", "dst_dtype")]
+
 
 _lib = None
 

@@ -1,0 +1,271 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores (forward and data-gradient).
+//
+//   dst[m, n] = sum_{tap, c} gather(src)[m, tap, c] * wgt[n, tap, c]   (+ bias[n]) (+ res[m, n])
+//
+// m = (image, y, x) of the DESTINATION grid, n = destination channel.  Activations
+// are NHWC, weights are [n][R][S][c] so both operands are K-contiguous: a 16-byte
+// piece (8 bf16 / 4 f32 channels of one tap) is the unit of every global load,
+// LDS write and MFMA fragment read.  `transposed` switches the gather between the
+// forward correlation (ys = y*stride - pad + r) and the data-gradient form
+// (ys = (y + pad - r)/stride when divisible), so the same kernel computes
+// conv2d forward, conv2d dgrad (with [cin][R][S][cout] weights), 1x1 GEMMs and
+// the fully-connected layer.  Replaces the cuDNN/MIOpen calls under
+// classification/resnet_pytorch.py:46-62,149-169 and resnet_cifar.py:133-138.
+//
+// Tiling (one 256-thread workgroup = 4 wavefronts of 64):
+//   block tile 128 pixels x BN channels (BN = 128 or 64), K step = 64 bytes of
+//   channels (32 bf16 / 16 f32); wave tile 64 pixels x BN/2 channels as 16x16 MFMA
+//   tiles: v_mfma_f32_16x16x32_bf16 (bf16) or 4 x v_mfma_f32_16x16x4_f32 (exact
+//   fp32 parity mode, k-ordered fmaf chain).  The MFMA "row" operand is the weight
+//   tile, so each lane ends with 4 consecutive output channels of one pixel
+//   (8-byte bf16 / 16-byte f32 stores).
+//   LDS: 2 x (128 + BN) x 64 B, double buffered, register staged (global loads of
+//   step k+1 are in flight while step k is multiplied).  Rows are 64 B, so the
+//   four 16-byte chunks of a row are XOR-swizzled by f(row>>2) = {0,2,3,1} which
+//   makes every ds_read_b128 lane group hit 16 distinct 16-byte bank slots.
+//   blockIdx -> tile map is XCD-aware: the n-tiles of one pixel tile run
+//   back-to-back on the same XCD so the activation tile is re-read from its L2.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct ET;
+template <> struct ET<unsigned short> { static constexpr int PE = 8, KE = 32; };   // bf16 bits
+template <> struct ET<float> { static constexpr int PE = 4, KE = 16; };
+
+struct ConvArgs {
+    const unsigned char* src; const unsigned char* wgt; unsigned char* dst; const unsigned char* res;
+    const float* bias;
+    int N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, sshift, pad, transposed, ldw, M, K, mtiles, ntiles;
+};
+
+__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+
+template <typename T, int BN, bool OUTF32>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
+    constexpr int BM = 128;
+    constexpr int PE = ET<T>::PE, KE = ET<T>::KE;
+    constexpr int NB = BN / 64;         // weight pieces per thread
+    constexpr int CI = BN / 32;         // channel 16-tiles per wave
+    constexpr int BUF = (BM + BN) * 64;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int mt = (j / a.ntiles) * 8 + xcd, nt = j % a.ntiles;
+    if (mt >= a.mtiles) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- per-thread staging geometry: rows (tid>>2) + 64*i, chunk tid&3
+    const int chunk = tid & 3, row0 = tid >> 2;
+    int by[2], bx[2], ib[2];
+    bool mv[2];
+    const int HW = a.Hd * a.Wd;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + row0 + 64 * i;
+        mv[i] = m < a.M;
+        const int mm = mv[i] ? m : 0;
+        const int n = mm / HW, rem = mm - n * HW;
+        const int y = rem / a.Wd, x = rem - y * a.Wd;
+        by[i] = a.transposed ? y + a.pad : (y << a.sshift) - a.pad;
+        bx[i] = a.transposed ? x + a.pad : (x << a.sshift) - a.pad;
+        ib[i] = n * a.Hs * a.Ws;
+    }
+    int e = chunk * PE;                 // K index of this thread's piece
+    int tap = e / a.Cs;
+    int c = e - tap * a.Cs;
+    int r = tap / a.S;
+    int s = tap - r * a.S;
+
+    u32x4 ra[2], rb[NB];
+    auto load_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int ys, xs;
+            bool ok = mv[i] && r < a.R;
+            if (a.transposed) {
+                const int ty = by[i] - r, tx = bx[i] - s;
+                ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & a.sshift) == 0;
+                ys = ty >> a.sshift; xs = tx >> a.sshift;
+                ok = ok && ys < a.Hs && xs < a.Ws;
+            } else {
+                ys = by[i] + r; xs = bx[i] + s;
+                ok = ok && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
+            }
+            ra[i] = u32x4{0u, 0u, 0u, 0u};
+            if (ok) {
+                const int64_t off = ((int64_t)(ib[i] + ys * a.Ws + xs) * a.Cs + c) * (int64_t)sizeof(T);
+                ra[i] = *reinterpret_cast<const u32x4*>(a.src + off);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int n = n0 + row0 + 64 * i;
+            rb[i] = u32x4{0u, 0u, 0u, 0u};
+            if (n < a.Cd && e < a.K) {
+                const int64_t off = ((int64_t)n * a.ldw + e) * (int64_t)sizeof(T);
+                rb[i] = *reinterpret_cast<const u32x4*>(a.wgt + off);
+            }
+        }
+    };
+    auto advance = [&]() {
+        e += KE;
+        c += KE;
+        while (c >= a.Cs) { c -= a.Cs; if (++s == a.S) { s = 0; ++r; } }
+    };
+    auto store_step = [&](int buf) {
+        unsigned char* A = smem + buf * BUF;
+        unsigned char* B = A + BM * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = row0 + 64 * i;
+            *reinterpret_cast<u32x4*>(A + row * 64 + ((chunk ^ swz(row)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = row0 + 64 * i;
+            *reinterpret_cast<u32x4*>(B + row * 64 + ((chunk ^ swz(row)) << 4)) = rb[i];
+        }
+    };
+
+    f32x4 acc[CI][4];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) acc[ci][pj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (a.K + KE - 1) / KE;
+    const int fr = lane & 15, fc = lane >> 4;     // fragment row within a 16-tile, 16-byte chunk
+    load_step();
+    store_step(0);
+    __syncthreads();
+    for (int k = 0; k < nk; ++k) {
+        const bool more = k + 1 < nk;
+        if (more) { advance(); load_step(); }
+        const unsigned char* A = smem + (k & 1) * BUF;
+        const unsigned char* B = A + BM * 64;
+        u32x4 wf[CI], xf[4];
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+            const int row = wn * (BN / 2) + ci * 16 + fr;
+            wf[ci] = *reinterpret_cast<const u32x4*>(B + row * 64 + ((fc ^ swz(row)) << 4));
+        }
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) {
+            const int row = wm * 64 + pj * 16 + fr;
+            xf[pj] = *reinterpret_cast<const u32x4*>(A + row * 64 + ((fc ^ swz(row)) << 4));
+        }
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) {
+                if constexpr (sizeof(T) == 2) {
+                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wf[ci]), __builtin_bit_cast(bf16x8, xf[pj]), acc[ci][pj], 0, 0, 0);
+                } else {
+                    const f32x4 wv = __builtin_bit_cast(f32x4, wf[ci]), xv = __builtin_bit_cast(f32x4, xf[pj]);
+                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc[ci][pj], 0, 0, 0);
+                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc[ci][pj], 0, 0, 0);
+                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[ci][pj], 0, 0, 0);
+                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[ci][pj], 0, 0, 0);
+                }
+            }
+        if (more) store_step((k + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels n0 + wn*BN/2 + ci*16 + fc*4 + {0..3} of pixel m0 + wm*64 + pj*16 + fr
+    using OT = typename std::conditional<OUTF32, float, T>::type;
+    const bool vec_ok = (a.Cd & 3) == 0;
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) {
+        const int m = m0 + wm * 64 + pj * 16 + fr;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+            const int n = n0 + wn * (BN / 2) + ci * 16 + fc * 4;
+            if (n >= a.Cd) continue;
+            float v[4] = {acc[ci][pj].x, acc[ci][pj].y, acc[ci][pj].z, acc[ci][pj].w};
+            const int64_t o = (int64_t)m * a.Cd + n;
+            const int cnt = a.Cd - n < 4 ? a.Cd - n : 4;
+            if (a.bias)
+                for (int q = 0; q < cnt; ++q) v[q] += a.bias[n + q];
+            OT* dp = reinterpret_cast<OT*>(a.dst) + o;
+            const OT* rp = reinterpret_cast<const OT*>(a.res) + o;
+            if (vec_ok) {
+                if constexpr (sizeof(OT) == 4) {
+                    if (a.res) { const f32x4 t = *reinterpret_cast<const f32x4*>(rp); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                    *reinterpret_cast<f32x4*>(dp) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    if (a.res) {
+                        const u32x2 t = *reinterpret_cast<const u32x2*>(rp);
+                        v[0] += bf16_bits_to_f32(t.x & 0xffffu); v[1] += __uint_as_float(t.x & 0xffff0000u);
+                        v[2] += bf16_bits_to_f32(t.y & 0xffffu); v[3] += __uint_as_float(t.y & 0xffff0000u);
+                    }
+                    u32x2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(dp) = w;
+                }
+            } else {
+                for (int q = 0; q < cnt; ++q) {
+                    if constexpr (sizeof(OT) == 4) {
+                        float t = v[q]; if (a.res) t += rp[q];
+                        dp[q] = t;
+                    } else {
+                        float t = v[q]; if (a.res) t += bf16_bits_to_f32(rp[q]);
+                        dp[q] = f32_to_bf16_bits(t);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, bool OUTF32>
+int launch_conv(const ConvArgs& a0, hipStream_t st) {
+    ConvArgs a = a0;
+    a.mtiles = (a.M + 127) / 128;
+    const bool narrow = a.Cd <= 64;
+    const int bn = narrow ? 64 : 128;
+    a.ntiles = (a.Cd + bn - 1) / bn;
+    const int64_t blocks = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
+    if (blocks > 0x7fffffff) return IIF_EUNSUPPORTED;
+    if (narrow) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, OUTF32>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<T, 128, OUTF32>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+}  // namespace
+
+extern "C" int iif_conv_igemm(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                              const float* bias, void* stream) {
+    if (!d || !src || !wgt || !dst) return IIF_EINVAL;
+    if (d->n <= 0 || d->hs <= 0 || d->ws <= 0 || d->cs <= 0 || d->hd <= 0 || d->wd <= 0 || d->cd <= 0 ||
+        d->r <= 0 || d->s <= 0 || d->pad < 0)
+        return IIF_EINVAL;
+    if (d->stride != 1 && d->stride != 2) return IIF_EUNSUPPORTED;
+    if (d->dtype != IIF_F32 && d->dtype != IIF_BF16) return IIF_EINVAL;
+    if (d->dst_dtype != d->dtype && d->dst_dtype != IIF_F32) return IIF_EINVAL;
+    const int pe = d->dtype == IIF_F32 ? 4 : 8;
+    if (d->cs % pe != 0 || d->ldw % pe != 0 || d->ldw < d->r * d->s * d->cs) return IIF_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(wgt) | reinterpret_cast<uintptr_t>(dst) |
+         reinterpret_cast<uintptr_t>(res)) & 15)
+        return IIF_EUNSUPPORTED;
+    const int64_t M = (int64_t)d->n * d->hd * d->wd;
+    if (M > 0x7fffff00LL || (int64_t)d->n * d->hs * d->ws > 0x7fffff00LL) return IIF_EUNSUPPORTED;
+    ConvArgs a{};
+    a.src = (const unsigned char*)src; a.wgt = (const unsigned char*)wgt; a.dst = (unsigned char*)dst;
+    a.res = (const unsigned char*)res; a.bias = bias;
+    a.N = d->n; a.Hs = d->hs; a.Ws = d->ws; a.Cs = d->cs; a.Hd = d->hd; a.Wd = d->wd; a.Cd = d->cd;
+    a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.transposed = d->transposed ? 1 : 0;
+    a.ldw = d->ldw; a.M = (int)M; a.K = d->r * d->s * d->cs;
+    hipStream_t st = as_stream(stream);
+    if (d->dtype == IIF_BF16) {
+        if (d->dst_dtype == IIF_F32) return launch_conv<unsigned short, true>(a, st);
+        return launch_conv<unsigned short, false>(a, st);
+    }
+    return launch_conv<float, true>(a, st);
+}

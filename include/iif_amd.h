@@ -109,6 +109,35 @@ int iif_scale_by_device_scalar(void* x, int dtype, int64_t n, const float* d_sca
 int iif_mix_rows(const void* x, int dtype, const int64_t* perm, float lam, int B, int64_t n,
                  void* out, void* stream);
 
+/* ------------------------------------------------------- ResNet forward/backward */
+
+/* Geometry of one convolution-shaped contraction (all tensors NHWC).
+ * "source" is what the taps gather from, "destination" is the output grid. */
+typedef struct iif_conv_desc {
+    int32_t n, hs, ws, cs;   /* source      [n, hs, ws, cs]                       */
+    int32_t hd, wd, cd;      /* destination [n, hd, wd, cd]                       */
+    int32_t r, s;            /* taps                                               */
+    int32_t stride, pad;     /* of the FORWARD convolution (stride 1 or 2)         */
+    int32_t transposed;      /* 0: ys = y*stride - pad + r   (forward)             */
+                             /* 1: ys = (y + pad - r)/stride (data gradient)       */
+    int32_t ldw;             /* weight row pitch in elements (>= r*s*cs, 16-B mult) */
+    int32_t dtype;           /* IIF_F32 / IIF_BF16 of src and wgt                  */
+    int32_t dst_dtype;       /* dtype of dst / res: == dtype, or IIF_F32           */
+} iif_conv_desc;
+
+/* Implicit-GEMM convolution on the matrix cores:
+ *   dst[m, k] = sum_{r,s,c} gather(src)[m; r,s,c] * wgt[k][r][s][c]  (+ bias[k]) (+ res[m, k])
+ * wgt: [cd][ldw] rows of r*s*cs K-contiguous elements.  With transposed=0 and
+ * KRSC weights this is conv2d forward (resnet_pytorch.py:46-62 conv3x3/conv1x1,
+ * resnet_cifar.py:112-115); with transposed=1 and [cin][R][S][cout] weights it is
+ * the data gradient; r=s=1 on a [B,1,1,C] tensor is the fully connected layer
+ * (resnet_pytorch.py:219, resnet_cifar.py:192) with `bias`.  res (nullable, same
+ * shape/dtype as dst, may alias dst) is added in the epilogue: gradient
+ * accumulation at residual joins.  bf16 inputs multiply on v_mfma_f32_16x16x32_bf16
+ * with fp32 accumulation; f32 inputs on v_mfma_f32_16x16x4_f32 (exact fp32). */
+int iif_conv_igemm(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
+                   const void* res, const float* bias, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,99 @@
+"""GPU parity of the implicit-GEMM convolution kernels against torch CPU
+conv2d (the third-party kernel the reference dispatches to).
+fp32 mode: exact-fp32 MFMA, tolerance 1e-5 relative to sum|a*b| scale.
+bf16 mode: inputs rounded to bf16 on both sides, fp32 accumulate; the only
+difference left is summation order and the final bf16 rounding (2^-8)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def krsc(w, pe):
+    """OIHW -> [Cout, R*S*Cin padded to a multiple of pe]"""
+    co, ci, r, s = w.shape
+    flat = w.permute(0, 2, 3, 1).reshape(co, r * s * ci)
+    k = flat.shape[1]
+    kp = (k + pe - 1) // pe * pe
+    out = torch.zeros(co, kp, dtype=w.dtype)
+    out[:, :k] = flat
+    return out
+
+
+CASES = [
+    # N, Cin, H, W, Cout, R, stride, pad
+    (2, 64, 14, 14, 64, 3, 1, 1),
+    (2, 64, 15, 13, 128, 3, 2, 1),
+    (3, 128, 9, 9, 256, 1, 1, 0),
+    (2, 256, 10, 10, 512, 1, 2, 0),
+    (2, 16, 12, 12, 16, 3, 1, 1),       # Cin=16: two taps per bf16 K step, ragged K tail
+    (2, 16, 12, 12, 32, 3, 2, 1),
+    (1, 32, 7, 7, 1000, 1, 1, 0),       # Cout not a multiple of the tile
+    (5, 8, 6, 6, 24, 3, 1, 1),
+    (2, 512, 7, 7, 512, 3, 1, 1),       # long K
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_conv_forward_and_dgrad(case, dt):
+    from iif_amd import ops
+    n, cin, h, w, cout, r, stride, pad = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(n, cin, h, w, generator=g).to(dt).float()
+    wt = (torch.randn(cout, cin, r, r, generator=g) / (cin * r * r) ** 0.5).to(dt).float()
+    pe = 4 if dt == torch.float32 else 8
+    ref = F.conv2d(x, wt, None, stride, pad)
+    y = ops.conv_forward(nhwc(x).to(dt).to(DEV), krsc(wt, pe).to(dt).to(DEV), r, r, stride, pad)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    scale = ref.abs().max().item()
+    tol = 2e-5 if dt == torch.float32 else 2.0 ** -7
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= tol * scale, (case, dt)
+    # data gradient: dX = conv_transpose(dY, W)
+    dy = torch.randn(ref.shape, generator=g).to(dt).float()
+    refdx = torch.nn.grad.conv2d_input(x.shape, wt, dy, stride, pad)
+    wtt = wt.permute(1, 0, 2, 3).contiguous()           # [Cin, Cout, R, S] -> rows over (r,s,cout)
+    dx = ops.conv_dgrad(nhwc(dy).to(dt).to(DEV), krsc(wtt, pe).to(dt).to(DEV), r, r, stride, pad, (h, w))
+    gotdx = dx.float().cpu().permute(0, 3, 1, 2)
+    assert (gotdx - refdx).abs().max().item() <= tol * refdx.abs().max().item(), (case, dt)
+    # epilogue residual (gradient accumulation at a residual join), aliasing dst
+    acc = nhwc(torch.randn(x.shape, generator=g).to(dt).float()).to(dt).to(DEV)
+    exp = gotdx + acc.float().cpu().permute(0, 3, 1, 2)
+    ops.conv_dgrad(nhwc(dy).to(dt).to(DEV), krsc(wtt, pe).to(dt).to(DEV), r, r, stride, pad, (h, w), out=acc, res=acc)
+    assert (acc.float().cpu().permute(0, 3, 1, 2) - exp).abs().max().item() <= tol * exp.abs().max().item()
+
+
+def test_fc_layer_bias_fp32_out():
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for dt in (torch.float32, torch.bfloat16):
+        for cout in (1000, 365, 100):
+            x = torch.randn(37, 2048, generator=g).to(dt).float()
+            w = (torch.randn(cout, 2048, generator=g) / 45.0).to(dt).float()
+            b = torch.randn(cout, generator=g)
+            ref = F.linear(x, w, b)
+            y = ops.conv_forward(x.view(37, 1, 1, 2048).to(dt).to(DEV), w.to(dt).to(DEV), 1, 1, 1, 0,
+                                 out_dtype=torch.float32, bias=b.to(DEV))
+            assert y.dtype == torch.float32
+            got = y.cpu().view(37, cout)
+            tol = 2e-5 if dt == torch.float32 else 1e-4
+            assert (got - ref).abs().max().item() <= tol * ref.abs().max().item(), (dt, cout)
+
+
+def test_conv_rejects_bad_shapes():
+    from iif_amd import ops, _lib
+    x = torch.zeros(1, 4, 4, 6, device=DEV)           # Cin=6 not a multiple of 4
+    w = torch.zeros(8, 56, device=DEV)
+    with pytest.raises(_lib.IIFNativeError):
+        ops.conv_forward(x, w, 3, 3, 1, 1)
+    x = torch.zeros(1, 4, 4, 8, device=DEV)
+    w = torch.zeros(8, 72, device=DEV)
+    with pytest.raises(_lib.IIFNativeError):
+        ops.conv_forward(x, w, 3, 3, 3, 1)            # stride 3 unsupported
