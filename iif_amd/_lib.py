@@ -30,6 +30,7 @@ SIGNATURES = {
     "iif_scale_by_device_scalar": [_P, _I, _L, _P, _P],
     "iif_mix_rows": [_P, _I, _P, _F, _I, _L, _P, _P],
     "iif_conv_igemm": [_P, _P, _P, _P, _P, _P, _P],
+    "iif_conv_wgrad": [_P, _P, _P, _P, _P, _L, _I, _P],
 }
 
 

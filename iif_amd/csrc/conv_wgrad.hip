@@ -1,0 +1,285 @@
+// Weight gradient of a convolution as an MFMA contraction over pixels (gfx950).
+//
+//   dW[k][r][s][c] = sum_m dY[m, k] * gather(X)[m; r,s,c]        m = (image, y, x)
+//
+// Both operands have the reduction index (the pixel) as their slow dimension, so
+// the tiles are staged pixel-major ([pixel][channel], exactly as they sit in HBM:
+// 16-byte channel pieces, coalesced) and the MFMA fragments are formed by the
+// gfx950 transposing LDS read ds_read_b64_tr_b16 (bf16) or by ds_read_b32 column
+// reads (exact-fp32 mode).  Row pitches (cols*2+32 B bf16, cols*4+64 B f32) make
+// both read patterns bank-conflict free.
+//
+// Block tile: BC output channels x 128 (tap,channel) columns, 32 (bf16) / 16 (f32)
+// pixels per K step, double-buffered LDS, register-staged prefetch.  The pixel
+// range is split across gridDim.y (split-K) into fp32 slabs that a second kernel
+// sums in fixed order: deterministic, no float atomics.
+// Replaces the cuDNN/MIOpen wgrad calls autograd issues for
+// classification/resnet_pytorch.py:46-62 and resnet_cifar.py:112-115.
+#include "common.h"
+
+namespace {
+
+struct WgArgs {
+    const unsigned char* x; const unsigned char* dy; float* out;
+    int N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, sshift, pad, ldw, M, K;
+    int ktiles, ntiles, steps_per_split, nsteps;
+    int64_t slab;          // elements between split slabs (0 when writing dW directly)
+};
+
+template <typename T> struct WT;
+template <> struct WT<unsigned short> {
+    static constexpr int PE = 8, ROWS = 32;
+    static constexpr int pitch(int cols) { return cols * 2 + 32; }
+};
+template <> struct WT<float> {
+    static constexpr int PE = 4, ROWS = 16;
+    static constexpr int pitch(int cols) { return cols * 4 + 64; }
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+}
+
+template <typename T, int BC>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgArgs a) {
+    constexpr int PE = WT<T>::PE, ROWS = WT<T>::ROWS;
+    constexpr int BNW = 128;
+    constexpr int PX = WT<T>::pitch(BNW), PY = WT<T>::pitch(BC);
+    constexpr int XB = ROWS * PX, YB = ROWS * PY, BUF = XB + YB;
+    constexpr int PPRX = BNW / PE;                 // pieces per X-tile row
+    constexpr int RPPX = 256 / PPRX;               // rows covered per pass (X): 16 (bf16) / 8 (f32)
+    constexpr int PPRY = BC / PE;
+    constexpr int RPPY = 256 / PPRY;
+    constexpr int NPY = ROWS / RPPY;               // passes for the dY tile: 2 (BC=128) / 1 (BC=64)
+    constexpr int KJ = BC / 32;                    // cout 16-tiles per wave
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;       // wave tile: 64 columns x BC/2 channels
+    const int kt = blockIdx.x % a.ktiles, ntile = blockIdx.x / a.ktiles;
+    const int k0 = kt * BC, n0 = ntile * BNW;
+    const int split = blockIdx.y;
+    const int step0 = split * a.steps_per_split;
+    int step1 = step0 + a.steps_per_split;
+    if (step1 > a.nsteps) step1 = a.nsteps;
+
+    // ---- X gather geometry: this thread's column piece is fixed, its 2 pixel rows advance by ROWS
+    const int xchunk = tid % PPRX, xrow0 = tid / PPRX;
+    const int ncol = n0 + xchunk * PE;
+    const bool nvalid = ncol < a.K;
+    int tap = ncol / a.Cs;
+    const int cch = ncol - tap * a.Cs;
+    const int tr = tap / a.S, ts = tap - tr * a.S;
+    int py[2], px[2], pb[2], pm[2];
+    const int HW = a.Hd * a.Wd, HWs = a.Hs * a.Ws;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = step0 * ROWS + xrow0 + RPPX * i;
+        pm[i] = m;
+        const int n = m / HW, rem = m - n * HW;
+        py[i] = rem / a.Wd; px[i] = rem - py[i] * a.Wd; pb[i] = n * HWs;
+    }
+    const int ychunk = tid % PPRY, yrow0 = tid / PPRY;
+    const int kcol = k0 + ychunk * PE;
+    const bool kvalid = kcol < a.Cd;
+
+    u32x4 rx[2], ry[NPY];
+    auto load_step = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ys = (py[i] << a.sshift) - a.pad + tr, xs = (px[i] << a.sshift) - a.pad + ts;
+            rx[i] = u32x4{0u, 0u, 0u, 0u};
+            if (nvalid && pm[i] < a.M && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws) {
+                const int64_t off = ((int64_t)(pb[i] + ys * a.Ws + xs) * a.Cs + cch) * (int64_t)sizeof(T);
+                rx[i] = *reinterpret_cast<const u32x4*>(a.x + off);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NPY; ++i) {
+            const int m = step * ROWS + yrow0 + RPPY * i;
+            ry[i] = u32x4{0u, 0u, 0u, 0u};
+            if (kvalid && m < a.M) {
+                const int64_t off = ((int64_t)m * a.Cd + kcol) * (int64_t)sizeof(T);
+                ry[i] = *reinterpret_cast<const u32x4*>(a.dy + off);
+            }
+        }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            pm[i] += ROWS;
+            px[i] += ROWS;
+            while (px[i] >= a.Wd) {
+                px[i] -= a.Wd;
+                if (++py[i] == a.Hd) { py[i] = 0; pb[i] += HWs; }
+            }
+        }
+    };
+    auto store_step = [&](int buf) {
+        unsigned char* X = smem + buf * BUF;
+        unsigned char* Y = X + XB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<u32x4*>(X + (xrow0 + RPPX * i) * PX + xchunk * 16) = rx[i];
+#pragma unroll
+        for (int i = 0; i < NPY; ++i)
+            *reinterpret_cast<u32x4*>(Y + (yrow0 + RPPY * i) * PY + ychunk * 16) = ry[i];
+    };
+
+    f32x4 acc[4][KJ];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int kj = 0; kj < KJ; ++kj) acc[ni][kj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, li = lane & 15;
+    if (step0 < step1) {
+        load_step(step0);
+        store_step(0);
+    }
+    __syncthreads();
+    for (int step = step0; step < step1; ++step) {
+        const bool more = step + 1 < step1;
+        if (more) { advance(); load_step(step + 1); }
+        const unsigned char* X = smem + ((step - step0) & 1) * BUF;
+        const unsigned char* Y = X + XB;
+        if constexpr (sizeof(T) == 2) {
+            // fragment element j<4 <-> LDS row 4g+j, j>=4 <-> row 16+4g+(j-4) (same map for both operands)
+            const int q = li >> 2, p = li & 3;
+            s16x8 xf[4], yf[KJ];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const unsigned char* base = X + (4 * g + q) * PX + (wn * 64 + ni * 16 + 4 * p) * 2;
+                const s16x4 lo = tr_read(base), hi = tr_read(base + 16 * PX);
+                xf[ni] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int kj = 0; kj < KJ; ++kj) {
+                const unsigned char* base = Y + (4 * g + q) * PY + (wk * (BC / 2) + kj * 16 + 4 * p) * 2;
+                const s16x4 lo = tr_read(base), hi = tr_read(base + 16 * PY);
+                yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int kj = 0; kj < KJ; ++kj)
+                    acc[ni][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, xf[ni]), __builtin_bit_cast(bf16x8, yf[kj]), acc[ni][kj], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                float xf[4], yf[KJ];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    xf[ni] = *reinterpret_cast<const float*>(X + (4 * qq + g) * PX + (wn * 64 + ni * 16 + li) * 4);
+#pragma unroll
+                for (int kj = 0; kj < KJ; ++kj)
+                    yf[kj] = *reinterpret_cast<const float*>(Y + (4 * qq + g) * PY + (wk * (BC / 2) + kj * 16 + li) * 4);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int kj = 0; kj < KJ; ++kj)
+                        acc[ni][kj] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[ni], yf[kj], acc[ni][kj], 0, 0, 0);
+            }
+        }
+        if (more) store_step((step + 1 - step0) & 1);
+        __syncthreads();
+    }
+
+    // D[row = column n'][col = channel k]: lane holds 4 consecutive n' for channel k0 + .. + li
+    float* out = a.out + (int64_t)split * a.slab;
+#pragma unroll
+    for (int kj = 0; kj < KJ; ++kj) {
+        const int k = k0 + wk * (BC / 2) + kj * 16 + li;
+        if (k >= a.Cd) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + g * 4;
+            if (n >= a.K) continue;
+            *reinterpret_cast<f32x4*>(out + (int64_t)k * a.ldw + n) = acc[ni][kj];
+        }
+    }
+}
+
+// dw[k][n] = sum_s slab[s][k][n] for n < K (pad columns untouched), fixed order
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int splits, int64_t slab, int Cd, int ldw,
+                                                           int K, float* dw) {
+    const int64_t total4 = (int64_t)Cd * ldw / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i * 4;
+        const int n = (int)(e % ldw);
+        if (n >= K) continue;
+        f32x4 s = *reinterpret_cast<const f32x4*>(ws + e);
+        for (int j = 1; j < splits; ++j) s += *reinterpret_cast<const f32x4*>(ws + j * slab + e);
+        *reinterpret_cast<f32x4*>(dw + e) = s;
+    }
+}
+
+template <typename T>
+int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_req, hipStream_t st) {
+    constexpr int ROWS = WT<T>::ROWS;
+    const int bc = a.Cd <= 64 ? 64 : 128;
+    a.ktiles = (a.Cd + bc - 1) / bc;
+    a.ntiles = (a.K + 127) / 128;
+    a.nsteps = (a.M + ROWS - 1) / ROWS;
+    const int tiles = a.ktiles * a.ntiles;
+    int splits = splits_req;
+    if (splits <= 0) {
+        splits = (1024 + tiles - 1) / tiles;           // ~4 workgroups per CU
+        const int max_by_work = a.nsteps / 8 > 0 ? a.nsteps / 8 : 1;
+        if (splits > max_by_work) splits = max_by_work;
+    }
+    const int64_t slab = (int64_t)a.Cd * a.ldw;
+    const int64_t fit = ws ? ws_bytes / (slab * 4) : 0;
+    if (splits > fit) splits = (int)fit;
+    if (splits < 1) splits = 1;
+    if (splits > a.nsteps) splits = a.nsteps > 0 ? a.nsteps : 1;
+    if (splits > 65535) splits = 65535;
+    a.steps_per_split = (a.nsteps + splits - 1) / splits;
+    splits = (a.nsteps + a.steps_per_split - 1) / a.steps_per_split;
+    if (splits < 1) splits = 1;
+    a.slab = splits > 1 ? slab : 0;
+    a.out = splits > 1 ? ws : dw;
+    const dim3 grid(tiles, splits);
+    if (bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, st, a);
+    IIF_LAUNCH_CHECK();
+    if (splits > 1) {
+        const int64_t total4 = slab / 4;
+        const int blocks = (int)(cdiv64(total4, 256) < 2048 ? cdiv64(total4, 256) : 2048);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, splits, slab, a.Cd, a.ldw, a.K, dw);
+        IIF_LAUNCH_CHECK();
+    }
+    return IIF_OK;
+}
+
+}  // namespace
+
+extern "C" int iif_conv_wgrad(const iif_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
+                              int64_t workspace_bytes, int splits, void* stream) {
+    if (!d || !x || !dy || !dw) return IIF_EINVAL;
+    if (d->n <= 0 || d->hs <= 0 || d->ws <= 0 || d->cs <= 0 || d->hd <= 0 || d->wd <= 0 || d->cd <= 0 ||
+        d->r <= 0 || d->s <= 0 || d->pad < 0 || workspace_bytes < 0)
+        return IIF_EINVAL;
+    if (d->stride != 1 && d->stride != 2) return IIF_EUNSUPPORTED;
+    if (d->dtype != IIF_F32 && d->dtype != IIF_BF16) return IIF_EINVAL;
+    if (d->transposed) return IIF_EINVAL;
+    const int pe = d->dtype == IIF_F32 ? 4 : 8;
+    if (d->cs % pe != 0 || d->cd % pe != 0 || d->ldw % 4 != 0 || d->ldw < d->r * d->s * d->cs) return IIF_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dw) |
+         reinterpret_cast<uintptr_t>(workspace)) & 15)
+        return IIF_EUNSUPPORTED;
+    const int64_t M = (int64_t)d->n * d->hd * d->wd;
+    if (M > 0x7fffff00LL || (int64_t)d->n * d->hs * d->ws > 0x7fffff00LL) return IIF_EUNSUPPORTED;
+    WgArgs a{};
+    a.x = (const unsigned char*)x; a.dy = (const unsigned char*)dy;
+    a.N = d->n; a.Hs = d->hs; a.Ws = d->ws; a.Cs = d->cs; a.Hd = d->hd; a.Wd = d->wd; a.Cd = d->cd;
+    a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.ldw = d->ldw; a.M = (int)M;
+    a.K = d->r * d->s * d->cs;
+    hipStream_t st = as_stream(stream);
+    if (d->dtype == IIF_BF16)
+        return launch_wgrad<unsigned short>(a, dw, (float*)workspace, workspace_bytes, splits, st);
+    return launch_wgrad<float>(a, dw, (float*)workspace, workspace_bytes, splits, st);
+}

@@ -138,6 +138,18 @@ typedef struct iif_conv_desc {
 int iif_conv_igemm(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
                    const void* res, const float* bias, void* stream);
 
+/* Weight gradient: dw[k][r][s][c] = sum_m dy[m, k] * gather(x)[m; r,s,c], fp32 out.
+ * d describes the FORWARD convolution (source = x, destination = dy grid,
+ * transposed must be 0).  dw: float [cd][ldw] (columns >= r*s*cs are not
+ * written).  The pixel reduction is split over `splits` workgroup rows
+ * (0 = choose) into fp32 slabs in `workspace` (>= splits*cd*ldw*4 bytes; fewer
+ * splits are used if it is smaller, NULL = no split) that are then summed in
+ * fixed order: deterministic, no float atomics.  bf16 fragments are formed by
+ * ds_read_b64_tr_b16.  Replaces the wgrad half of autograd's conv backward for
+ * resnet_pytorch.py:46-62 / resnet_cifar.py:112-115 and the fc layer. */
+int iif_conv_wgrad(const iif_conv_desc* d, const void* x, const void* dy, float* dw,
+                   void* workspace, int64_t workspace_bytes, int splits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,3 +97,39 @@ def test_conv_rejects_bad_shapes():
     w = torch.zeros(8, 72, device=DEV)
     with pytest.raises(_lib.IIFNativeError):
         ops.conv_forward(x, w, 3, 3, 3, 1)            # stride 3 unsupported
+
+
+@pytest.mark.parametrize("case", CASES + [(4, 64, 28, 28, 64, 3, 1, 1), (2, 64, 33, 31, 256, 1, 1, 0)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_conv_wgrad(case, dt):
+    from iif_amd import ops
+    n, cin, h, w, cout, r, stride, pad = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 1)
+    x = torch.randn(n, cin, h, w, generator=g).to(dt).float()
+    ho, wo = ops.conv_out_hw(h, w, r, r, stride, pad)
+    dy = torch.randn(n, cout, ho, wo, generator=g).to(dt).float()
+    ref = torch.nn.grad.conv2d_weight(x, (cout, cin, r, r), dy, stride, pad)     # OIHW
+    ref = ref.permute(0, 2, 3, 1).reshape(cout, r * r * cin)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    tol = 2e-5 if dt == torch.float32 else 1e-4      # fp32 accumulate of exact bf16 products
+    for splits in (0, 1, 3):
+        dw = ops.conv_wgrad(nhwc(x).to(dt).to(DEV), nhwc(dy).to(dt).to(DEV), r, r, stride, pad, workspace=ws,
+                            splits=splits)
+        assert (dw.cpu() - ref).abs().max().item() <= tol * ref.abs().max().item(), (case, dt, splits)
+    # padded row pitch: pad columns stay untouched
+    ldw = r * r * cin + 16
+    out = torch.full((cout, ldw), 7.0, device=DEV)
+    ops.conv_wgrad(nhwc(x).to(dt).to(DEV), nhwc(dy).to(dt).to(DEV), r, r, stride, pad, ldw=ldw, out=out, workspace=ws)
+    assert (out[:, r * r * cin:] == 7.0).all()
+    assert (out[:, :r * r * cin].cpu() - ref).abs().max().item() <= tol * ref.abs().max().item()
+
+
+def test_wgrad_is_deterministic():
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(8, 28, 28, 64, generator=g).to(torch.bfloat16).to(DEV)
+    dy = torch.randn(8, 28, 28, 64, generator=g).to(torch.bfloat16).to(DEV)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    a = ops.conv_wgrad(x, dy, 3, 3, 1, 1, workspace=ws)
+    b = ops.conv_wgrad(x, dy, 3, 3, 1, 1, workspace=ws)
+    assert torch.equal(a, b)
