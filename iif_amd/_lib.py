@@ -31,6 +31,21 @@ SIGNATURES = {
     "iif_mix_rows": [_P, _I, _P, _F, _I, _L, _P, _P],
     "iif_conv_igemm": [_P, _P, _P, _P, _P, _P, _P],
     "iif_conv_wgrad": [_P, _P, _P, _P, _P, _L, _I, _P],
+    "iif_bn_workspace_bytes": [_L, _I],
+    "iif_bn_forward_stats": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _P],
+    "iif_bn_apply": [_P, _I, _L, _I, _P, _P, _P, _I, _P, _P],
+    "iif_bn_backward": [_P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P],
+    "iif_maxpool_forward": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "iif_maxpool_backward": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "iif_avgpool_forward": [_P, _I, _I, _I, _I, _P, _P],
+    "iif_avgpool_backward": [_P, _I, _I, _I, _I, _P, _P],
+    "iif_im2col_nchw": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "iif_cast": [_P, _I, _P, _I, _L, _P],
+    "iif_weight_transpose": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "iif_shortcut_a_forward": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "iif_shortcut_a_backward_acc": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "iif_colsum_f32": [_P, _I, _I, _L, _P, _P],
+    "iif_sgd_step": [_P, _P, _P, _L, _F, _P, _F, _F, _I, _F, _P],
 }
 
 
@@ -62,7 +77,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = argtypes
-            fn.restype = _I
+            fn.restype = _L if name == "iif_bn_workspace_bytes" else _I
         _lib = l
     return _lib
 

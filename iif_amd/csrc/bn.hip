@@ -1,0 +1,359 @@
+// Training-mode batch normalisation on NHWC activations, gfx950.
+//
+// The activation is a row-major [M, C] matrix (M = N*H*W pixels, C channels
+// fastest), so per-channel statistics are column reductions.  Every thread owns
+// one 16-byte channel vector (8 bf16 / 4 f32) and walks rows; a wave therefore
+// reads whole 128-byte lines.  All kernels are HBM-bound streaming passes:
+//   stats    : x -> per-block partial (sum, sumsq)            [1 read]
+//   finalize : partials -> mean, invstd, scale a, shift b, running stats (fp64 sums)
+//   apply    : y = relu?(a*x + b (+ a2*r + b2 | + r))          [1-2 reads, 1 write]
+//   bwd_red  : partial (sum dy, sum dy*xhat), dy = g * [y > 0] [2-3 reads]
+//   bwd_fin  : dgamma, dbeta, per-channel coefficients
+//   bwd_apply: dx = k1*(dy - k2 - (x-mean)*k3) (+ masked g out) [2-3 reads, 1-2 writes]
+// Partials are reduced in a fixed order (no float atomics): deterministic.
+// Replaces torch's batch_norm / relu / add forward+backward under
+// classification/resnet_pytorch.py:152-167 and resnet_cifar.py:133-138.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct VT;
+template <> struct VT<float> {
+    static constexpr int V = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+};
+template <> struct VT<unsigned short> {
+    static constexpr int V = 8;
+    static __device__ __forceinline__ void load(const unsigned short* p, float (&v)[8]) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_bits_to_f32(t[i] & 0xffffu); v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(unsigned short* p, const float (&v)[8]) {
+        u32x4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        *reinterpret_cast<u32x4*>(p) = t;
+    }
+};
+
+// thread -> (channel vector, row lane) for a [M, C] matrix
+struct Map {
+    int cvb;      // channel vectors handled per block row (<= 256)
+    int rpb;      // rows per block pass = 256 / cvb
+};
+
+struct Geo {
+    int M, C, cv, cvb, rpb, colblocks, rows_per_block, nblk;
+};
+
+inline Geo make_geo(int64_t M, int C, int V, int target_blocks) {
+    Geo g;
+    g.M = (int)M; g.C = C; g.cv = C / V;
+    g.cvb = g.cv < 256 ? g.cv : 256;
+    g.rpb = 256 / g.cvb;
+    g.colblocks = (g.cv + g.cvb - 1) / g.cvb;
+    int nblk = target_blocks / g.colblocks;
+    if (nblk < 1) nblk = 1;
+    int64_t rows = (M + nblk - 1) / nblk;
+    rows = (rows + g.rpb - 1) / g.rpb * g.rpb;
+    if (rows < g.rpb) rows = g.rpb;
+    g.rows_per_block = (int)rows;
+    g.nblk = (int)((M + rows - 1) / rows);
+    return g;
+}
+
+// ------------------------------------------------------------------ forward
+template <typename T>
+__global__ void __launch_bounds__(256) bn_stats_kernel(const T* x, Geo g, float* partial) {
+    constexpr int V = VT<T>::V;
+    __shared__ float sh[2][256 * V];
+    const int tid = threadIdx.x;
+    const int cvl = tid % g.cvb, rl = tid / g.cvb;
+    const int cvec = blockIdx.y * g.cvb + cvl;
+    float s[V], q[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { s[i] = 0.f; q[i] = 0.f; }
+    const int r0 = blockIdx.x * g.rows_per_block;
+    int r1 = r0 + g.rows_per_block; if (r1 > g.M) r1 = g.M;
+    if (rl < g.rpb && cvec < g.cv) {
+        for (int r = r0 + rl; r < r1; r += g.rpb) {
+            float v[V];
+            VT<T>::load(x + (int64_t)r * g.C + cvec * V, v);
+#pragma unroll
+            for (int i = 0; i < V; ++i) { s[i] += v[i]; q[i] += v[i] * v[i]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) { sh[0][tid * V + i] = s[i]; sh[1][tid * V + i] = q[i]; }
+    __syncthreads();
+    // thread (rl == 0) sums its column over the row lanes in fixed order
+    if (rl == 0 && cvec < g.cv) {
+        for (int j = 1; j < g.rpb; ++j)
+#pragma unroll
+            for (int i = 0; i < V; ++i) { s[i] += sh[0][(j * g.cvb + cvl) * V + i]; q[i] += sh[1][(j * g.cvb + cvl) * V + i]; }
+        float* p = partial + (int64_t)blockIdx.x * 2 * g.C + cvec * V;
+#pragma unroll
+        for (int i = 0; i < V; ++i) { p[i] = s[i]; p[g.C + i] = q[i]; }
+    }
+}
+
+// stats layout: [4][C] = mean, invstd, a (=gamma*invstd), b (=beta-mean*a)
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partial, int nblk, int C, double count,
+                                                          const float* gamma, const float* beta, float eps,
+                                                          float momentum, float* running_mean, float* running_var,
+                                                          float* stats) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += partial[(int64_t)b * 2 * C + c]; q += partial[(int64_t)b * 2 * C + C + c]; }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float a = gamma[c] * invstd;
+    stats[c] = (float)mean;
+    stats[C + c] = invstd;
+    stats[2 * C + c] = a;
+    stats[3 * C + c] = beta[c] - (float)mean * a;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+template <typename T, bool RELU, int RES>   // RES 0: none, 1: + r, 2: + a2*r + b2
+__global__ void __launch_bounds__(256) bn_apply_kernel(const T* x, const float* stats, const T* r, const float* stats2,
+                                                       T* y, int64_t total_vec, int cv, int C) {
+    constexpr int V = VT<T>::V;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % cv) * V;
+        float v[V], w[V];
+        VT<T>::load(x + i * V, v);
+        if (RES) VT<T>::load(r + i * V, w);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float t = stats[2 * C + c0 + k] * v[k] + stats[3 * C + c0 + k];
+            if (RES == 1) t += w[k];
+            if (RES == 2) t += stats2[2 * C + c0 + k] * w[k] + stats2[3 * C + c0 + k];
+            v[k] = RELU ? fmaxf(t, 0.f) : t;
+        }
+        VT<T>::store(y + i * V, v);
+    }
+}
+
+// ----------------------------------------------------------------- backward
+template <typename T, bool MASK>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* g_, const T* ymask, const T* x, const float* stats,
+                                                            Geo g, float* partial) {
+    constexpr int V = VT<T>::V;
+    __shared__ float sh[2][256 * V];
+    const int tid = threadIdx.x;
+    const int cvl = tid % g.cvb, rl = tid / g.cvb;
+    const int cvec = blockIdx.y * g.cvb + cvl;
+    float s1[V], s2[V], mean[V], istd[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { s1[i] = 0.f; s2[i] = 0.f; mean[i] = 0.f; istd[i] = 0.f; }
+    const int r0 = blockIdx.x * g.rows_per_block;
+    int r1 = r0 + g.rows_per_block; if (r1 > g.M) r1 = g.M;
+    if (rl < g.rpb && cvec < g.cv) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) { mean[i] = stats[cvec * V + i]; istd[i] = stats[g.C + cvec * V + i]; }
+        for (int r = r0 + rl; r < r1; r += g.rpb) {
+            const int64_t o = (int64_t)r * g.C + cvec * V;
+            float dy[V], xv[V], yv[V];
+            VT<T>::load(g_ + o, dy);
+            VT<T>::load(x + o, xv);
+            if (MASK) VT<T>::load(ymask + o, yv);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float d = MASK ? (yv[i] > 0.f ? dy[i] : 0.f) : dy[i];
+                s1[i] += d;
+                s2[i] += d * ((xv[i] - mean[i]) * istd[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) { sh[0][tid * V + i] = s1[i]; sh[1][tid * V + i] = s2[i]; }
+    __syncthreads();
+    if (rl == 0 && cvec < g.cv) {
+        for (int j = 1; j < g.rpb; ++j)
+#pragma unroll
+            for (int i = 0; i < V; ++i) { s1[i] += sh[0][(j * g.cvb + cvl) * V + i]; s2[i] += sh[1][(j * g.cvb + cvl) * V + i]; }
+        float* p = partial + (int64_t)blockIdx.x * 2 * g.C + cvec * V;
+#pragma unroll
+        for (int i = 0; i < V; ++i) { p[i] = s1[i]; p[g.C + i] = s2[i]; }
+    }
+}
+
+// coef layout [3][C]: k1 = gamma*invstd, k2 = mean(dy), k3 = mean(dy*xhat)*invstd
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* partial, int nblk, int C, double count,
+                                                              const float* gamma, const float* stats, float* dgamma,
+                                                              float* dbeta, float* coef) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) { s1 += partial[(int64_t)b * 2 * C + c]; s2 += partial[(int64_t)b * 2 * C + C + c]; }
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+    const float invstd = stats[C + c];
+    coef[c] = gamma[c] * invstd;
+    coef[C + c] = (float)(s1 / count);
+    coef[2 * C + c] = (float)(s2 / count) * invstd;
+}
+
+template <typename T, bool MASK, bool GMOUT>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T* ymask, const T* x, const float* stats,
+                                                           const float* coef, T* dx, T* gm, int64_t total_vec, int cv,
+                                                           int C) {
+    constexpr int V = VT<T>::V;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % cv) * V;
+        float dy[V], xv[V], yv[V];
+        VT<T>::load(g_ + i * V, dy);
+        VT<T>::load(x + i * V, xv);
+        if (MASK) VT<T>::load(ymask + i * V, yv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float d = MASK ? (yv[k] > 0.f ? dy[k] : 0.f) : dy[k];
+            dy[k] = d;
+            xv[k] = coef[c0 + k] * (d - coef[C + c0 + k] - (xv[k] - stats[c0 + k]) * coef[2 * C + c0 + k]);
+        }
+        VT<T>::store(dx + i * V, xv);
+        if (GMOUT) VT<T>::store(gm + i * V, dy);
+    }
+}
+
+inline int stream_blocks(int64_t total_vec) {
+    const int64_t b = (total_vec + 255) / 256;
+    return (int)(b < 4096 ? b : 4096);
+}
+
+template <typename T>
+int bn_forward_t(const T* x, int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                 float* rm, float* rv, float* stats, float* ws, int64_t ws_bytes, hipStream_t st) {
+    constexpr int V = VT<T>::V;
+    Geo g = make_geo(M, C, V, 1024);
+    if ((int64_t)g.nblk * 2 * C * 4 > ws_bytes) return IIF_EINVAL;
+    hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(g.nblk, g.colblocks), dim3(256), 0, st, x, g, ws);
+    IIF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, g.nblk, C, (double)M, gamma,
+                       beta, eps, momentum, rm, rv, stats);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+template <typename T>
+int bn_apply_t(const T* x, const float* stats, const T* r, const float* stats2, T* y, int64_t M, int C, int relu,
+               hipStream_t st) {
+    constexpr int V = VT<T>::V;
+    const int cv = C / V;
+    const int64_t tv = M * cv;
+    const dim3 grid(stream_blocks(tv)), blk(256);
+    const int res = r ? (stats2 ? 2 : 1) : 0;
+#define IIF_APPLY(RL, RS) hipLaunchKernelGGL((bn_apply_kernel<T, RL, RS>), grid, blk, 0, st, x, stats, r, stats2, y, tv, cv, C)
+    if (relu) { if (res == 0) IIF_APPLY(true, 0); else if (res == 1) IIF_APPLY(true, 1); else IIF_APPLY(true, 2); }
+    else { if (res == 0) IIF_APPLY(false, 0); else if (res == 1) IIF_APPLY(false, 1); else IIF_APPLY(false, 2); }
+#undef IIF_APPLY
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+template <typename T>
+int bn_backward_t(const T* gy, const T* ymask, const T* x, const float* stats, const float* gamma, int64_t M, int C,
+                  float* dgamma, float* dbeta, T* dx, T* gm, float* ws, int64_t ws_bytes, hipStream_t st) {
+    constexpr int V = VT<T>::V;
+    Geo g = make_geo(M, C, V, 1024);
+    const int64_t need = ((int64_t)g.nblk * 2 * C + 3 * C) * 4;
+    if (need > ws_bytes) return IIF_EINVAL;
+    float* coef = ws + (int64_t)g.nblk * 2 * C;
+    const dim3 rgrid(g.nblk, g.colblocks), blk(256);
+    if (ymask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), rgrid, blk, 0, st, gy, ymask, x, stats, g, ws);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), rgrid, blk, 0, st, gy, ymask, x, stats, g, ws);
+    IIF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), blk, 0, st, ws, g.nblk, C, (double)M, gamma, stats,
+                       dgamma, dbeta, coef);
+    IIF_LAUNCH_CHECK();
+    const int cv = C / V;
+    const int64_t tv = M * cv;
+    const dim3 agrid(stream_blocks(tv));
+#define IIF_BAPPLY(MK, GO) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MK, GO>), agrid, blk, 0, st, gy, ymask, x, stats, coef, dx, gm, tv, cv, C)
+    if (ymask) { if (gm) IIF_BAPPLY(true, true); else IIF_BAPPLY(true, false); }
+    else { if (gm) IIF_BAPPLY(false, true); else IIF_BAPPLY(false, false); }
+#undef IIF_BAPPLY
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+inline bool bad_align(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t iif_bn_workspace_bytes(int64_t m, int c) { return ((int64_t)1100 * 2 * c + 3 * (int64_t)c) * 4 + 256; }
+
+int iif_bn_forward_stats(const void* x, int dtype, int64_t m, int c, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* stats, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+    if (!x || !gamma || !beta || !stats || !workspace || m <= 0 || c <= 0) return IIF_EINVAL;
+    if (m > 0x7fffff00LL || bad_align(x)) return IIF_EUNSUPPORTED;
+    if (dtype == IIF_F32) {
+        if (c % 4) return IIF_EUNSUPPORTED;
+        return bn_forward_t<float>((const float*)x, m, c, gamma, beta, eps, momentum, running_mean, running_var, stats,
+                                   (float*)workspace, workspace_bytes, as_stream(stream));
+    }
+    if (dtype == IIF_BF16) {
+        if (c % 8) return IIF_EUNSUPPORTED;
+        return bn_forward_t<unsigned short>((const unsigned short*)x, m, c, gamma, beta, eps, momentum, running_mean,
+                                            running_var, stats, (float*)workspace, workspace_bytes, as_stream(stream));
+    }
+    return IIF_EINVAL;
+}
+
+int iif_bn_apply(const void* x, int dtype, int64_t m, int c, const float* stats, const void* residual,
+                 const float* residual_stats, int relu, void* y, void* stream) {
+    if (!x || !stats || !y || m <= 0 || c <= 0) return IIF_EINVAL;
+    if (bad_align(x) || bad_align(y) || bad_align(residual)) return IIF_EUNSUPPORTED;
+    if (dtype == IIF_F32) {
+        if (c % 4) return IIF_EUNSUPPORTED;
+        return bn_apply_t<float>((const float*)x, stats, (const float*)residual, residual_stats, (float*)y, m, c, relu,
+                                 as_stream(stream));
+    }
+    if (dtype == IIF_BF16) {
+        if (c % 8) return IIF_EUNSUPPORTED;
+        return bn_apply_t<unsigned short>((const unsigned short*)x, stats, (const unsigned short*)residual,
+                                          residual_stats, (unsigned short*)y, m, c, relu, as_stream(stream));
+    }
+    return IIF_EINVAL;
+}
+
+int iif_bn_backward(const void* gy, const void* y_mask, const void* x, int dtype, int64_t m, int c, const float* stats,
+                    const float* gamma, float* dgamma, float* dbeta, void* dx, void* gmasked, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
+    if (!gy || !x || !stats || !gamma || !dgamma || !dbeta || !dx || !workspace || m <= 0 || c <= 0) return IIF_EINVAL;
+    if (m > 0x7fffff00LL || bad_align(gy) || bad_align(x) || bad_align(dx) || bad_align(y_mask) || bad_align(gmasked))
+        return IIF_EUNSUPPORTED;
+    if (dtype == IIF_F32) {
+        if (c % 4) return IIF_EUNSUPPORTED;
+        return bn_backward_t<float>((const float*)gy, (const float*)y_mask, (const float*)x, stats, gamma, m, c, dgamma,
+                                    dbeta, (float*)dx, (float*)gmasked, (float*)workspace, workspace_bytes,
+                                    as_stream(stream));
+    }
+    if (dtype == IIF_BF16) {
+        if (c % 8) return IIF_EUNSUPPORTED;
+        return bn_backward_t<unsigned short>((const unsigned short*)gy, (const unsigned short*)y_mask,
+                                             (const unsigned short*)x, stats, gamma, m, c, dgamma, dbeta,
+                                             (unsigned short*)dx, (unsigned short*)gmasked, (float*)workspace,
+                                             workspace_bytes, as_stream(stream));
+    }
+    return IIF_EINVAL;
+}
+
+}  // extern "C"

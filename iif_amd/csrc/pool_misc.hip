@@ -1,0 +1,439 @@
+// Pooling, stem patch gather, layout/precision casts, option-A shortcut and the
+// fused SGD update — the HBM-bound glue of the ResNet step on gfx950.  NHWC, 16-byte
+// channel vectors per lane wherever alignment allows.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct PT;
+template <> struct PT<float> {
+    static constexpr int V = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+    static __device__ __forceinline__ float load1(const float* p) { return *p; }
+    static __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+};
+template <> struct PT<unsigned short> {
+    static constexpr int V = 8;
+    static __device__ __forceinline__ void load(const unsigned short* p, float (&v)[8]) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_bits_to_f32(t[i] & 0xffffu); v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(unsigned short* p, const float (&v)[8]) {
+        u32x4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        *reinterpret_cast<u32x4*>(p) = t;
+    }
+    static __device__ __forceinline__ float load1(const unsigned short* p) { return bf16_bits_to_f32(*p); }
+    static __device__ __forceinline__ void store1(unsigned short* p, float v) { *p = f32_to_bf16_bits(v); }
+};
+
+inline int sblocks(int64_t n) { const int64_t b = (n + 255) / 256; return (int)(b < 8192 ? (b > 0 ? b : 1) : 8192); }
+
+// ---------------------------------------------------------------- max pool 3x3/s2/p1 (general k,s,p)
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* x, int N, int H, int W, int C, int k, int s, int p,
+                                                          int Ho, int Wo, T* y, unsigned char* idx) {
+    constexpr int V = PT<T>::V;
+    const int cv = C / V;
+    const int64_t total = (int64_t)N * Ho * Wo * cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cv) * V;
+        int64_t pix = i / cv;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        float best[V]; unsigned char bi[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) { best[q] = -INFINITY; bi[q] = 0; }
+        bool first = true;
+        for (int kh = 0; kh < k; ++kh) {
+            const int h = ho * s - p + kh;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int w = wo * s - p + kw;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float v[V];
+                PT<T>::load(x + (((int64_t)n * H + h) * W + w) * C + c, v);
+#pragma unroll
+                for (int q = 0; q < V; ++q)
+                    if (first || v[q] > best[q] || v[q] != v[q]) { best[q] = v[q]; bi[q] = (unsigned char)(kh * k + kw); }
+                first = false;
+            }
+        }
+        const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + c;
+        PT<T>::store(y + o, best);
+#pragma unroll
+        for (int q = 0; q < V; ++q) idx[o + q] = bi[q];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* gy, const unsigned char* idx, int N, int H, int W,
+                                                          int C, int k, int s, int p, int Ho, int Wo, T* dx) {
+    constexpr int V = PT<T>::V;
+    const int cv = C / V;
+    const int64_t total = (int64_t)N * H * W * cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cv) * V;
+        int64_t pix = i / cv;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H);
+        const int n = (int)(pix / H);
+        float acc[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc[q] = 0.f;
+        // windows (ho, wo) with ho*s - p <= h <= ho*s - p + k - 1
+        int ho_lo = (h + p - (k - 1) + s - 1) / s; if (h + p - (k - 1) < 0) ho_lo = 0;
+        int ho_hi = (h + p) / s; if (ho_hi > Ho - 1) ho_hi = Ho - 1;
+        int wo_lo = (w + p - (k - 1) + s - 1) / s; if (w + p - (k - 1) < 0) wo_lo = 0;
+        int wo_hi = (w + p) / s; if (wo_hi > Wo - 1) wo_hi = Wo - 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho)
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                const int code = (h - (ho * s - p)) * k + (w - (wo * s - p));
+                const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + c;
+                float g[V];
+                PT<T>::load(gy + o, g);
+#pragma unroll
+                for (int q = 0; q < V; ++q)
+                    if (idx[o + q] == code) acc[q] += g[q];
+            }
+        PT<T>::store(dx + (((int64_t)n * H + h) * W + w) * C + c, acc);
+    }
+}
+
+// ---------------------------------------------------------------- global average pool
+template <typename T>
+__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const T* x, int N, int HW, int C, T* y) {
+    constexpr int V = PT<T>::V;
+    const int cv = C / V;
+    const int64_t total = (int64_t)N * cv;
+    const float inv = 1.0f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cv) * V;
+        const int n = (int)(i / cv);
+        float acc[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc[q] = 0.f;
+        for (int j = 0; j < HW; ++j) {
+            float v[V];
+            PT<T>::load(x + ((int64_t)n * HW + j) * C + c, v);
+#pragma unroll
+            for (int q = 0; q < V; ++q) acc[q] += v[q];
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc[q] *= inv;
+        PT<T>::store(y + (int64_t)n * C + c, acc);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) avgpool_bwd_kernel(const T* gy, int N, int HW, int C, T* dx) {
+    constexpr int V = PT<T>::V;
+    const int cv = C / V;
+    const int64_t total = (int64_t)N * HW * cv;
+    const float inv = 1.0f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cv) * V;
+        const int n = (int)(i / ((int64_t)HW * cv));
+        float g[V];
+        PT<T>::load(gy + (int64_t)n * C + c, g);
+#pragma unroll
+        for (int q = 0; q < V; ++q) g[q] *= inv;
+        PT<T>::store(dx + i * V, g);
+    }
+}
+
+// ---------------------------------------------------------------- stem patches (im2col of a few-channel image)
+// img: NCHW fp32 [N, Cin, H, W] -> patches [N*Ho*Wo][kp], column (r*S + s)*Cin + c, zero pad to kp
+template <typename T>
+__global__ void __launch_bounds__(256) im2col_kernel(const float* img, int N, int Cin, int H, int W, int R, int S,
+                                                     int stride, int pad, int Ho, int Wo, int kp, T* out) {
+    constexpr int V = PT<T>::V;
+    const int gv = kp / V;
+    const int K = R * S * Cin;
+    const int64_t total = (int64_t)N * Ho * Wo * gv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k0 = (int)(i % gv) * V;
+        int64_t pix = i / gv;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        float v[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const int kk = k0 + q;
+            float t = 0.f;
+            if (kk < K) {
+                const int c = kk % Cin, tap = kk / Cin;
+                const int r = tap / S, s = tap - r * S;
+                const int h = ho * stride - pad + r, w = wo * stride - pad + s;
+                if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W)
+                    t = img[(((int64_t)n * Cin + c) * H + h) * W + w];
+            }
+            v[q] = t;
+        }
+        PT<T>::store(out + i * V, v);
+    }
+}
+
+// ---------------------------------------------------------------- casts
+template <typename T>
+__global__ void __launch_bounds__(256) cast_from_f32_kernel(const float* src, T* dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        PT<T>::store1(dst + i, src[i]);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) cast_to_f32_kernel(const T* src, float* dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dst[i] = PT<T>::load1(src + i);
+}
+// w: fp32 [Cout][ldw] (r,s,c) -> wt: T [Cin][ldwt] (r,s,k); pad columns zeroed
+template <typename T>
+__global__ void __launch_bounds__(256) weight_transpose_kernel(const float* w, int Cout, int Cin, int RS, int ldw,
+                                                               int ldwt, T* wt) {
+    const int64_t total = (int64_t)Cin * ldwt;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int col = (int)(i % ldwt), c = (int)(i / ldwt);
+        float v = 0.f;
+        if (col < RS * Cout) {
+            const int tap = col / Cout, k = col - tap * Cout;
+            v = w[(int64_t)k * ldw + tap * Cin + c];
+        }
+        PT<T>::store1(wt + i, v);
+    }
+}
+
+// ---------------------------------------------------------------- option-A shortcut (resnet_cifar.py:125-126)
+template <typename T>
+__global__ void __launch_bounds__(256) shortcut_a_fwd_kernel(const T* x, int N, int H, int W, int Cin, int Ho, int Wo,
+                                                             int Cout, int cpad, T* y) {
+    const int64_t total = (int64_t)N * Ho * Wo * Cout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cout);
+        int64_t pix = i / Cout;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        float v = 0.f;
+        const int ci = c - cpad;
+        if (ci >= 0 && ci < Cin) v = PT<T>::load1(x + (((int64_t)n * H + 2 * ho) * W + 2 * wo) * Cin + ci);
+        PT<T>::store1(y + i, v);
+    }
+}
+// dx[n,h,w,ci] += g[n,h/2,w/2,ci+cpad] at even (h,w)
+template <typename T>
+__global__ void __launch_bounds__(256) shortcut_a_bwd_kernel(const T* g, int N, int H, int W, int Cin, int Ho, int Wo,
+                                                             int Cout, int cpad, T* dx) {
+    const int64_t total = (int64_t)N * Ho * Wo * Cin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(i % Cin);
+        int64_t pix = i / Cin;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        const int64_t o = (((int64_t)n * H + 2 * ho) * W + 2 * wo) * Cin + ci;
+        const float gv = PT<T>::load1(g + (((int64_t)n * Ho + ho) * Wo + wo) * Cout + ci + cpad);
+        PT<T>::store1(dx + o, PT<T>::load1(dx + o) + gv);
+    }
+}
+
+// ---------------------------------------------------------------- column sums (bias gradient)
+__global__ void __launch_bounds__(256) colsum_kernel(const float* a, int rows, int cols, int64_t ld, float* out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += a[(int64_t)r * ld + c];
+    out[c] = s;
+}
+
+// ---------------------------------------------------------------- fused SGD over a flat arena
+// torch.optim.SGD semantics (dampening 0): d = g + wd*p; buf = m*buf + d (zero-initialised buf gives
+// buf = d on the first step); p -= lr * (nesterov ? d + m*buf : buf).  grad_scale folds 1/world_size.
+__global__ void __launch_bounds__(256) sgd_kernel(float* p, const float* g, float* buf, int64_t n, float lr,
+                                                  const float* d_lr, float momentum, float wd, int nesterov,
+                                                  float grad_scale) {
+    const float step = d_lr ? *d_lr : lr;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 bv = reinterpret_cast<f32x4*>(buf)[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float d = gv[q] * grad_scale + wd * pv[q];
+            bv[q] = momentum * bv[q] + d;
+            pv[q] -= step * (nesterov ? d + momentum * bv[q] : bv[q]);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(buf)[i] = bv;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = g[i] * grad_scale + wd * p[i];
+        const float b = momentum * buf[i] + d;
+        buf[i] = b;
+        p[i] -= step * (nesterov ? d + momentum * b : b);
+    }
+}
+
+inline bool mis(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+
+}  // namespace
+
+#define IIF_BY_DTYPE(dtype, CALL_F32, CALL_BF16) \
+    if ((dtype) == IIF_F32) { CALL_F32; } else if ((dtype) == IIF_BF16) { CALL_BF16; } else return IIF_EINVAL;
+
+extern "C" {
+
+int iif_maxpool_forward(const void* x, int dtype, int n, int h, int w, int c, int k, int stride, int pad, void* y,
+                        uint8_t* argmax, void* stream) {
+    if (!x || !y || !argmax || n <= 0 || h <= 0 || w <= 0 || c <= 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0)
+        return IIF_EINVAL;
+    const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+    if (ho <= 0 || wo <= 0) return IIF_EINVAL;
+    if (mis(x) || mis(y) || c % (dtype == IIF_F32 ? 4 : 8)) return IIF_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = (int64_t)n * ho * wo * (c / (dtype == IIF_F32 ? 4 : 8));
+    IIF_BY_DTYPE(dtype,
+        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, (const float*)x, n, h, w, c, k, stride, pad, ho, wo, (float*)y, argmax),
+        hipLaunchKernelGGL(maxpool_fwd_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, (const unsigned short*)x, n, h, w, c, k, stride, pad, ho, wo, (unsigned short*)y, argmax))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_maxpool_backward(const void* gy, const uint8_t* argmax, int dtype, int n, int h, int w, int c, int k, int stride,
+                         int pad, void* dx, void* stream) {
+    if (!gy || !dx || !argmax || n <= 0 || h <= 0 || w <= 0 || c <= 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0)
+        return IIF_EINVAL;
+    const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+    if (ho <= 0 || wo <= 0) return IIF_EINVAL;
+    if (mis(gy) || mis(dx) || c % (dtype == IIF_F32 ? 4 : 8)) return IIF_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = (int64_t)n * h * w * (c / (dtype == IIF_F32 ? 4 : 8));
+    IIF_BY_DTYPE(dtype,
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, (const float*)gy, argmax, n, h, w, c, k, stride, pad, ho, wo, (float*)dx),
+        hipLaunchKernelGGL(maxpool_bwd_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, (const unsigned short*)gy, argmax, n, h, w, c, k, stride, pad, ho, wo, (unsigned short*)dx))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_avgpool_forward(const void* x, int dtype, int n, int hw, int c, void* y, void* stream) {
+    if (!x || !y || n <= 0 || hw <= 0 || c <= 0) return IIF_EINVAL;
+    if (mis(x) || mis(y) || c % (dtype == IIF_F32 ? 4 : 8)) return IIF_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = (int64_t)n * (c / (dtype == IIF_F32 ? 4 : 8));
+    IIF_BY_DTYPE(dtype,
+        hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, (const float*)x, n, hw, c, (float*)y),
+        hipLaunchKernelGGL(avgpool_fwd_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, (const unsigned short*)x, n, hw, c, (unsigned short*)y))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_avgpool_backward(const void* gy, int dtype, int n, int hw, int c, void* dx, void* stream) {
+    if (!gy || !dx || n <= 0 || hw <= 0 || c <= 0) return IIF_EINVAL;
+    if (mis(gy) || mis(dx) || c % (dtype == IIF_F32 ? 4 : 8)) return IIF_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = (int64_t)n * hw * (c / (dtype == IIF_F32 ? 4 : 8));
+    IIF_BY_DTYPE(dtype,
+        hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, (const float*)gy, n, hw, c, (float*)dx),
+        hipLaunchKernelGGL(avgpool_bwd_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, (const unsigned short*)gy, n, hw, c, (unsigned short*)dx))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_im2col_nchw(const float* img, int n, int cin, int h, int w, int r, int s, int stride, int pad, int kp,
+                    int out_dtype, void* out, void* stream) {
+    if (!img || !out || n <= 0 || cin <= 0 || h <= 0 || w <= 0 || r <= 0 || s <= 0 || stride <= 0 || pad < 0)
+        return IIF_EINVAL;
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - s) / stride + 1;
+    if (ho <= 0 || wo <= 0 || kp < r * s * cin) return IIF_EINVAL;
+    if (mis(out) || kp % (out_dtype == IIF_F32 ? 4 : 8)) return IIF_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = (int64_t)n * ho * wo * (kp / (out_dtype == IIF_F32 ? 4 : 8));
+    IIF_BY_DTYPE(out_dtype,
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, img, n, cin, h, w, r, s, stride, pad, ho, wo, kp, (float*)out),
+        hipLaunchKernelGGL(im2col_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, img, n, cin, h, w, r, s, stride, pad, ho, wo, kp, (unsigned short*)out))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+    if (n < 0) return IIF_EINVAL;
+    if (n == 0) return IIF_OK;
+    if (!src || !dst) return IIF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(sblocks(n)), blk(256);
+    if (src_dtype == IIF_F32 && dst_dtype == IIF_BF16)
+        hipLaunchKernelGGL(cast_from_f32_kernel<unsigned short>, grid, blk, 0, st, (const float*)src, (unsigned short*)dst, n);
+    else if (src_dtype == IIF_BF16 && dst_dtype == IIF_F32)
+        hipLaunchKernelGGL(cast_to_f32_kernel<unsigned short>, grid, blk, 0, st, (const unsigned short*)src, (float*)dst, n);
+    else if (src_dtype == IIF_F32 && dst_dtype == IIF_F32)
+        hipLaunchKernelGGL(cast_from_f32_kernel<float>, grid, blk, 0, st, (const float*)src, (float*)dst, n);
+    else
+        return IIF_EINVAL;
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_weight_transpose(const float* w, int cout, int cin, int rs, int ldw, int ldwt, int out_dtype, void* wt,
+                         void* stream) {
+    if (!w || !wt || cout <= 0 || cin <= 0 || rs <= 0 || ldw < rs * cin || ldwt < rs * cout) return IIF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = (int64_t)cin * ldwt;
+    IIF_BY_DTYPE(out_dtype,
+        hipLaunchKernelGGL(weight_transpose_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, w, cout, cin, rs, ldw, ldwt, (float*)wt),
+        hipLaunchKernelGGL(weight_transpose_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, w, cout, cin, rs, ldw, ldwt, (unsigned short*)wt))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_shortcut_a_forward(const void* x, int dtype, int n, int h, int w, int cin, int cout, void* y, void* stream) {
+    if (!x || !y || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout < cin || (cout - cin) % 2) return IIF_EINVAL;
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2, cpad = (cout - cin) / 2;
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = (int64_t)n * ho * wo * cout;
+    IIF_BY_DTYPE(dtype,
+        hipLaunchKernelGGL(shortcut_a_fwd_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, (const float*)x, n, h, w, cin, ho, wo, cout, cpad, (float*)y),
+        hipLaunchKernelGGL(shortcut_a_fwd_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, (const unsigned short*)x, n, h, w, cin, ho, wo, cout, cpad, (unsigned short*)y))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_shortcut_a_backward_acc(const void* g, int dtype, int n, int h, int w, int cin, int cout, void* dx, void* stream) {
+    if (!g || !dx || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout < cin || (cout - cin) % 2) return IIF_EINVAL;
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2, cpad = (cout - cin) / 2;
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = (int64_t)n * ho * wo * cin;
+    IIF_BY_DTYPE(dtype,
+        hipLaunchKernelGGL(shortcut_a_bwd_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, (const float*)g, n, h, w, cin, ho, wo, cout, cpad, (float*)dx),
+        hipLaunchKernelGGL(shortcut_a_bwd_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, (const unsigned short*)g, n, h, w, cin, ho, wo, cout, cpad, (unsigned short*)dx))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_colsum_f32(const float* a, int rows, int cols, int64_t ld, float* out, void* stream) {
+    if (!a || !out || rows <= 0 || cols <= 0 || ld < cols) return IIF_EINVAL;
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, as_stream(stream), a, rows, cols, ld, out);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, const float* d_lr,
+                 float momentum, float weight_decay, int nesterov, float grad_scale, void* stream) {
+    if (n < 0) return IIF_EINVAL;
+    if (n == 0) return IIF_OK;
+    if (!params || !grads || !momentum_buf) return IIF_EINVAL;
+    if (mis(params) || mis(grads) || mis(momentum_buf)) return IIF_EUNSUPPORTED;
+    hipLaunchKernelGGL(sgd_kernel, dim3(sblocks(n / 4 + 1)), dim3(256), 0, as_stream(stream), params, grads, momentum_buf,
+                       n, lr, d_lr, momentum, weight_decay, nesterov, grad_scale);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+}  // extern "C"

@@ -59,3 +59,117 @@ def conv_wgrad(x, dy, r, s, stride, pad, ldw=None, out=None, workspace=None, spl
     check(lib().iif_conv_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), ptr(workspace), wsb, splits, stream_ptr()),
           "iif_conv_wgrad")
     return out
+
+
+# ------------------------------------------------------------------ batch norm
+def bn_workspace(m, c, device):
+    nbytes = lib().iif_bn_workspace_bytes(m, c)
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def bn_forward_stats(x2d, gamma, beta, running_mean, running_var, stats, ws, eps=1e-5, momentum=0.1):
+    """x2d: [M, C] view of an NHWC activation; fills stats [4, C]."""
+    m, c = x2d.shape
+    check(lib().iif_bn_forward_stats(ptr(x2d), dtype_code(x2d), m, c, ptr(gamma), ptr(beta), eps, momentum,
+                                     ptr(running_mean), ptr(running_var), ptr(stats), ptr(ws), ws.numel(),
+                                     stream_ptr()), "iif_bn_forward_stats")
+    return stats
+
+
+def bn_apply(x2d, stats, y2d, relu=True, residual=None, residual_stats=None):
+    m, c = x2d.shape
+    check(lib().iif_bn_apply(ptr(x2d), dtype_code(x2d), m, c, ptr(stats), ptr(residual), ptr(residual_stats),
+                             1 if relu else 0, ptr(y2d), stream_ptr()), "iif_bn_apply")
+    return y2d
+
+
+def bn_backward(gy, y_mask, x2d, stats, gamma, dgamma, dbeta, dx, ws, gmasked=None):
+    m, c = x2d.shape
+    check(lib().iif_bn_backward(ptr(gy), ptr(y_mask), ptr(x2d), dtype_code(x2d), m, c, ptr(stats), ptr(gamma),
+                                ptr(dgamma), ptr(dbeta), ptr(dx), ptr(gmasked), ptr(ws), ws.numel(), stream_ptr()),
+          "iif_bn_backward")
+    return dx
+
+
+# --------------------------------------------------------------------- pooling
+def maxpool_forward(x, k, stride, pad):
+    n, h, w, c = x.shape
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    y = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+    idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
+    check(lib().iif_maxpool_forward(ptr(x), dtype_code(x), n, h, w, c, k, stride, pad, ptr(y), ptr(idx),
+                                    stream_ptr()), "iif_maxpool_forward")
+    return y, idx
+
+
+def maxpool_backward(gy, idx, in_shape, k, stride, pad, out=None):
+    n, h, w, c = in_shape
+    dx = out if out is not None else torch.empty(in_shape, dtype=gy.dtype, device=gy.device)
+    check(lib().iif_maxpool_backward(ptr(gy), ptr(idx), dtype_code(gy), n, h, w, c, k, stride, pad, ptr(dx),
+                                     stream_ptr()), "iif_maxpool_backward")
+    return dx
+
+
+def avgpool_forward(x, out=None):
+    n, h, w, c = x.shape
+    y = out if out is not None else torch.empty((n, c), dtype=x.dtype, device=x.device)
+    check(lib().iif_avgpool_forward(ptr(x), dtype_code(x), n, h * w, c, ptr(y), stream_ptr()), "iif_avgpool_forward")
+    return y
+
+
+def avgpool_backward(gy, hw, out=None):
+    n, c = gy.shape
+    dx = out if out is not None else torch.empty((n, hw, c), dtype=gy.dtype, device=gy.device)
+    check(lib().iif_avgpool_backward(ptr(gy), dtype_code(gy), n, hw, c, ptr(dx), stream_ptr()), "iif_avgpool_backward")
+    return dx
+
+
+# ------------------------------------------------------------------------ misc
+def im2col_nchw(img, r, s, stride, pad, kp, dtype, out=None):
+    require_gpu(img)
+    if img.dtype != torch.float32 or not img.is_contiguous():
+        img = img.float().contiguous()
+    n, cin, h, w = img.shape
+    ho, wo = conv_out_hw(h, w, r, s, stride, pad)
+    if out is None:
+        out = torch.empty((n, ho, wo, kp), dtype=dtype, device=img.device)
+    check(lib().iif_im2col_nchw(ptr(img), n, cin, h, w, r, s, stride, pad, kp, dtype_code(out), ptr(out),
+                                stream_ptr()), "iif_im2col_nchw")
+    return out
+
+
+def cast(src, dst):
+    check(lib().iif_cast(ptr(src), dtype_code(src), ptr(dst), dtype_code(dst), src.numel(), stream_ptr()), "iif_cast")
+    return dst
+
+
+def weight_transpose(w2d, cout, cin, rs, wt2d):
+    check(lib().iif_weight_transpose(ptr(w2d), cout, cin, rs, w2d.shape[1], wt2d.shape[1], dtype_code(wt2d),
+                                     ptr(wt2d), stream_ptr()), "iif_weight_transpose")
+    return wt2d
+
+
+def shortcut_a_forward(x, cout, out=None):
+    n, h, w, cin = x.shape
+    y = out if out is not None else torch.empty((n, (h + 1) // 2, (w + 1) // 2, cout), dtype=x.dtype, device=x.device)
+    check(lib().iif_shortcut_a_forward(ptr(x), dtype_code(x), n, h, w, cin, cout, ptr(y), stream_ptr()),
+          "iif_shortcut_a_forward")
+    return y
+
+
+def shortcut_a_backward_acc(g, dx):
+    n, h, w, cin = dx.shape
+    cout = g.shape[-1]
+    check(lib().iif_shortcut_a_backward_acc(ptr(g), dtype_code(g), n, h, w, cin, cout, ptr(dx), stream_ptr()),
+          "iif_shortcut_a_backward_acc")
+    return dx
+
+
+def colsum_f32(a, rows, cols, ld, out):
+    check(lib().iif_colsum_f32(ptr(a), rows, cols, ld, ptr(out), stream_ptr()), "iif_colsum_f32")
+    return out
+
+
+def sgd_step(params, grads, bufs, lr, momentum, weight_decay, nesterov=False, grad_scale=1.0, d_lr=None):
+    check(lib().iif_sgd_step(ptr(params), ptr(grads), ptr(bufs), params.numel(), float(lr), ptr(d_lr), float(momentum),
+                             float(weight_decay), 1 if nesterov else 0, float(grad_scale), stream_ptr()), "iif_sgd_step")

@@ -150,6 +150,82 @@ int iif_conv_igemm(const iif_conv_desc* d, const void* src, const void* wgt, voi
 int iif_conv_wgrad(const iif_conv_desc* d, const void* x, const void* dy, float* dw,
                    void* workspace, int64_t workspace_bytes, int splits, void* stream);
 
+/* Training-mode batch norm, NHWC activation viewed as x[m, c] (m = N*H*W).
+ * Replaces F.batch_norm(training=True) + ReLU + residual add and their autograd
+ * backward under resnet_pytorch.py:152-167 / resnet_cifar.py:133-138.
+ *
+ * forward_stats: batch mean / biased variance per channel (fixed-order partial
+ *   sums, fp64 finalisation), running stats updated in place with `momentum`
+ *   (unbiased variance, as torch), and `stats` = float[4*c]:
+ *   mean | invstd | a = gamma*invstd | b = beta - mean*a.
+ * apply: y = act(a*x + b + R) with R = 0, `residual`, or a2*residual + b2 when
+ *   residual_stats (another BN's stats block) is given; act = ReLU if relu.
+ * backward: given gy = dL/dy (y = the activated output), y_mask (the stored
+ *   activated output; NULL = no ReLU), the BN input x and `stats`:
+ *   dy = gy*[y_mask>0]; dgamma = sum dy*xhat; dbeta = sum dy;
+ *   dx = gamma*invstd*(dy - mean(dy) - xhat*mean(dy*xhat)).
+ *   gmasked (nullable, may alias gy) receives dy — the gradient that also flows
+ *   into the residual branch.  dx may alias gy when gmasked is NULL.
+ * workspace: iif_bn_workspace_bytes(m, c) bytes. */
+int64_t iif_bn_workspace_bytes(int64_t m, int c);
+int iif_bn_forward_stats(const void* x, int dtype, int64_t m, int c, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean,
+                         float* running_var, float* stats, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+int iif_bn_apply(const void* x, int dtype, int64_t m, int c, const float* stats,
+                 const void* residual, const float* residual_stats, int relu, void* y, void* stream);
+int iif_bn_backward(const void* gy, const void* y_mask, const void* x, int dtype, int64_t m, int c,
+                    const float* stats, const float* gamma, float* dgamma, float* dbeta, void* dx,
+                    void* gmasked, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Max pooling k x k / stride / pad on NHWC (resnet_pytorch.py:206 MaxPool2d(3,2,1)).
+ * argmax: uint8 per output element = kh*k + kw of the first maximum in scan
+ * order (torch's tie rule); backward routes gy to that input position. */
+int iif_maxpool_forward(const void* x, int dtype, int n, int h, int w, int c, int k, int stride,
+                        int pad, void* y, uint8_t* argmax, void* stream);
+int iif_maxpool_backward(const void* gy, const uint8_t* argmax, int dtype, int n, int h, int w, int c,
+                         int k, int stride, int pad, void* dx, void* stream);
+
+/* Global average pooling over hw pixels (resnet_pytorch.py:211 AdaptiveAvgPool2d(1),
+ * resnet_cifar.py:209 avg_pool2d). */
+int iif_avgpool_forward(const void* x, int dtype, int n, int hw, int c, void* y, void* stream);
+int iif_avgpool_backward(const void* gy, int dtype, int n, int hw, int c, void* dx, void* stream);
+
+/* Stem patches: NCHW fp32 image -> [n*ho*wo][kp] matrix, column (r*S+s)*cin + c,
+ * zero padded to kp, so the few-channel first convolution (resnet_pytorch.py:203
+ * 7x7/2, resnet_cifar.py:179 3x3) runs as a K-contiguous MFMA GEMM. */
+int iif_im2col_nchw(const float* img, int n, int cin, int h, int w, int r, int s, int stride, int pad,
+                    int kp, int out_dtype, void* out, void* stream);
+
+/* Element-wise precision cast (f32 -> bf16 | f32, bf16 -> f32). */
+int iif_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+
+/* fp32 master weights [cout][ldw] (r,s,cin order) -> [cin][ldwt] (r,s,cout order) in
+ * out_dtype: the operand layout of the data-gradient contraction. */
+int iif_weight_transpose(const float* w, int cout, int cin, int rs, int ldw, int ldwt, int out_dtype,
+                         void* wt, void* stream);
+
+/* Option-A shortcut of the CIFAR ResNet (resnet_cifar.py:125-126):
+ * y[n,y,x,c] = x[n,2y,2x,c-(cout-cin)/2] inside the channel band, else 0;
+ * backward_acc adds g back into dx at the even pixels. */
+int iif_shortcut_a_forward(const void* x, int dtype, int n, int h, int w, int cin, int cout, void* y,
+                           void* stream);
+int iif_shortcut_a_backward_acc(const void* g, int dtype, int n, int h, int w, int cin, int cout,
+                                void* dx, void* stream);
+
+/* out[c] = sum_r a[r*ld + c] (bias gradient of the fc layer). */
+int iif_colsum_f32(const float* a, int rows, int cols, int64_t ld, float* out, void* stream);
+
+/* One fused SGD update over a flat fp32 arena (all parameters of the model in
+ * one launch).  torch.optim.SGD semantics as used at classification/train.py:199-204
+ * (dampening 0; a zero-initialised momentum buffer reproduces buf = grad on the
+ * first step): d = grad_scale*g + wd*p; buf = m*buf + d;
+ * p -= lr*(nesterov ? d + m*buf : buf).  d_lr (nullable) overrides lr with a
+ * device scalar so a captured graph can follow the schedule. */
+int iif_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
+                 const float* d_lr, float momentum, float weight_decay, int nesterov,
+                 float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,197 @@
+"""GPU parity of the BN / pooling / glue kernels against torch CPU ops."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import iif_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def tol_for(dt):
+    return 2e-5 if dt == torch.float32 else 2.0 ** -7
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 14, 14), (3, 16, 9, 7), (2, 256, 5, 5), (2, 2048, 2, 2), (8, 8, 3, 3)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["relu", "plain", "res", "res2"])
+def test_batchnorm_forward_backward(shape, dt, mode):
+    from iif_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h)
+    x = (torch.randn(shape, generator=g) * 1.7 + 0.3).to(dt).float()
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g) * 0.2
+    rm, rv = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    res = torch.randn(shape, generator=g).to(dt).float()
+    gamma2, beta2 = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    gy = torch.randn(shape, generator=g).to(dt).float()
+    # --- torch CPU reference
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    resr = res.clone().requires_grad_(True)
+    g2r = gamma2.clone().requires_grad_(True); b2r = beta2.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    if mode == "res":
+        y = y + resr
+    if mode == "res2":
+        y = y + F.batch_norm(resr, None, None, g2r, b2r, True, 0.1, 1e-5)
+    if mode != "plain":
+        y = F.relu(y)
+    y.backward(gy)
+    # --- native
+    m = n * h * w
+    xd = nhwc(x).to(dt).to(DEV).view(m, c)
+    ws = ops.bn_workspace(m, c, DEV)
+    stats = torch.empty(4, c, device=DEV)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    ops.bn_forward_stats(xd, gd, bd, rmd, rvd, stats, ws)
+    yd = torch.empty_like(xd)
+    resd = nhwc(res).to(dt).to(DEV).view(m, c)
+    stats2 = None
+    if mode == "res2":
+        stats2 = torch.empty(4, c, device=DEV)
+        ops.bn_forward_stats(resd, gamma2.to(DEV), beta2.to(DEV), None, None, stats2, ws)
+    ops.bn_apply(xd, stats, yd, relu=(mode != "plain"), residual=resd if mode in ("res", "res2") else None,
+                 residual_stats=stats2)
+    tol = tol_for(dt)
+    got_y = nchw(yd.view(n, h, w, c).float().cpu())
+    assert (got_y - y.detach()).abs().max().item() <= tol * max(1.0, y.detach().abs().max().item())
+    assert (rmd.cpu() - rm_ref).abs().max().item() <= 1e-5
+    assert (rvd.cpu() - rv_ref).abs().max().item() <= 1e-5 * max(1.0, rv_ref.abs().max().item())
+    # backward
+    gyd = nhwc(gy).to(dt).to(DEV).view(m, c)
+    dgam, dbet = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    dxd = torch.empty_like(xd)
+    gm = torch.empty_like(xd) if mode in ("res", "res2") else None
+    ops.bn_backward(gyd, yd if mode != "plain" else None, xd, stats, gd, dgam, dbet, dxd, ws, gmasked=gm)
+    gtol = 1e-4 if dt == torch.float32 else 3e-2        # bf16: mask flips on rounded outputs near 0
+    ref_dx = xr.grad
+    assert (nchw(dxd.view(n, h, w, c).float().cpu()) - ref_dx).abs().max().item() <= gtol * max(1e-3, ref_dx.abs().max().item())
+    assert (dgam.cpu() - gr.grad).abs().max().item() <= gtol * max(1.0, gr.grad.abs().max().item())
+    assert (dbet.cpu() - br.grad).abs().max().item() <= gtol * max(1.0, br.grad.abs().max().item())
+    if mode == "res":
+        assert (nchw(gm.view(n, h, w, c).float().cpu()) - resr.grad).abs().max().item() <= gtol * resr.grad.abs().max().item()
+    if mode == "res2":
+        d2g, d2b = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+        dres = torch.empty_like(xd)
+        ops.bn_backward(gm, None, resd, stats2, gamma2.to(DEV), d2g, d2b, dres, ws)
+        assert (nchw(dres.view(n, h, w, c).float().cpu()) - resr.grad).abs().max().item() <= gtol * max(1e-3, resr.grad.abs().max().item())
+        assert (d2g.cpu() - g2r.grad).abs().max().item() <= gtol * max(1.0, g2r.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_maxpool_and_avgpool(dt):
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for shape in ((2, 64, 12, 12), (3, 8, 7, 9), (1, 16, 112, 112)):
+        x = F.relu(torch.randn(shape, generator=g)).to(dt).float().requires_grad_(True)   # many ties at 0
+        y = F.max_pool2d(x, 3, 2, 1)
+        gy = torch.randn(y.shape, generator=g).to(dt).float()
+        y.backward(gy)
+        yd, idx = ops.maxpool_forward(nhwc(x.detach()).to(dt).to(DEV), 3, 2, 1)
+        assert torch.equal(nchw(yd.float().cpu()), y.detach())
+        dx = ops.maxpool_backward(nhwc(gy).to(dt).to(DEV), idx, tuple(nhwc(x.detach()).shape), 3, 2, 1)
+        # ties at 0 may route gradient to a different zero element than torch's NCHW scan,
+        # ReLU backward zeroes those; compare where x > 0 and total mass
+        ref = x.grad
+        got = nchw(dx.float().cpu())
+        pos = x.detach() > 0
+        assert (got[pos] - ref[pos]).abs().max().item() <= tol_for(dt) * max(1.0, ref.abs().max().item())
+        assert abs(got.sum().item() - ref.sum().item()) <= 1e-2 * max(1.0, ref.abs().sum().item() ** 0.5)
+    x = torch.randn(5, 128, 7, 7, generator=g).to(dt).float().requires_grad_(True)
+    y = F.adaptive_avg_pool2d(x, 1).flatten(1)
+    gy = torch.randn(y.shape, generator=g).to(dt).float()
+    y.backward(gy)
+    yd = ops.avgpool_forward(nhwc(x.detach()).to(dt).to(DEV))
+    assert (yd.float().cpu() - y.detach()).abs().max().item() <= tol_for(dt) * y.detach().abs().max().item()
+    dx = ops.avgpool_backward(gy.to(dt).to(DEV), 49).view(5, 7, 7, 128)
+    assert (nchw(dx.float().cpu()) - x.grad).abs().max().item() <= tol_for(dt) * x.grad.abs().max().item()
+
+
+def test_maxpool_first_max_tie_rule():
+    """Exact ties: the gradient goes to the first maximum in (kh, kw) scan order, as torch."""
+    from iif_amd import ops
+    x = torch.ones(1, 8, 6, 6)
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(xr, 3, 2, 1)
+    y.backward(torch.ones_like(y))
+    yd, idx = ops.maxpool_forward(nhwc(x).to(DEV), 3, 2, 1)
+    dx = ops.maxpool_backward(torch.ones_like(yd), idx, (1, 6, 6, 8), 3, 2, 1)
+    assert torch.equal(nchw(dx.cpu()), xr.grad)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_im2col_stem_equals_conv(dt):
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(2)
+    for (n, hw, cout, r, stride, pad, kp) in ((2, 32, 64, 7, 2, 3, 160), (3, 16, 16, 3, 1, 1, 32)):
+        img = torch.randn(n, 3, hw, hw, generator=g)
+        w = (torch.randn(cout, 3, r, r, generator=g) * 0.1).to(dt).float()
+        ref = F.conv2d(img.to(dt).float(), w, None, stride, pad)
+        patches = ops.im2col_nchw(img.to(DEV), r, r, stride, pad, kp, dt)
+        w2 = torch.zeros(cout, kp)
+        w2[:, :r * r * 3] = w.permute(0, 2, 3, 1).reshape(cout, -1)
+        y = ops.conv_forward(patches, w2.to(dt).to(DEV), 1, 1, 1, 0)
+        got = nchw(y.float().cpu())
+        assert (got - ref).abs().max().item() <= tol_for(dt) * ref.abs().max().item()
+
+
+def test_weight_transpose_cast_colsum_shortcut():
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(24, 3, 3, 16, generator=g)                 # KRSC
+    w2 = torch.zeros(24, 160); w2[:, :144] = w.reshape(24, -1)
+    for dt in (torch.float32, torch.bfloat16):
+        wt = torch.full((16, 224), 9.0, dtype=dt, device=DEV)
+        ops.weight_transpose(w2.to(DEV), 24, 16, 9, wt)
+        ref = w.permute(3, 1, 2, 0).reshape(16, -1).to(dt)     # [c][r][s][k]
+        assert torch.equal(wt[:, :216].cpu(), ref) and (wt[:, 216:] == 0).all()
+    src = torch.randn(1000, generator=g)
+    dst = torch.empty(1000, dtype=torch.bfloat16, device=DEV)
+    assert torch.equal(ops.cast(src.to(DEV), dst).cpu(), src.to(torch.bfloat16))
+    a = torch.randn(37, 104, generator=g)
+    out = torch.empty(100, device=DEV)
+    ops.colsum_f32(a.to(DEV), 37, 100, 104, out)
+    assert (out.cpu() - a[:, :100].sum(0)).abs().max().item() <= 1e-5
+    x = torch.randn(2, 16, 8, 8, generator=g).requires_grad_(True)
+    y = F.pad(x[:, :, ::2, ::2], (0, 0, 0, 0, 8, 8))
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    yd = ops.shortcut_a_forward(nhwc(x.detach()).to(DEV), 32)
+    assert torch.equal(nchw(yd.cpu()), y.detach())
+    dx = torch.zeros(2, 8, 8, 16, device=DEV)
+    ops.shortcut_a_backward_acc(nhwc(gy).to(DEV), dx)
+    assert torch.equal(nchw(dx.cpu()), x.grad)
+
+
+def test_fused_sgd_matches_torch_optim():
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for nesterov in (False, True):
+        p = torch.randn(10007, generator=g)
+        pd, bd = p.clone().to(DEV), torch.zeros(10007, device=DEV)
+        q = p.clone().requires_grad_(True)
+        opt = torch.optim.SGD([q], lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=nesterov)
+        ref_p, ref_b = [p.clone()], [None]
+        for it in range(4):
+            gr = torch.randn(10007, generator=g)
+            lr = 0.1 * O.warmup_factor(it, 1000)
+            for grp in opt.param_groups:
+                grp["lr"] = lr
+            q.grad = gr.clone()
+            opt.step()
+            O.sgd_step(ref_p, [gr], ref_b, lr, 0.9, 1e-4, nesterov)
+            ops.sgd_step(pd, gr.to(DEV), bd, lr, 0.9, 1e-4, nesterov)
+        assert (pd.cpu() - q.detach()).abs().max().item() <= 1e-6
+        assert (pd.cpu() - ref_p[0]).abs().max().item() <= 1e-6
