@@ -139,9 +139,9 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* x, const float* 
         if (RES) VT<T>::load(r + i * V, w);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            float t = stats[2 * C + c0 + k] * v[k] + stats[3 * C + c0 + k];
+            float t = fmaf(stats[2 * C + c0 + k], v[k], stats[3 * C + c0 + k]);   // one rounding, as vec fmadd
             if (RES == 1) t += w[k];
-            if (RES == 2) t += stats2[2 * C + c0 + k] * w[k] + stats2[3 * C + c0 + k];
+            if (RES == 2) t += fmaf(stats2[2 * C + c0 + k], w[k], stats2[3 * C + c0 + k]);
             v[k] = RELU ? fmaxf(t, 0.f) : t;
         }
         VT<T>::store(y + i * V, v);

@@ -1,0 +1,619 @@
+"""Native ResNet forward/backward engine for MI355X.
+
+One ``NativeResNet`` module owns
+  * a flat fp32 PARAMETER ARENA (all weights of the model, each tensor 64-byte
+    aligned, conv weights stored [Cout][R][S][Cin] with a 16-element row pitch
+    padding) and a parallel GRADIENT ARENA and MOMENTUM ARENA — one fused SGD
+    launch and contiguous all-reduce buckets fall out of the layout;
+  * ``nn.Parameter`` views into the arena that carry the REFERENCE's names and
+    OIHW shapes (channels-last strided views), so ``state_dict`` /
+    ``load_state_dict`` / ``model.fc`` / ``model.linear`` interoperate with
+    checkpoints of classification/resnet_pytorch.py and resnet_cifar.py;
+  * a static per-input-shape PLAN: every activation (NHWC, bf16 or fp32), BN
+    statistic block and gradient buffer is allocated once; a step is a fixed
+    sequence of C-ABI kernel launches on the current HIP stream (capturable
+    into a hipGraph) — no autograd tape, no per-op allocation.
+
+Data flow per conv unit:  x = conv(src)  ->  stats = bn_stats(x)  ->
+y = relu(a*x + b [+ residual]).  Backward walks the units in reverse:
+bn_backward (mask from the stored y) -> wgrad (x-operand = stored src) ->
+dgrad (residual gradients are added in the dgrad epilogue).
+
+Compute dtype: ``torch.bfloat16`` (performance mode: bf16 storage, fp32
+accumulate on v_mfma_f32_16x16x32_bf16) or ``torch.float32`` (parity mode: exact
+fp32 MFMA, used to match the CPU reference to 1e-4).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+# ----------------------------------------------------------------- holders
+class ConvParam(nn.Module):
+    """Holds one convolution's weight (reference name ``<prefix>.weight``)."""
+
+    def __init__(self, cin, cout, k, stride, pad):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        self.kdim = k * k * cin                   # GEMM K of the forward contraction
+        self.ldw = _round_up(self.kdim, 16)       # row pitch of the stored [cout][ldw] matrix
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+
+    def forward(self, *a, **k):
+        raise RuntimeError("ConvParam is a parameter holder; NativeResNet.forward runs the network")
+
+
+class BNParam(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.num_features = c
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class LinearParam(nn.Module):
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.out_padded = _round_up(out_features, 8)
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+
+
+class BlockParam(nn.Module):
+    """conv/bn pairs of one residual block, registered in the reference's order."""
+
+    def __init__(self, kind, inplanes, planes, stride, width, out_planes, downsample, shortcut_a=False):
+        super().__init__()
+        self.kind, self.stride, self.shortcut_a = kind, stride, shortcut_a
+        self.inplanes, self.out_planes = inplanes, out_planes
+        if kind == "bottleneck":
+            self.conv1 = ConvParam(inplanes, width, 1, 1, 0); self.bn1 = BNParam(width)
+            self.conv2 = ConvParam(width, width, 3, stride, 1); self.bn2 = BNParam(width)
+            self.conv3 = ConvParam(width, out_planes, 1, 1, 0); self.bn3 = BNParam(out_planes)
+        else:
+            self.conv1 = ConvParam(inplanes, planes, 3, stride, 1); self.bn1 = BNParam(planes)
+            self.conv2 = ConvParam(planes, planes, 3, 1, 1); self.bn2 = BNParam(planes)
+        if downsample:
+            self.downsample = nn.Sequential(ConvParam(inplanes, out_planes, 1, stride, 0), BNParam(out_planes))
+        else:
+            self.downsample = None
+
+    def units(self):
+        if self.kind == "bottleneck":
+            return [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2)]
+
+
+# --------------------------------------------------------------- the network
+class NativeResNet(nn.Module):
+    """ImageNet-style (``style='imagenet'``) or CIFAR-style (``style='cifar'``) ResNet."""
+
+    def __init__(self, style, block, layers, num_classes, groups=1, width_per_group=64, device="cuda",
+                 compute_dtype=torch.bfloat16, zero_init_residual=False):
+        super().__init__()
+        if groups != 1:
+            raise NotImplementedError("grouped 3x3 convolutions (ResNeXt) are not built yet (SURVEY §8 a10)")
+        assert compute_dtype in (torch.bfloat16, torch.float32)
+        self.style, self.block_kind = style, block
+        self.compute_dtype = compute_dtype
+        self.num_classes = num_classes
+        self._plans = {}
+        self._saved = None
+        if style == "imagenet":
+            self.conv1 = ConvParam(3, 64, 7, 2, 3); self.bn1 = BNParam(64)
+            exp = 4 if block == "bottleneck" else 1
+            inpl = 64
+            stages = []
+            for li, (planes, nb) in enumerate(zip((64, 128, 256, 512), layers)):
+                blocks = []
+                for b in range(nb):
+                    stride = 2 if (b == 0 and li > 0) else 1
+                    width = int(planes * (width_per_group / 64.0)) * groups
+                    ds = b == 0 and (stride != 1 or inpl != planes * exp)
+                    blocks.append(BlockParam(block, inpl, planes, stride, width, planes * exp, ds))
+                    inpl = planes * exp
+                stages.append(nn.Sequential(*blocks))
+            self.layer1, self.layer2, self.layer3, self.layer4 = stages
+            self.fc = LinearParam(inpl, num_classes)
+            self._stages = stages
+        else:
+            self.conv1 = ConvParam(3, 16, 3, 1, 1); self.bn1 = BNParam(16)
+            inpl = 16
+            stages = []
+            for li, (planes, nb) in enumerate(zip((16, 32, 64), layers)):
+                blocks = []
+                for b in range(nb):
+                    stride = 2 if (b == 0 and li > 0) else 1
+                    sa = stride != 1 or inpl != planes
+                    blocks.append(BlockParam("basic", inpl, planes, stride, planes, planes, False, shortcut_a=sa))
+                    inpl = planes
+                stages.append(nn.Sequential(*blocks))
+            self.layer1, self.layer2, self.layer3 = stages
+            self.linear = LinearParam(inpl, num_classes)
+            self._stages = stages
+        # the stem runs as a GEMM over gathered patches: K padded to a multiple of 32
+        self.conv1.ldw = _round_up(self.conv1.kdim, 32)
+        self._init_parameters(zero_init_residual)
+        self._flatten(torch.device(device))
+
+    @property
+    def _head(self):
+        return self.fc if self.style == "imagenet" else self.linear
+
+    # ------------------------------------------------------------ init / arena
+    def _init_parameters(self, zero_init_residual):
+        for m in self.modules():
+            if isinstance(m, ConvParam):
+                if self.style == "imagenet":      # resnet_pytorch.py:221-223 kaiming_normal_(fan_out, relu)
+                    std = math.sqrt(2.0 / (m.cout * m.k * m.k))
+                else:                             # resnet_cifar.py:33-36 kaiming_normal_ (fan_in)
+                    std = math.sqrt(2.0 / (m.cin * m.k * m.k))
+                nn.init.normal_(m.weight, 0.0, std)
+            elif isinstance(m, LinearParam):
+                if self.style == "imagenet":      # nn.Linear default
+                    nn.init.kaiming_uniform_(m.weight, a=math.sqrt(5))
+                else:
+                    nn.init.kaiming_normal_(m.weight)
+                bound = 1.0 / math.sqrt(m.in_features)
+                nn.init.uniform_(m.bias, -bound, bound)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, BlockParam):
+                    nn.init.constant_((m.bn3 if m.kind == "bottleneck" else m.bn2).weight, 0)
+
+    def _param_specs(self):
+        """[(module, attr, rows, pitch)] in registration (= reference) order."""
+        specs = []
+        for m in self.modules():
+            if isinstance(m, ConvParam):
+                specs.append((m, "weight", m.cout, m.ldw))
+            elif isinstance(m, BNParam):
+                specs.append((m, "weight", 1, m.num_features))
+                specs.append((m, "bias", 1, m.num_features))
+            elif isinstance(m, LinearParam):
+                specs.append((m, "weight", m.out_padded, m.in_features))
+                specs.append((m, "bias", 1, m.out_padded))
+        return specs
+
+    def _flatten(self, device):
+        """(Re)build the arenas on ``device`` and point every Parameter at its view."""
+        specs = self._param_specs()
+        off, offs = 0, []
+        for (_, _, rows, pitch) in specs:
+            offs.append(off)
+            off += _round_up(rows * pitch, 16)
+        total = off
+        arena = torch.zeros(total, dtype=torch.float32, device=device)
+        self._offsets = {}
+        with torch.no_grad():
+            for (m, attr, rows, pitch), o in zip(specs, offs):
+                flat = arena[o:o + rows * pitch].view(rows, pitch)
+                old = getattr(m, attr)
+                if isinstance(m, ConvParam):
+                    view = flat[:, :m.kdim].view(m.cout, m.k, m.k, m.cin).permute(0, 3, 1, 2)
+                    m._w2d = flat
+                elif isinstance(m, LinearParam):
+                    if attr == "weight":
+                        view = flat[:m.out_features]
+                        m._w2d = flat
+                    else:
+                        view = flat.view(-1)[:m.out_features]
+                        m._b1d = flat.view(-1)
+                else:
+                    view = flat.view(-1)
+                view.copy_(old.detach().to(device))
+                old.data = view
+                self._offsets[(id(m), attr)] = (o, rows, pitch)
+        self._arena = arena
+        self._grad_arena = torch.zeros_like(arena)
+        self._mom_arena = torch.zeros_like(arena)
+        # running statistics / counters: flat buffers too
+        bns = [m for m in self.modules() if isinstance(m, BNParam)]
+        ctot = sum(_round_up(b.num_features, 16) for b in bns)
+        self._rstat = torch.zeros(2 * ctot, dtype=torch.float32, device=device)
+        self._nbt = torch.zeros(len(bns), dtype=torch.long, device=device)
+        o = 0
+        with torch.no_grad():
+            for i, b in enumerate(bns):
+                c = b.num_features
+                rm, rv = self._rstat[o:o + c], self._rstat[ctot + o:ctot + o + c]
+                rm.copy_(b.running_mean.to(device)); rv.copy_(b.running_var.to(device))
+                b.running_mean, b.running_var = rm, rv
+                nb = self._nbt[i]
+                nb.copy_(b.num_batches_tracked.to(device))
+                b.num_batches_tracked = nb
+                o += _round_up(c, 16)
+        self._device = device
+        self._plans = {}
+        self._saved = None
+        # gradient views (KRSC storage seen as OIHW), same order as parameters()
+        self._grad_views = []
+        for (m, attr, rows, pitch), o2 in zip(specs, offs):
+            gflat = self._grad_arena[o2:o2 + rows * pitch].view(rows, pitch)
+            if isinstance(m, ConvParam):
+                gv = gflat[:, :m.kdim].view(m.cout, m.k, m.k, m.cin).permute(0, 3, 1, 2)
+                m._g2d = gflat
+            elif isinstance(m, LinearParam):
+                if attr == "weight":
+                    gv = gflat[:m.out_features]; m._g2d = gflat
+                else:
+                    gv = gflat.view(-1)[:m.out_features]; m._gb1d = gflat.view(-1)
+            else:
+                gv = gflat.view(-1)
+                if attr == "weight":
+                    m._dgamma = gv
+                else:
+                    m._dbeta = gv
+            self._grad_views.append(gv)
+        self._param_list = [getattr(m, attr) for (m, attr, _, _) in specs]
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        dev = next(self.parameters()).device
+        if next(self.parameters()).dtype != torch.float32:
+            raise RuntimeError("NativeResNet keeps fp32 master weights; choose bf16 compute with compute_dtype=")
+        self._flatten(dev)
+        return out
+
+    # ------------------------------------------------------------------ plan
+    def _units(self):
+        """Flat list of descriptors in forward order."""
+        seq = [("stem", self.conv1, self.bn1)]
+        for st in self._stages:
+            for blk in st:
+                seq.append(("block", blk))
+        seq.append(("head", self._head))
+        return seq
+
+    def _plan(self, n, h, w):
+        key = (n, h, w, self.compute_dtype)
+        if key in self._plans:
+            return self._plans[key]
+        P = _Plan(self, n, h, w)
+        self._plans[key] = P
+        return P
+
+    # --------------------------------------------------------------- forward
+    def forward(self, x):
+        _lib.require_gpu(x)
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected an NCHW image batch [N,3,H,W], got %s" % (tuple(x.shape),))
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list)
+        if need_grad:
+            return _NetFunction.apply(self, x, *self._param_list)
+        return self.run_forward(x, self.training)
+
+    def run_forward(self, x, training):
+        """Native forward.  Returns fp32 logits [N, num_classes] (a view of the plan's buffer)."""
+        plan = self._plan(x.shape[0], x.shape[2], x.shape[3])
+        plan.forward(x, training)
+        self._saved = plan if training else None
+        return plan.logits[:, :self.num_classes]
+
+    def run_backward(self, dlogits=None):
+        """Native backward from d(loss)/d(logits); fills the gradient arena.
+        ``dlogits`` None means the plan's own dlogits buffer was already filled
+        (fused loss path)."""
+        plan = self._saved
+        if plan is None:
+            raise RuntimeError("run_backward() without a preceding training-mode forward")
+        if dlogits is not None:
+            plan.dlogits[:, :self.num_classes].copy_(dlogits)
+        plan.backward()
+
+    # -------------------------------------------------- fused training step
+    def sgd_step(self, lr, momentum=0.9, weight_decay=1e-4, nesterov=False, grad_scale=1.0):
+        """ONE launch over the whole parameter arena (classification/train.py:199-204,78)."""
+        ops.sgd_step(self._arena, self._grad_arena, self._mom_arena, lr, momentum, weight_decay, nesterov, grad_scale)
+
+    def loss_and_backward(self, x, targets, criterion, targets_b=None, lam=1.0):
+        """forward -> fused IIF loss (writes dlogits in the same pass) -> backward.
+        Returns (loss 0-dim tensor, logits view).  No autograd involved."""
+        from .custom import IIFLoss
+        if not isinstance(criterion, IIFLoss):
+            raise TypeError("loss_and_backward needs an iif_amd.custom.IIFLoss criterion")
+        logits = self.run_forward(x, True)
+        plan = self._saved
+        B, C = x.shape[0], self.num_classes
+        table = criterion._table(plan.logits)
+        scale = 1.0 / B if criterion.reduction == "mean" else 1.0
+        cw = criterion.weight
+        rc = _lib.lib().iif_ce_fwd_bwd(
+            _lib.ptr(plan.logits), _lib.IIF_F32, plan.logits.stride(0), _lib.ptr(table), _lib.ptr(targets),
+            _lib.ptr(targets_b), float(lam), 0, _lib.ptr(cw), -100, scale, B, C, _lib.ptr(plan.loss_rows),
+            _lib.ptr(plan.loss), _lib.ptr(plan.dlogits), plan.dlogits.stride(0), 0, _lib.stream_ptr())
+        _lib.check(rc, "iif_ce_fwd_bwd")
+        plan.backward()
+        return plan.loss, logits
+
+    @property
+    def grad_arena(self):
+        return self._grad_arena
+
+    @property
+    def param_arena(self):
+        return self._arena
+
+
+class _NetFunction(torch.autograd.Function):
+    """Autograd bridge: the whole network is one node, so ``loss.backward()`` and
+    ``torch.optim`` / DDP work on the drop-in surface (classification/train.py:66-78)."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        ctx.net = net
+        out = net.run_forward(x, net.training)
+        if not net.training:       # eval-mode forward under grad: statistics are frozen, still differentiable
+            net._saved = net._plan(x.shape[0], x.shape[2], x.shape[3])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        net = ctx.net
+        net.run_backward(g)
+        return (None, None) + tuple(net._grad_views)
+
+
+# ------------------------------------------------------------------- the plan
+class _ConvUnit(object):
+    """Buffers of one conv+BN unit inside a plan."""
+    __slots__ = ("conv", "bn", "src", "x", "stats", "y", "w", "wt", "n", "hi", "wi", "ho", "wo", "is_patch_gemm")
+
+
+class _Plan(object):
+    def __init__(self, net, n, h, w):
+        self.net = net
+        self.n, self.h, self.w = n, h, w
+        self.dt = net.compute_dtype
+        self.dev = net._device
+        dt, dev = self.dt, self.dev
+        E = lambda *s: torch.empty(s, dtype=dt, device=dev)   # noqa: E731
+        self.units = []
+        self.steps = []          # structural description used by forward/backward
+        # ---- stem
+        c1 = net.conv1
+        ho, wo = ops.conv_out_hw(h, w, c1.k, c1.k, c1.stride, c1.pad)
+        self.patches = E(n, ho, wo, c1.ldw)
+        u = self._unit(c1, net.bn1, self.patches, n, ho, wo, patch=True)
+        self.stem = u
+        if net.style == "imagenet":
+            self.pool_hw = ((ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1)
+            self.pool_out = E(n, self.pool_hw[0], self.pool_hw[1], c1.cout)
+            self.pool_idx = torch.empty((n, self.pool_hw[0], self.pool_hw[1], c1.cout), dtype=torch.uint8, device=dev)
+            cur = self.pool_out
+        else:
+            cur = u.y
+        # ---- blocks
+        self.blocks = []
+        for st in net._stages:
+            for blk in st:
+                b = {"blk": blk, "inp": cur}
+                units = []
+                src = cur
+                for (cv, bn) in blk.units():
+                    hh, ww = src.shape[1], src.shape[2]
+                    oh, ow = ops.conv_out_hw(hh, ww, cv.k, cv.k, cv.stride, cv.pad)
+                    uu = self._unit(cv, bn, src, n, oh, ow)
+                    units.append(uu)
+                    src = uu.y
+                b["units"] = units
+                last = units[-1]
+                if blk.downsample is not None:
+                    dcv, dbn = blk.downsample[0], blk.downsample[1]
+                    du = self._unit(dcv, dbn, cur, n, last.ho, last.wo, need_y=False)
+                    b["ds"] = du
+                elif blk.shortcut_a:
+                    b["sc"] = E(n, last.ho, last.wo, blk.out_planes)
+                self.blocks.append(b)
+                cur = last.y
+        self.final = cur
+        # ---- head
+        head = net._head
+        self.pooled = E(n, head.in_features)
+        self.logits = torch.zeros((n, head.out_padded), dtype=torch.float32, device=dev)
+        self.dlogits = torch.zeros((n, head.out_padded), dtype=torch.float32, device=dev)
+        self.dlogits_t = torch.zeros((n, head.out_padded), dtype=dt, device=dev)
+        self.loss_rows = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.head_w = head._w2d if dt == torch.float32 else torch.empty_like(head._w2d, dtype=dt)
+        self.head_wt = torch.zeros((head.in_features, _round_up(head.out_padded, 16)), dtype=dt, device=dev)
+        # ---- scratch
+        cmax = max(u.conv.cout for u in self.units)
+        mmax = max(u.n * u.ho * u.wo for u in self.units)
+        self.bn_ws = ops.bn_workspace(mmax, cmax, dev)
+        wmax = max(max(u.conv.cout * u.conv.ldw for u in self.units), head.out_padded * head.in_features)
+        self.wg_ws = torch.empty(min(16 * wmax * 4, 512 << 20), dtype=torch.uint8, device=dev)
+        self._grad_pool = {}
+        self._bwd_ready = False
+
+    def _unit(self, conv, bn, src, n, ho, wo, patch=False, need_y=True):
+        dt, dev = self.dt, self.dev
+        u = _ConvUnit()
+        u.conv, u.bn, u.src = conv, bn, src
+        u.n, u.ho, u.wo = n, ho, wo
+        u.hi, u.wi = src.shape[1], src.shape[2]
+        u.is_patch_gemm = patch
+        u.x = torch.empty((n, ho, wo, conv.cout), dtype=dt, device=dev)
+        u.y = torch.empty((n, ho, wo, conv.cout), dtype=dt, device=dev) if need_y else None
+        u.stats = torch.empty((4, conv.cout), dtype=torch.float32, device=dev)
+        u.w = conv._w2d if dt == torch.float32 else torch.empty((conv.cout, conv.ldw), dtype=dt, device=dev)
+        if patch:
+            u.wt = None
+        else:
+            u.wt = torch.zeros((conv.cin, _round_up(conv.k * conv.k * conv.cout, 16)), dtype=dt, device=dev)
+        self.units.append(u)
+        return u
+
+    # ---------------------------------------------------------------- weights
+    def prepare_weights(self, need_transposed):
+        for u in self.units:
+            if self.dt != torch.float32:
+                ops.cast(u.conv._w2d, u.w)
+            if need_transposed and u.wt is not None:
+                ops.weight_transpose(u.conv._w2d, u.conv.cout, u.conv.cin, u.conv.k * u.conv.k, u.wt)
+        head = self.net._head
+        if self.dt != torch.float32:
+            ops.cast(head._w2d, self.head_w)
+        if need_transposed:
+            ops.weight_transpose(head._w2d, head.out_padded, head.in_features, 1, self.head_wt)
+
+    # ---------------------------------------------------------------- forward
+    def _conv_bn(self, u, training):
+        cv = u.conv
+        if u.is_patch_gemm:
+            ops.conv_forward(u.src, u.w, 1, 1, 1, 0, out=u.x)
+        else:
+            ops.conv_forward(u.src, u.w, cv.k, cv.k, cv.stride, cv.pad, out=u.x)
+        m = u.n * u.ho * u.wo
+        x2 = u.x.view(m, cv.cout)
+        if training:
+            ops.bn_forward_stats(x2, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var, u.stats, self.bn_ws,
+                                 BN_EPS, BN_MOMENTUM)
+        else:
+            _eval_stats(u.bn, u.stats)
+        return x2
+
+    def forward(self, img, training):
+        net = self.net
+        self.prepare_weights(training)
+        c1 = net.conv1
+        ops.im2col_nchw(img, c1.k, c1.k, c1.stride, c1.pad, c1.ldw, self.dt, out=self.patches)
+        u = self.stem
+        x2 = self._conv_bn(u, training)
+        ops.bn_apply(x2, u.stats, u.y.view(x2.shape), relu=True)
+        if net.style == "imagenet":
+            self._maxpool_fwd(u.y)
+        for b in self.blocks:
+            units = b["units"]
+            for uu in units[:-1]:
+                x2 = self._conv_bn(uu, training)
+                ops.bn_apply(x2, uu.stats, uu.y.view(x2.shape), relu=True)
+            last = units[-1]
+            x2 = self._conv_bn(last, training)
+            if "ds" in b:
+                du = b["ds"]
+                xd = self._conv_bn(du, training)
+                ops.bn_apply(x2, last.stats, last.y.view(x2.shape), relu=True, residual=xd, residual_stats=du.stats)
+            elif "sc" in b:
+                ops.shortcut_a_forward(b["inp"], b["blk"].out_planes, out=b["sc"])
+                ops.bn_apply(x2, last.stats, last.y.view(x2.shape), relu=True, residual=b["sc"].view(x2.shape))
+            else:
+                ops.bn_apply(x2, last.stats, last.y.view(x2.shape), relu=True, residual=b["inp"].view(x2.shape))
+        ops.avgpool_forward(self.final, out=self.pooled)
+        head = net._head
+        ops.conv_forward(self.pooled.view(self.n, 1, 1, head.in_features), self.head_w, 1, 1, 1, 0,
+                         out=self.logits.view(self.n, 1, 1, head.out_padded), bias=head._b1d)
+        if training:
+            net._nbt += 1
+
+    def _maxpool_fwd(self, y):
+        n, h, w, c = y.shape
+        _lib.check(_lib.lib().iif_maxpool_forward(_lib.ptr(y), _lib.dtype_code(y), n, h, w, c, 3, 2, 1,
+                                                  _lib.ptr(self.pool_out), _lib.ptr(self.pool_idx), _lib.stream_ptr()),
+                   "iif_maxpool_forward")
+
+    # --------------------------------------------------------------- backward
+    def _gbuf(self, key, shape):
+        t = self._grad_pool.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=self.dt, device=self.dev)
+            self._grad_pool[key] = t
+        return t
+
+    def _unit_backward(self, u, gy, mask, gmasked=None, dgrad_out=None, dgrad_res=None, need_dgrad=True):
+        """gy: grad w.r.t. the unit's activated output (NHWC).  Computes in place
+        dx (into gy's storage unless gmasked is requested), the weight / BN
+        gradients, and (optionally) the data gradient w.r.t. the unit's source."""
+        cv, bn = u.conv, u.bn
+        m = u.n * u.ho * u.wo
+        g2 = gy.view(m, cv.cout)
+        if gmasked is not None:
+            dx = self._gbuf(("dx", m, cv.cout), (m, cv.cout))
+            ops.bn_backward(g2, None if mask is None else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats, bn.weight,
+                            bn._dgamma, bn._dbeta, dx, self.bn_ws, gmasked=gmasked.view(m, cv.cout))
+        else:
+            dx = g2
+            ops.bn_backward(g2, None if mask is None else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats, bn.weight,
+                            bn._dgamma, bn._dbeta, dx, self.bn_ws)
+        dx4 = dx.view(u.n, u.ho, u.wo, cv.cout)
+        if u.is_patch_gemm:
+            ops.conv_wgrad(u.src, dx4, 1, 1, 1, 0, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws)
+            return None
+        ops.conv_wgrad(u.src, dx4, cv.k, cv.k, cv.stride, cv.pad, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws)
+        if not need_dgrad:
+            return None
+        return ops.conv_dgrad(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), out=dgrad_out, res=dgrad_res)
+
+    def backward(self):
+        net = self.net
+        head = net._head
+        n = self.n
+        # ---- head: dlogits (fp32, pad columns are zero) -> fc grads -> pooled grad -> final activation grad
+        ops.colsum_f32(self.dlogits, n, head.out_padded, head.out_padded, head._gb1d)
+        if self.dt == torch.float32:
+            dl = self.dlogits
+        else:
+            dl = ops.cast(self.dlogits, self.dlogits_t)
+        ops.conv_wgrad(self.pooled.view(n, 1, 1, head.in_features), dl.view(n, 1, 1, head.out_padded), 1, 1, 1, 0,
+                       ldw=head.in_features, out=head._g2d, workspace=self.wg_ws)
+        dpooled = self._gbuf(("dpooled",), (n, 1, 1, head.in_features))
+        ops.conv_dgrad(dl.view(n, 1, 1, head.out_padded), self.head_wt, 1, 1, 1, 0, (1, 1), out=dpooled)
+        fh, fw, fc = self.final.shape[1], self.final.shape[2], self.final.shape[3]
+        g = self._gbuf(("g", self.final.shape), self.final.shape)
+        ops.avgpool_backward(dpooled.view(n, head.in_features), fh * fw, out=g.view(n, fh * fw, fc))
+        # ---- blocks in reverse
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            b = self.blocks[bi]
+            units = b["units"]
+            last = units[-1]
+            inp = b["inp"]
+            # g is the gradient w.r.t. the block output (pre-mask).  After this call g holds the masked
+            # gradient (the residual-branch gradient) and dx of the last conv has been consumed.
+            gin = self._gbuf(("gin", tuple(inp.shape), bi & 1), inp.shape)
+            d = self._unit_backward(last, g, last.y, gmasked=g,
+                                    dgrad_out=self._gbuf(("d", tuple(last.src.shape), len(units) - 1), last.src.shape))
+            for ui in range(len(units) - 2, 0, -1):
+                uu = units[ui]
+                d = self._unit_backward(uu, d, uu.y, dgrad_out=self._gbuf(("d", tuple(uu.src.shape), ui), uu.src.shape))
+            first = units[0]
+            if "ds" in b:
+                self._unit_backward(first, d, first.y, dgrad_out=gin)
+                du = b["ds"]
+                self._unit_backward(du, g, None, dgrad_out=gin, dgrad_res=gin)
+            elif "sc" in b:
+                self._unit_backward(first, d, first.y, dgrad_out=gin)
+                ops.shortcut_a_backward_acc(g, gin)
+            else:
+                self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=g)
+            g = gin
+        # ---- stem
+        u = self.stem
+        if net.style == "imagenet":
+            dy0 = self._gbuf(("dy0",), u.y.shape)
+            _lib.check(_lib.lib().iif_maxpool_backward(_lib.ptr(g), _lib.ptr(self.pool_idx), _lib.dtype_code(g), u.n, u.ho,
+                                                       u.wo, u.conv.cout, 3, 2, 1, _lib.ptr(dy0), _lib.stream_ptr()),
+                       "iif_maxpool_backward")
+            g = dy0
+        self._unit_backward(u, g, u.y, need_dgrad=False)
+
+
+def _eval_stats(bn, stats):
+    """Inference-mode BN: the affine from running statistics (host-free vector math on [C] tensors)."""
+    invstd = torch.rsqrt(bn.running_var + BN_EPS)
+    a = bn.weight.detach() * invstd
+    stats[0].copy_(bn.running_mean); stats[1].copy_(invstd); stats[2].copy_(a)
+    stats[3].copy_(bn.bias.detach() - bn.running_mean * a)

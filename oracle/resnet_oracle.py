@@ -122,6 +122,47 @@ def trainable_keys(sd):
 
 
 # --------------------------------------------------------------------- forward
+def bf16_storage(t):
+    """Round to bf16 and back (straight-through for autograd): emulates the
+    product's bf16 STORAGE of a tensor whose arithmetic stays fp32."""
+    return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
+
+
+def _id(t):
+    return t
+
+
+class ReluMasks(object):
+    """Optional externally supplied ReLU decisions (NCHW bool tensors, in forward
+    order).  ``relu(t)`` becomes ``t * mask``: identical to ``F.relu`` wherever the
+    mask equals ``t > 0`` and, where it does not, ``t`` is within rounding of zero
+    (tests assert that), so values agree while the BACKWARD uses exactly the given
+    decisions.  Lets a test compare gradients of two fp32 implementations without
+    the ambiguity of pre-activations that round to different signs."""
+
+    def __init__(self, masks):
+        self.masks, self.i, self.disagree, self.total, self.worst = list(masks), 0, 0, 0, 0.0
+
+    def __call__(self, t):
+        m = self.masks[self.i]
+        self.i += 1
+        own = t.detach() > 0
+        diff = own != m
+        self.disagree += int(diff.sum())
+        self.total += m.numel()
+        if diff.any():
+            scale = float(t.detach().abs().max())
+            self.worst = max(self.worst, float(t.detach()[diff].abs().max()) / max(scale, 1e-30))
+        return t * m.to(t.dtype)
+
+
+_RELU = [F.relu]
+
+
+def _relu(t):
+    return _RELU[0](t)
+
+
 def _bn(sd, prefix, x, training):
     return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
                         sd[prefix + ".weight"], sd[prefix + ".bias"], training,
@@ -133,12 +174,15 @@ def _count_bn(sd, prefix, training):
         sd[prefix + ".num_batches_tracked"] += 1
 
 
-def forward_imagenet(sd, x, arch, training=True):
+def forward_imagenet(sd, x, arch, training=True, q=_id):
     """resnet_pytorch.py:279-295 (stem, 4 stages, GAP, fc); blocks :95-111 and
-    :149-169 (stride on the 3x3 = v1.5)."""
+    :149-169 (stride on the 3x3 = v1.5).  ``q`` (identity by default) is applied
+    wherever the MI355X product STORES a tensor (input, weights, conv outputs,
+    activated outputs, pooled features): ``q=bf16_storage`` gives the bf16-storage
+    variant of the same arithmetic; with the default this is the reference."""
     kind, layers, groups, _ = IMAGENET_ARCHS[arch]
-    x = F.conv2d(x, sd["conv1.weight"], None, 2, 3)
-    x = F.relu(_bn(sd, "bn1", x, training)); _count_bn(sd, "bn1", training)
+    x = q(F.conv2d(q(x), q(sd["conv1.weight"]), None, 2, 3))
+    x = q(_relu(_bn(sd, "bn1", x, training))); _count_bn(sd, "bn1", training)
     x = F.max_pool2d(x, 3, 2, 1)
     for li, nb in enumerate(layers):
         for b in range(nb):
@@ -146,58 +190,59 @@ def forward_imagenet(sd, x, arch, training=True):
             stride = 2 if (b == 0 and li > 0) else 1
             idt = x
             if kind == "bottleneck":
-                o = F.conv2d(x, sd[p + ".conv1.weight"])
-                o = F.relu(_bn(sd, p + ".bn1", o, training)); _count_bn(sd, p + ".bn1", training)
-                o = F.conv2d(o, sd[p + ".conv2.weight"], None, stride, 1, 1, groups)
-                o = F.relu(_bn(sd, p + ".bn2", o, training)); _count_bn(sd, p + ".bn2", training)
-                o = F.conv2d(o, sd[p + ".conv3.weight"])
+                o = q(F.conv2d(x, q(sd[p + ".conv1.weight"])))
+                o = q(_relu(_bn(sd, p + ".bn1", o, training))); _count_bn(sd, p + ".bn1", training)
+                o = q(F.conv2d(o, q(sd[p + ".conv2.weight"]), None, stride, 1, 1, groups))
+                o = q(_relu(_bn(sd, p + ".bn2", o, training))); _count_bn(sd, p + ".bn2", training)
+                o = q(F.conv2d(o, q(sd[p + ".conv3.weight"])))
                 o = _bn(sd, p + ".bn3", o, training); _count_bn(sd, p + ".bn3", training)
             else:
-                o = F.conv2d(x, sd[p + ".conv1.weight"], None, stride, 1)
-                o = F.relu(_bn(sd, p + ".bn1", o, training)); _count_bn(sd, p + ".bn1", training)
-                o = F.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1)
+                o = q(F.conv2d(x, q(sd[p + ".conv1.weight"]), None, stride, 1))
+                o = q(_relu(_bn(sd, p + ".bn1", o, training))); _count_bn(sd, p + ".bn1", training)
+                o = q(F.conv2d(o, q(sd[p + ".conv2.weight"]), None, 1, 1))
                 o = _bn(sd, p + ".bn2", o, training); _count_bn(sd, p + ".bn2", training)
             if (p + ".downsample.0.weight") in sd:
-                idt = F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride)
+                idt = q(F.conv2d(x, q(sd[p + ".downsample.0.weight"]), None, stride))
                 idt = _bn(sd, p + ".downsample.1", idt, training)
                 _count_bn(sd, p + ".downsample.1", training)
-            x = F.relu(o + idt)
-    x = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
-    return F.linear(x, sd["fc.weight"], sd["fc.bias"])
+            x = q(_relu(o + idt))
+    x = q(torch.flatten(F.adaptive_avg_pool2d(x, 1), 1))
+    return F.linear(x, q(sd["fc.weight"]), sd["fc.bias"])
 
 
-def forward_cifar(sd, x, arch="resnet32", training=True):
+def forward_cifar(sd, x, arch="resnet32", training=True, q=_id):
     """resnet_cifar.py:204-212; blocks :133-138; option-A shortcut :125-126
-    (spatial ::2 subsample, planes//4 zero channels on each side)."""
+    (spatial ::2 subsample, planes//4 zero channels on each side).  ``q``: see
+    forward_imagenet."""
     nbs = CIFAR_ARCHS[arch]
-    x = F.conv2d(x, sd["conv1.weight"], None, 1, 1)
-    x = F.relu(_bn(sd, "bn1", x, training)); _count_bn(sd, "bn1", training)
+    x = q(F.conv2d(q(x), q(sd["conv1.weight"]), None, 1, 1))
+    x = q(_relu(_bn(sd, "bn1", x, training))); _count_bn(sd, "bn1", training)
     inpl = 16
     for li, (planes, nb) in enumerate(zip((16, 32, 64), nbs)):
         for b in range(nb):
             p = "layer%d.%d" % (li + 1, b)
             stride = 2 if (b == 0 and li > 0) else 1
-            o = F.conv2d(x, sd[p + ".conv1.weight"], None, stride, 1)
-            o = F.relu(_bn(sd, p + ".bn1", o, training)); _count_bn(sd, p + ".bn1", training)
-            o = F.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1)
+            o = q(F.conv2d(x, q(sd[p + ".conv1.weight"]), None, stride, 1))
+            o = q(_relu(_bn(sd, p + ".bn1", o, training))); _count_bn(sd, p + ".bn1", training)
+            o = q(F.conv2d(o, q(sd[p + ".conv2.weight"]), None, 1, 1))
             o = _bn(sd, p + ".bn2", o, training); _count_bn(sd, p + ".bn2", training)
             sc = x
             if stride != 1 or inpl != planes:
                 sc = F.pad(x[:, :, ::2, ::2], (0, 0, 0, 0, planes // 4, planes // 4))
-            x = F.relu(o + sc)
+            x = q(_relu(o + sc))
             inpl = planes
-    x = F.avg_pool2d(x, x.size(3)).view(x.size(0), -1)
-    return F.linear(x, sd["linear.weight"], sd["linear.bias"])
+    x = q(F.avg_pool2d(x, x.size(3)).view(x.size(0), -1))
+    return F.linear(x, q(sd["linear.weight"]), sd["linear.bias"])
 
 
-def forward(sd, x, arch, training=True):
+def forward(sd, x, arch, training=True, q=_id):
     if arch in CIFAR_ARCHS:
-        return forward_cifar(sd, x, arch, training)
-    return forward_imagenet(sd, x, arch, training)
+        return forward_cifar(sd, x, arch, training, q)
+    return forward_imagenet(sd, x, arch, training, q)
 
 
 # ----------------------------------------------------------------- train step
-def loss_and_grads(sd, x, y, table, arch, class_weight=None, reduction="mean"):
+def loss_and_grads(sd, x, y, table, arch, class_weight=None, reduction="mean", q=_id, relu_masks=None):
     """Forward (train mode, running stats updated in ``sd``), IIF loss
     (custom.py:28-36) and autograd gradients for every trainable key.
     Returns (loss, logits, {key: grad})."""
@@ -205,7 +250,12 @@ def loss_and_grads(sd, x, y, table, arch, class_weight=None, reduction="mean"):
     leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
     work = dict(sd)
     work.update(leaves)
-    logits = forward(work, x, arch, training=True)
+    if relu_masks is not None:
+        _RELU[0] = relu_masks
+    try:
+        logits = forward(work, x, arch, training=True, q=q)
+    finally:
+        _RELU[0] = F.relu
     for k in sd:                                   # running stats / counters
         if k not in leaves:
             sd[k] = work[k]
@@ -215,11 +265,11 @@ def loss_and_grads(sd, x, y, table, arch, class_weight=None, reduction="mean"):
 
 
 def train_step(sd, bufs, x, y, table, arch, lr, momentum=0.9, weight_decay=1e-4,
-               nesterov=False, class_weight=None, reduction="mean"):
+               nesterov=False, class_weight=None, reduction="mean", q=_id, relu_masks=None):
     """One iteration of classification/train.py:60-78 without the logging:
     forward, loss, backward, SGD.  ``bufs`` is a dict key -> momentum buffer
     (missing = first step).  Updates ``sd`` and ``bufs`` in place."""
-    loss, logits, grads = loss_and_grads(sd, x, y, table, arch, class_weight, reduction)
+    loss, logits, grads = loss_and_grads(sd, x, y, table, arch, class_weight, reduction, q, relu_masks)
     keys = list(grads.keys())
     params = [sd[k] for k in keys]
     blist = [bufs.get(k) for k in keys]

@@ -1,0 +1,189 @@
+"""End-to-end parity of the native ResNet training step against the CPU oracle
+(which is pinned to the reference by tests/golden/g7_nets.npz).
+
+fp32 parity mode: logits / loss / gradients / loss curve within 1e-4 relative
+(BASELINE.json north_star tolerance).  bf16 performance mode: same checks with
+the tolerance of bf16 storage (stated per assertion)."""
+import pytest
+import torch
+
+from oracle import iif_oracle as O
+from oracle import resnet_oracle as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class DS:
+    def __init__(self, c):
+        self.c = list(c)
+
+    def get_cls_num_list(self):
+        return self.c
+
+
+def _build(arch, num_classes, dt):
+    from iif_amd import resnet_cifar, resnet_pytorch
+    if arch in R.CIFAR_ARCHS:
+        sd = R.init_cifar(arch, num_classes, seed=3)
+        net = getattr(resnet_cifar, arch)(num_classes=num_classes, use_norm="None", compute_dtype=dt)
+    else:
+        sd = R.init_imagenet(arch, num_classes, seed=3)
+        net = getattr(resnet_pytorch, arch)(num_classes=num_classes, use_norm="None", pretrained="None", compute_dtype=dt)
+    net.load_state_dict(sd)
+    return net, sd
+
+
+def _data(B, hw, counts, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 3, hw, hw, generator=g)
+    prior = torch.tensor(counts, dtype=torch.float64)
+    y = torch.multinomial(prior / prior.sum(), B, replacement=True, generator=g)
+    return x, y
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+def gpu_relu_masks(net):
+    """The ReLU decisions the GPU step actually took (stored activated outputs > 0),
+    in forward order, as NCHW bool tensors for oracle.ReluMasks."""
+    plan = net._saved
+    ys = [plan.stem.y] + [u.y for b in plan.blocks for u in b["units"]]
+    return [(y > 0).permute(0, 3, 1, 2).cpu() for y in ys]
+
+
+def damp_residual_branches(sd, arch, factor=0.25):
+    """Scale the last BN gain of every residual block.  A freshly initialised deep
+    ResNet evaluated on a handful of images amplifies fp32 rounding ~300x (measured:
+    the reference's own fp32 CPU gradients are 1-2e-2 away from an fp64 evaluation);
+    trained networks, and this damped init, are well conditioned, so 1e-4 is testable."""
+    last = "bn3.weight" if R.IMAGENET_ARCHS.get(arch, ("basic",))[0] == "bottleneck" else "bn2.weight"
+    for k in sd:
+        if k.endswith(last) and k.startswith("layer"):
+            sd[k] = sd[k] * factor
+    return sd
+
+
+CASES = [("resnet32", 100, 8, 32), ("resnet20", 10, 5, 32), ("resnet50", 1000, 8, 64), ("resnet18", 365, 4, 96)]
+
+
+@pytest.mark.parametrize("arch,C,B,hw", CASES)
+def test_fp32_forward_backward_parity(arch, C, B, hw):
+    """Drop-in surface (model(x) -> criterion -> loss.backward()) in exact-fp32 mode
+    against the CPU oracle: logits, loss and EVERY parameter gradient within 1e-4
+    (2e-4 L2 per tensor), given the same ReLU decisions.  Two fp32 implementations
+    can round a pre-activation lying within ~1e-7 of zero to different signs; the
+    oracle therefore replays the decisions the GPU took, and the test asserts that
+    they differ from the oracle's own only on such near-zero elements."""
+    from iif_amd.custom import IIFLoss
+    counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
+    net, sd = _build(arch, C, torch.float32)
+    if arch not in R.CIFAR_ARCHS:
+        net.load_state_dict(damp_residual_branches(sd, arch))
+    x, y = _data(B, hw, counts)
+    table = O.iif_tables(counts)["raw"]
+    net.train()
+    crit = IIFLoss(DS(counts), variant="raw")
+    logits = net(x.to(DEV))
+    loss = crit(logits, y.to(DEV))
+    loss.backward()
+    masks = R.ReluMasks(gpu_relu_masks(net))
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    ref_loss, ref_logits, ref_grads = R.loss_and_grads(ref_sd, x, y, table, arch, relu_masks=masks)
+    assert masks.i == len(masks.masks)
+    assert masks.disagree <= 1e-4 * masks.total and masks.worst <= 1e-4, (masks.disagree, masks.total, masks.worst)
+    assert relerr(logits, ref_logits) <= 1e-4
+    assert relerr(loss, ref_loss) <= 1e-4
+    for k, p in net.named_parameters():
+        a, b = p.grad.double().cpu(), ref_grads[k].double()
+        e = (a - b).norm().item() / max(b.norm().item(), 1e-12)
+        assert e <= 2e-4, (k, e)
+    # running statistics / counters follow the reference
+    for k, v in net.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert relerr(v.float(), ref_sd[k].float()) <= 1e-5, k
+    # eval mode uses the running statistics
+    net.eval()
+    with torch.no_grad():
+        ev = net(x.to(DEV))
+    ref_ev = R.forward(ref_sd, x, arch, training=False)
+    assert relerr(ev, ref_ev) <= 1e-4
+
+
+@pytest.mark.parametrize("arch,C,B,hw", [("resnet32", 100, 8, 32), ("resnet50", 1000, 8, 64)])
+def test_fp32_loss_curve_fused_step(arch, C, B, hw):
+    """forward -> fused IIF loss -> backward -> ONE fused SGD launch, 4 steps with
+    the first-epoch warm-up (train.py:52-56): the loss sequence matches the CPU
+    reference to 1e-4 and the final weights to 2e-4 (same ReLU decisions, see above)."""
+    from iif_amd.custom import IIFLoss
+    counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
+    net, sd = _build(arch, C, torch.float32)
+    if arch not in R.CIFAR_ARCHS:
+        net.load_state_dict(damp_residual_branches(sd, arch))
+    x, y = _data(B, hw, counts, seed=9)
+    table = O.iif_tables(counts)["raw"]
+    crit = IIFLoss(DS(counts), variant="raw")
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    bufs = {}
+    xd, yd = x.to(DEV), y.to(DEV)
+    net.train()
+    for it in range(4):
+        lr = 0.1 * O.warmup_factor(it, 1000)
+        loss, _ = net.loss_and_backward(xd, yd, crit)
+        masks = R.ReluMasks(gpu_relu_masks(net))
+        net.sgd_step(lr, 0.9, 1e-4)
+        ref_loss, _ = R.train_step(ref_sd, bufs, x, y, table, arch, lr, relu_masks=masks)
+        assert masks.disagree <= 1e-4 * masks.total and masks.worst <= 1e-4
+        assert relerr(loss, ref_loss) <= 1e-4, (it, loss.item(), ref_loss.item())
+    for k, v in net.state_dict().items():
+        if v.is_floating_point():
+            assert relerr(v, ref_sd[k]) <= 2e-4, (k, relerr(v, ref_sd[k]))
+
+
+@pytest.mark.parametrize("arch,C,B,hw", [("resnet50", 1000, 8, 64), ("resnet32", 100, 16, 32)])
+def test_bf16_mode_against_bf16_storage_oracle(arch, C, B, hw):
+    """Performance mode (bf16 storage, fp32 accumulate).  The oracle run with
+    ``q=bf16_storage`` rounds the same tensors at the same places, so what is left
+    is accumulation order and 1-ulp bf16 rounding flips: at step 0 logits 2e-2 of
+    their range and loss 5e-3; 8e-2 / 2e-2 after SGD steps.  Against the pure-fp32 reference the same
+    run must stay within bf16 noise (loss 3e-2)."""
+    from iif_amd.custom import IIFLoss
+    counts = [max(int(1280 * (5 / 1280) ** (i / (C - 1.0))), 1) for i in range(C)]
+    net, sd = _build(arch, C, torch.bfloat16)
+    if arch not in R.CIFAR_ARCHS:
+        net.load_state_dict(damp_residual_branches(sd, arch))
+    x, y = _data(B, hw, counts, seed=11)
+    table = O.iif_tables(counts)["raw"]
+    crit = IIFLoss(DS(counts), variant="raw")
+    q_sd = {k: v.clone() for k, v in sd.items()}
+    f_sd = {k: v.clone() for k, v in sd.items()}
+    qb, fb = {}, {}
+    net.train()
+    for it in range(3):
+        lr = 0.1 * O.warmup_factor(it, 1000)
+        q_loss, q_logits = R.train_step(q_sd, qb, x, y, table, arch, lr, q=R.bf16_storage)
+        f_loss, _ = R.train_step(f_sd, fb, x, y, table, arch, lr)
+        loss, logits = net.loss_and_backward(x.to(DEV), y.to(DEV), crit)
+        net.sgd_step(lr, 0.9, 1e-4)
+        # step 0: same weights, only forward rounding differs.  Later steps also carry the bf16
+        # storage of the GPU's gradient tensors, which the oracle's autograd keeps in fp32.
+        assert relerr(logits, q_logits) <= (2e-2 if it == 0 else 8e-2), (it, relerr(logits, q_logits))
+        assert relerr(loss, q_loss) <= (5e-3 if it == 0 else 2e-2), (it, loss.item(), q_loss.item())
+        assert relerr(loss, f_loss) <= 3e-2, (it, loss.item(), f_loss.item())
+
+
+def test_state_dict_roundtrip_and_device_move():
+    from iif_amd import resnet_cifar
+    net = resnet_cifar.resnet20(num_classes=10, device="cpu", compute_dtype=torch.float32)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    assert net._arena.is_cuda and net.conv1.weight.is_cuda
+    for k, v in net.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k
+    assert net.linear.weight.data_ptr() >= net._arena.data_ptr()
+    x = torch.randn(2, 3, 32, 32, device=DEV)
+    out = net(x)
+    assert out.shape == (2, 10) and torch.isfinite(out).all()
