@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of a full ResNet50 + IIF training step on
+synthetic ImageNet-LT-shaped batches, bs=256 per GPU, bf16 storage / fp32
+accumulate (BASELINE.json configs[1]; weak scaling over N GPUs of one node).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = forward + fused IIF loss + backward + gradient all-reduce (N>1) + fused
+SGD, all through the hand-written gfx950 kernels (libiif_amd.so); inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects in that line:
+  roofline     - the MFMA implicit-GEMM convolution family (forward / dgrad /
+                 wgrad kernels): algorithmic FLOPs of every launch in one step
+                 divided by the summed launch durations measured with HIP events
+                 on the launching stream over the timed region.
+  cpu_baseline - the CPU oracle (torch-CPU restatement of the reference step,
+                 oracle/) timed on the host cores of this box on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def lt_counts(C, top, bottom=5):
+    return [max(int(top * (bottom / top) ** (i / max(C - 1.0, 1.0))), 1) for i in range(C)]
+
+
+class _Counts(object):
+    def __init__(self, c):
+        self.c = c
+
+    def get_cls_num_list(self):
+        return self.c
+
+
+class ConvTimer(object):
+    """HIP-event brackets around every MFMA convolution launch (on the stream the
+    launch goes to: the kernels are enqueued on torch's current stream)."""
+
+    def __init__(self):
+        self.records = []      # (kind, flops, start_event, stop_event)
+
+    def wrap(self, ops):
+        timer = self
+        orig = {k: getattr(ops, k) for k in ("conv_forward", "conv_dgrad", "conv_wgrad")}
+
+        def flops_fwd(x, w, r, s, stride, pad, **kw):
+            n, h, wd, cin = x.shape
+            ho, wo = ops.conv_out_hw(h, wd, r, s, stride, pad)
+            return 2.0 * n * ho * wo * w.shape[0] * r * s * cin
+
+        def conv_forward(x, w, r, s, stride, pad, **kw):
+            return timer._timed("fwd", flops_fwd(x, w, r, s, stride, pad), orig["conv_forward"], x, w, r, s, stride, pad, **kw)
+
+        def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, **kw):
+            n, ho, wo, cout = dy.shape
+            fl = 2.0 * n * ho * wo * cout * r * s * wt.shape[0]
+            return timer._timed("dgrad", fl, orig["conv_dgrad"], dy, wt, r, s, stride, pad, in_hw, **kw)
+
+        def conv_wgrad(x, dy, r, s, stride, pad, **kw):
+            n, ho, wo, cout = dy.shape
+            fl = 2.0 * n * ho * wo * cout * r * s * x.shape[3]
+            return timer._timed("wgrad", fl, orig["conv_wgrad"], x, dy, r, s, stride, pad, **kw)
+
+        ops.conv_forward, ops.conv_dgrad, ops.conv_wgrad = conv_forward, conv_dgrad, conv_wgrad
+        self._orig, self._ops = orig, ops
+
+    def unwrap(self):
+        for k, v in self._orig.items():
+            setattr(self._ops, k, v)
+
+    def _timed(self, kind, flops, fn, *a, **kw):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*a, **kw)
+        e1.record()
+        self.records.append((kind, flops, e0, e1))
+        return out
+
+    def summary(self):
+        tot_ms, tot_fl, by = 0.0, 0.0, {}
+        for kind, fl, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            tot_ms += ms; tot_fl += fl
+            k = by.setdefault(kind, [0, 0.0, 0.0])
+            k[0] += 1; k[1] += ms; k[2] += fl
+        return tot_ms, tot_fl, by
+
+
+def cpu_baseline(counts, sample_bs, steps):
+    """The CPU oracle (torch-CPU fp32 restatement of the reference training step)
+    on a bounded sample: same model, same loss, same SGD, `sample_bs` images."""
+    from oracle import iif_oracle as O
+    from oracle import resnet_oracle as R
+    # threads = this process's CPU share (a 1-GPU box gives 16 cores; os.cpu_count() reports the whole host)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("IIF_CPU_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    sd = R.init_imagenet("resnet50", len(counts), seed=0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(sample_bs, 3, 224, 224, generator=g)
+    prior = torch.tensor(counts, dtype=torch.float64)
+    y = torch.multinomial(prior / prior.sum(), sample_bs, replacement=True, generator=g)
+    table = O.iif_tables(counts)["raw"]
+    bufs = {}
+    R.train_step(sd, bufs, x, y, table, "resnet50", 1e-4)            # warm-up
+    t0 = time.time()
+    for it in range(steps):
+        R.train_step(sd, bufs, x, y, table, "resnet50", 1e-4)
+    dt = time.time() - t0
+    return {"value": round(sample_bs * steps / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "oracle.resnet_oracle.train_step, ResNet50+IIF(raw) fp32, bs=%d 224x224, %d steps after 1 warm-up "
+                      "(%.1f s)" % (sample_bs, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--model", default="resnet50")
+    ap.add_argument("--image", type=int, default=224)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    from iif_amd import ops, resnet_pytorch
+    from iif_amd.custom import IIFLoss
+    from iif_amd.ddp import broadcast_parameters
+
+    C = 1000
+    counts = lt_counts(C, 1280)                      # ImageNet-LT-shaped profile
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    net = getattr(resnet_pytorch, args.model)(num_classes=C, use_norm="None", pretrained="None", device=dev,
+                                              compute_dtype=cdt)
+    net.train()
+    broadcast_parameters(net)
+    crit = IIFLoss(_Counts(counts), variant="raw", reduction="mean", device=dev)
+    reducer = net.make_reducer() if world > 1 else None
+    g = torch.Generator().manual_seed(1234 + rank)
+    B = args.batch
+    x = torch.randn(B, 3, args.image, args.image, generator=g).to(dev)
+    prior = torch.tensor(counts, dtype=torch.float64)
+    y = torch.multinomial(prior / prior.sum(), B, replacement=True, generator=g).to(dev)
+    scale = reducer.grad_scale if reducer is not None else 1.0
+
+    def step(it):
+        lr = 0.1 * (1e-3 * (1 - min(it, 1000) / 1000.0) + min(it, 1000) / 1000.0)      # train.py:52-56 warm-up
+        loss, _ = net.loss_and_backward(x, y, crit, reducer=reducer)
+        net.sgd_step(lr, 0.9, 1e-4, grad_scale=scale)
+        return loss
+
+    def note(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    note("model built (%d params), starting %d warm-up steps" % (sum(p.numel() for p in net.parameters()), args.warmup))
+    for it in range(args.warmup):
+        step(it)
+        if it == 0:
+            torch.cuda.synchronize()
+            note("first step done")
+    timer = None
+    if not args.no_kernel_events:
+        timer = ConvTimer()
+        timer.wrap(ops)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        loss = step(args.warmup + it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if timer is not None:
+        timer.unwrap()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+    note("timed region: %.3f s for %d steps" % (dt, args.steps))
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec ResNet50+IIF ImageNet-LT bs=256/GPU",
+            "value": round(B * world * args.steps / dt, 2),
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if cdt == torch.bfloat16 else "f32", "data": "synthetic",
+            "config": {"workload": "%s + IIF(raw) training step, synthetic ImageNet-LT %dx%d, C=1000 (counts 1280..5), "
+                                   "bs=%d/GPU, SGD momentum 0.9 wd 1e-4 with warm-up, random init" % (args.model, args.image, args.image, B),
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4)},
+        }
+        if timer is not None:
+            tot_ms, tot_fl, by = timer.summary()
+            nl = len(timer.records)
+            ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "conv_igemm_kernel + conv_wgrad_kernel (implicit-GEMM convolution family)",
+                "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": nl // max(args.steps, 1),
+                "avg_launch_us": round(1000.0 * tot_ms / max(nl, 1), 2),
+                "algorithmic_gflop_per_step": round(tot_fl / max(args.steps, 1) / 1e9, 1),
+                "conv_ms_per_step": round(tot_ms / max(args.steps, 1), 3),
+                "by_kind_ms_per_step": {k: round(v[1] / max(args.steps, 1), 3) for k, v in by.items()},
+                "by_kind_tflops": {k: round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(counts, args.cpu_batch, args.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

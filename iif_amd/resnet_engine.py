@@ -304,7 +304,7 @@ class NativeResNet(nn.Module):
         self._saved = plan if training else None
         return plan.logits[:, :self.num_classes]
 
-    def run_backward(self, dlogits=None):
+    def run_backward(self, dlogits=None, reducer=None):
         """Native backward from d(loss)/d(logits); fills the gradient arena.
         ``dlogits`` None means the plan's own dlogits buffer was already filled
         (fused loss path)."""
@@ -313,16 +313,31 @@ class NativeResNet(nn.Module):
             raise RuntimeError("run_backward() without a preceding training-mode forward")
         if dlogits is not None:
             plan.dlogits[:, :self.num_classes].copy_(dlogits)
-        plan.backward()
+        plan.backward(reducer)
 
     # -------------------------------------------------- fused training step
     def sgd_step(self, lr, momentum=0.9, weight_decay=1e-4, nesterov=False, grad_scale=1.0):
         """ONE launch over the whole parameter arena (classification/train.py:199-204,78)."""
         ops.sgd_step(self._arena, self._grad_arena, self._mom_arena, lr, momentum, weight_decay, nesterov, grad_scale)
 
-    def loss_and_backward(self, x, targets, criterion, targets_b=None, lam=1.0):
+    def make_reducer(self, bucket_bytes=32 << 20, process_group=None):
+        """Bucketed, backward-overlapped all-reduce of the gradient arena (see iif_amd.ddp)."""
+        from .ddp import ArenaReducer
+        bounds = [o for (o, _, _) in self._offsets.values()]
+        return ArenaReducer(self._grad_arena, bounds, bucket_bytes, process_group)
+
+    def block_offsets(self):
+        """Arena offset of the first parameter of the stem, of every block (forward order) and of the head."""
+        first = lambda mod: min(self._offsets[(id(m), a)][0] for m in mod.modules()      # noqa: E731
+                                for a in ("weight", "bias") if (id(m), a) in self._offsets)
+        blocks = [first(b) for st in self._stages for b in st]
+        return {"stem": 0, "blocks": blocks, "head": first(self._head)}
+
+    def loss_and_backward(self, x, targets, criterion, targets_b=None, lam=1.0, reducer=None):
         """forward -> fused IIF loss (writes dlogits in the same pass) -> backward.
-        Returns (loss 0-dim tensor, logits view).  No autograd involved."""
+        Returns (loss 0-dim tensor, logits view).  No autograd involved.  With a
+        ``reducer`` the gradient all-reduce is launched bucket by bucket while
+        backward is still running."""
         from .custom import IIFLoss
         if not isinstance(criterion, IIFLoss):
             raise TypeError("loss_and_backward needs an iif_amd.custom.IIFLoss criterion")
@@ -337,7 +352,7 @@ class NativeResNet(nn.Module):
             _lib.ptr(targets_b), float(lam), 0, _lib.ptr(cw), -100, scale, B, C, _lib.ptr(plan.loss_rows),
             _lib.ptr(plan.loss), _lib.ptr(plan.dlogits), plan.dlogits.stride(0), 0, _lib.stream_ptr())
         _lib.check(rc, "iif_ce_fwd_bwd")
-        plan.backward()
+        plan.backward(reducer)
         return plan.loss, logits
 
     @property
@@ -558,10 +573,13 @@ class _Plan(object):
             return None
         return ops.conv_dgrad(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), out=dgrad_out, res=dgrad_res)
 
-    def backward(self):
+    def backward(self, reducer=None):
         net = self.net
         head = net._head
         n = self.n
+        offs = net.block_offsets() if reducer is not None else None
+        if reducer is not None:
+            reducer.begin()
         # ---- head: dlogits (fp32, pad columns are zero) -> fc grads -> pooled grad -> final activation grad
         ops.colsum_f32(self.dlogits, n, head.out_padded, head.out_padded, head._gb1d)
         if self.dt == torch.float32:
@@ -575,6 +593,8 @@ class _Plan(object):
         fh, fw, fc = self.final.shape[1], self.final.shape[2], self.final.shape[3]
         g = self._gbuf(("g", self.final.shape), self.final.shape)
         ops.avgpool_backward(dpooled.view(n, head.in_features), fh * fw, out=g.view(n, fh * fw, fc))
+        if reducer is not None:
+            reducer.gradients_ready_from(offs["head"])
         # ---- blocks in reverse
         for bi in range(len(self.blocks) - 1, -1, -1):
             b = self.blocks[bi]
@@ -600,6 +620,8 @@ class _Plan(object):
             else:
                 self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=g)
             g = gin
+            if reducer is not None:
+                reducer.gradients_ready_from(offs["blocks"][bi])
         # ---- stem
         u = self.stem
         if net.style == "imagenet":
@@ -609,6 +631,8 @@ class _Plan(object):
                        "iif_maxpool_backward")
             g = dy0
         self._unit_backward(u, g, u.y, need_dgrad=False)
+        if reducer is not None:
+            reducer.finish()
 
 
 def _eval_stats(bn, stats):
