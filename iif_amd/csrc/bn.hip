@@ -103,15 +103,31 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* x, Geo g, float*
     }
 }
 
+// Column sums of the [nblk][2][C] partials: a 256-thread block owns 32 channels, 8 lanes per channel
+// walk the partial rows (stride 8) in double and are combined in fixed order through LDS.
+__device__ __forceinline__ void reduce_partials(const float* partial, int nblk, int C, int c, int lane8,
+                                                double (&sh)[2][8][32], int cl, double& s, double& q) {
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int r = lane8; r < nblk; r += 8) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
+    sh[0][lane8][cl] = a; sh[1][lane8][cl] = b;
+    __syncthreads();
+    s = 0.0; q = 0.0;
+    if (lane8 == 0)
+        for (int j = 0; j < 8; ++j) { s += sh[0][j][cl]; q += sh[1][j][cl]; }
+}
+
 // stats layout: [4][C] = mean, invstd, a (=gamma*invstd), b (=beta-mean*a)
 __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partial, int nblk, int C, double count,
                                                           const float* gamma, const float* beta, float eps,
                                                           float momentum, float* running_mean, float* running_var,
                                                           float* stats) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += partial[(int64_t)b * 2 * C + c]; q += partial[(int64_t)b * 2 * C + C + c]; }
+    __shared__ double sh[2][8][32];
+    const int cl = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s, q;
+    reduce_partials(partial, nblk, C, c, lane8, sh, cl, s, q);
+    if (lane8 != 0 || c >= C) return;
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -196,10 +212,12 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* g_, const T
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* partial, int nblk, int C, double count,
                                                               const float* gamma, const float* stats, float* dgamma,
                                                               float* dbeta, float* coef) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) { s1 += partial[(int64_t)b * 2 * C + c]; s2 += partial[(int64_t)b * 2 * C + C + c]; }
+    __shared__ double sh[2][8][32];
+    const int cl = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s1, s2;
+    reduce_partials(partial, nblk, C, c, lane8, sh, cl, s1, s2);
+    if (lane8 != 0 || c >= C) return;
     dgamma[c] = (float)s2;
     dbeta[c] = (float)s1;
     const float invstd = stats[C + c];
@@ -239,11 +257,11 @@ template <typename T>
 int bn_forward_t(const T* x, int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum,
                  float* rm, float* rv, float* stats, float* ws, int64_t ws_bytes, hipStream_t st) {
     constexpr int V = VT<T>::V;
-    Geo g = make_geo(M, C, V, 1024);
+    Geo g = make_geo(M, C, V, 512);
     if ((int64_t)g.nblk * 2 * C * 4 > ws_bytes) return IIF_EINVAL;
     hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(g.nblk, g.colblocks), dim3(256), 0, st, x, g, ws);
     IIF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, g.nblk, C, (double)M, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, ws, g.nblk, C, (double)M, gamma,
                        beta, eps, momentum, rm, rv, stats);
     IIF_LAUNCH_CHECK();
     return IIF_OK;
@@ -269,7 +287,7 @@ template <typename T>
 int bn_backward_t(const T* gy, const T* ymask, const T* x, const float* stats, const float* gamma, int64_t M, int C,
                   float* dgamma, float* dbeta, T* dx, T* gm, float* ws, int64_t ws_bytes, hipStream_t st) {
     constexpr int V = VT<T>::V;
-    Geo g = make_geo(M, C, V, 1024);
+    Geo g = make_geo(M, C, V, 512);
     const int64_t need = ((int64_t)g.nblk * 2 * C + 3 * C) * 4;
     if (need > ws_bytes) return IIF_EINVAL;
     float* coef = ws + (int64_t)g.nblk * 2 * C;
@@ -277,7 +295,7 @@ int bn_backward_t(const T* gy, const T* ymask, const T* x, const float* stats, c
     if (ymask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), rgrid, blk, 0, st, gy, ymask, x, stats, g, ws);
     else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), rgrid, blk, 0, st, gy, ymask, x, stats, g, ws);
     IIF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), blk, 0, st, ws, g.nblk, C, (double)M, gamma, stats,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), blk, 0, st, ws, g.nblk, C, (double)M, gamma, stats,
                        dgamma, dbeta, coef);
     IIF_LAUNCH_CHECK();
     const int cv = C / V;
