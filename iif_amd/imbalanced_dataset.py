@@ -1,0 +1,90 @@
+"""Class-count / class-map arithmetic of the reference's long-tailed datasets
+(the part of classification/imbalanced_dataset.py that feeds ``IIFLoss``) plus
+synthetic long-tailed datasets of the same shapes.  Image IO, augmentation and
+samplers of the reference are out of scope; there is no network in
+this environment, so every dataset here is generated from a seed.
+"""
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+def img_num_per_cls(cls_num, n_images, imb_type="exp", imb_factor=0.01):
+    """Per-class image counts of the imbalanced CIFAR subsets
+    (imbalanced_dataset.py:23-37): python-float power, ``int()`` truncation."""
+    img_max = n_images / cls_num
+    if imb_type == "exp":
+        return [int(img_max * (imb_factor ** (i / (cls_num - 1.0)))) for i in range(cls_num)]
+    if imb_type == "step":
+        return [int(img_max)] * (cls_num // 2) + [int(img_max * imb_factor)] * (cls_num // 2)
+    return [int(img_max)] * cls_num
+
+
+def lt_class_map(targets, num_classes):
+    """Rank classes by descending count and remap labels (imbalanced_dataset.py:112-127).
+
+    The reference's ``np.argsort(-counts)`` is not stable, so its order among
+    equal-count classes is unspecified; here ties keep ascending original class
+    id (stable sort).  Returns (class_map, remapped_targets, cls_num_list).
+    """
+    t = np.asarray(targets, dtype=np.int64)
+    counts = np.bincount(t, minlength=num_classes)[:num_classes]
+    order = np.argsort(-counts, kind="stable")
+    class_map = np.empty(num_classes, dtype=np.int64)
+    class_map[order] = np.arange(num_classes)
+    new_t = class_map[t]
+    cls_num_list = np.bincount(new_t, minlength=num_classes)[:num_classes]
+    return class_map.tolist(), new_t.tolist(), [int(v) for v in cls_num_list]
+
+
+def lt_profile(num_classes, top, bottom=5):
+    """Exponential head-to-tail profile used for the synthetic ImageNet-LT / Places-LT shapes."""
+    return [max(int(top * (bottom / top) ** (i / max(num_classes - 1.0, 1.0))), 1) for i in range(num_classes)]
+
+
+class SyntheticLT(Dataset):
+    """Long-tailed synthetic image classification set: labels follow
+    ``cls_num_list`` exactly, images are class-dependent Gaussian blobs generated
+    from (seed, index) — already 'normalised', as the reference normalises on the
+    host (initialisers.py:59,132)."""
+
+    def __init__(self, cls_num_list, image_size, seed=0, length=None):
+        self.cls_num_list = [int(c) for c in cls_num_list]
+        self.num_classes = len(self.cls_num_list)
+        self.image_size = image_size
+        self.seed = seed
+        t = np.repeat(np.arange(self.num_classes), self.cls_num_list)
+        rng = np.random.RandomState(seed)
+        rng.shuffle(t)
+        if length is not None:
+            t = t[:length]
+        self.targets = t.tolist()
+        g = torch.Generator().manual_seed(seed)
+        self._means = torch.randn(self.num_classes, 3, 1, 1, generator=g) * 0.5
+
+    def __len__(self):
+        return len(self.targets)
+
+    def __getitem__(self, i):
+        y = self.targets[i]
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        x = torch.randn(3, self.image_size, self.image_size, generator=g) + self._means[y]
+        return x, y
+
+    def get_cls_num_list(self):
+        return self.cls_num_list
+
+
+def synthetic_cifar_lt(num_classes=100, imb_type="exp", imb_factor=0.01, seed=0, train=True):
+    counts = img_num_per_cls(num_classes, 50000, imb_type, imb_factor)
+    if not train:
+        counts = [10000 // num_classes // 10] * num_classes       # small balanced eval split
+    return SyntheticLT(counts, 32, seed if train else seed + 1)
+
+
+def synthetic_lt(name, seed=0, train=True, scale=1.0):
+    shapes = {"imagenet_lt": (1000, 1280), "places_lt": (365, 4980), "inat18": (8142, 1000)}
+    C, top = shapes[name]
+    counts = lt_profile(C, top) if train else [2] * C
+    counts = [max(int(c * scale), 1) for c in counts]
+    return SyntheticLT(counts, 224, seed if train else seed + 1)

@@ -1,0 +1,63 @@
+"""Criterion / data factories with the surface of classification/initialisers.py.
+Only the IIF and plain cross-entropy criteria are on the hot path; the datasets
+are the synthetic long-tailed sets of ``iif_amd.imbalanced_dataset`` (no
+torchvision / network here)."""
+import torch
+
+from . import custom, imbalanced_dataset
+
+
+def get_weights(dataset, device="cuda"):
+    """Deferred re-weighting class weights ``sum/count`` (initialisers.py:16-19)."""
+    c = torch.tensor(dataset.get_cls_num_list(), device=device)
+    return c.sum() / c
+
+
+class _UniformTable(object):
+    def __init__(self, n):
+        self.n = n
+
+    def get_cls_num_list(self):
+        return [1] * self.n
+
+
+def get_criterion(args, dataset, model, num_classes):
+    """initialisers.py:22-48.  'iif' -> fused IIFLoss; 'ce' -> the same fused kernel
+    with an all-ones table built by hand (plain softmax cross-entropy); the focal / BCE
+    branches of the reference are outside the hot path."""
+    device = getattr(args, "device", "cuda")
+    weight = get_weights(dataset, device) if getattr(args, "deffered", False) else None
+    if args.classif == "iif":
+        return custom.IIFLoss(dataset, variant=args.iif, iif_norm=args.iif_norm, reduction=args.reduction,
+                              device=device, weight=weight)
+    if args.classif == "ce":
+        crit = custom.IIFLoss(dataset, variant="raw", reduction=args.reduction, device=device, weight=weight)
+        ones = torch.ones(1, num_classes, device=device)
+        crit.iif = {k: ones for k in crit.iif}
+        crit.is_plain_ce = True
+        return crit
+    raise NotImplementedError("criterion %r is outside the IIF hot path (SURVEY §2a: FocalLoss hard-codes CUDA tensors "
+                              "and is used by no config)" % (args.classif,))
+
+
+def get_data(args):
+    """Synthetic stand-in for initialisers.py:51-112: returns
+    (dataset, num_classes, train_loader, test_loader, train_sampler)."""
+    name = args.dset_name.lower()
+    if name.startswith("cifar"):
+        C = 100 if "100" in name else 10
+        ds = imbalanced_dataset.synthetic_cifar_lt(C, args.imb_type, args.imb_factor, args.rand_number, True)
+        ds_test = imbalanced_dataset.synthetic_cifar_lt(C, args.imb_type, args.imb_factor, args.rand_number, False)
+    else:
+        key = {"imagenet": "imagenet_lt", "imagenet_lt": "imagenet_lt", "places_lt": "places_lt", "inat18": "inat18"}[name]
+        ds = imbalanced_dataset.synthetic_lt(key, args.rand_number, True, getattr(args, "synthetic_scale", 1.0))
+        ds_test = imbalanced_dataset.synthetic_lt(key, args.rand_number, False)
+    sampler = test_sampler = None
+    if getattr(args, "distributed", False):
+        sampler = torch.utils.data.distributed.DistributedSampler(ds)
+        test_sampler = torch.utils.data.distributed.DistributedSampler(ds_test, shuffle=False)
+    loader = torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
+                                         num_workers=args.workers, pin_memory=True, drop_last=True)
+    loader_test = torch.utils.data.DataLoader(ds_test, batch_size=args.batch_size, shuffle=False, sampler=test_sampler,
+                                              num_workers=args.workers, pin_memory=True)
+    return ds, ds.num_classes, loader, loader_test, sampler

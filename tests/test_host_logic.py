@@ -1,0 +1,87 @@
+"""CPU tests of the host-side mirrors: class-count / class-map arithmetic against
+the golden vectors, LR schedule against torch's schedulers, CLI surface."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from iif_amd import imbalanced_dataset as D
+
+
+def test_class_counts_bit_exact(golden):
+    g = golden("g1_class_counts")
+    for key in g.files:
+        c, imb_type, imb = key.split("_")
+        assert D.img_num_per_cls(int(c[1:]), 50000, imb_type, float(imb)) == g[key].tolist(), key
+
+
+@pytest.mark.parametrize("case", ["distinct8", "ties12", "lt200", "ties40"])
+def test_class_map(golden, case):
+    g = golden("g2_class_map")
+    C = len(g[case + "_class_map"])
+    cmap, tgt, cnl = D.lt_class_map(g[case + "_labels"], C)
+    assert cnl == g[case + "_cls_num_list"].tolist()          # the profile never depends on the tie rule
+    assert sorted(cmap) == list(range(C))
+    assert all(a >= b for a, b in zip(cnl, cnl[1:]))           # rank = descending count
+    if case in ("distinct8", "lt200"):                         # no ties: must equal the reference
+        assert cmap == g[case + "_class_map"].tolist() and tgt == g[case + "_targets"].tolist()
+    # stable tie rule: equal counts keep ascending original class id
+    old = np.bincount(g[case + "_labels"], minlength=C)
+    for a in range(C):
+        for b in range(a + 1, C):
+            if old[a] == old[b]:
+                assert cmap[a] < cmap[b]
+
+
+def test_synthetic_lt_dataset_follows_counts():
+    ds = D.synthetic_cifar_lt(100, "exp", 0.01, seed=0)
+    assert ds.get_cls_num_list() == D.img_num_per_cls(100, 50000, "exp", 0.01)
+    assert len(ds) == 10847
+    assert np.bincount(ds.targets, minlength=100).tolist() == ds.get_cls_num_list()
+    x, y = ds[5]
+    assert x.shape == (3, 32, 32) and 0 <= y < 100
+    x2, _ = ds[5]
+    assert torch.equal(x, x2)
+
+
+def test_lr_schedule_matches_torch_schedulers():
+    from iif_amd import train, utils
+    for cosine in (False, True):
+        args = train.get_args_parser().parse_args(["--epochs", "8", "--lr", "0.2", "--milestones", "3", "6"] +
+                                                  (["--cosine_scheduler"] if cosine else []))
+        p = torch.zeros(1, requires_grad=True)
+        opt = torch.optim.SGD([p], lr=args.lr)
+        sched = (torch.optim.lr_scheduler.CosineAnnealingLR(opt, args.epochs, 0) if cosine
+                 else torch.optim.lr_scheduler.MultiStepLR(opt, milestones=args.milestones, gamma=args.lr_gamma))
+        iters = 12
+        for epoch in range(args.epochs):
+            warm = utils.warmup_lr_scheduler(opt, min(1000, iters - 1), 1.0 / 1000) if epoch < 1 else None
+            for it in range(iters):
+                assert math.isclose(train.lr_at(args, epoch, it, iters), opt.param_groups[0]["lr"], rel_tol=1e-9, abs_tol=1e-12)
+                opt.step()
+                if warm is not None:
+                    warm.step()
+            sched.step()
+
+
+def test_cli_flags_cover_the_reference_surface():
+    from iif_amd import train
+    p = train.get_args_parser()
+    have = {a for act in p._actions for a in act.option_strings}
+    ref_flags = ["--data-path", "--dset_name", "--rand_number", "--imb_type", "--imb_factor", "--model", "--device",
+                 "-b", "--batch-size", "--epochs", "-j", "--workers", "--opt", "--lr", "--cosine_scheduler", "--momentum",
+                 "--wd", "--weight-decay", "--milestones", "--lr-gamma", "--print-freq", "--output-dir", "--resume",
+                 "--load_from", "--classif", "--classif_norm", "--gamma", "--alpha", "--iif", "--iif_norm", "--decoup",
+                 "--mixup", "--sampler", "--reduction", "--start-epoch", "--cache-dataset", "--sync-bn", "--test-only",
+                 "--pretrained", "--deffered", "--auto-augment", "--random-erase", "--apex", "--apex-opt-level",
+                 "--world-size", "--dist-url", "--record-result"]
+    assert not [f for f in ref_flags if f not in have]
+
+
+def test_unbuilt_rows_fail_loudly():
+    from iif_amd import resnet_pytorch, resnet_cifar
+    with pytest.raises(NotImplementedError):
+        resnet_pytorch.resnext50_32x4d(num_classes=10, device="cpu")
+    with pytest.raises(NotImplementedError):
+        resnet_cifar.resnet32(num_classes=10, use_norm="cosine", device="cpu")

@@ -187,3 +187,20 @@ def test_state_dict_roundtrip_and_device_move():
     x = torch.randn(2, 3, 32, 32, device=DEV)
     out = net(x)
     assert out.shape == (2, 10) and torch.isfinite(out).all()
+
+
+def test_train_cli_runs_natively(tmp_path, capsys):
+    """`python -m iif_amd.train` surface: 1 epoch x 4 iterations of ResNet20 + IIF with mixup on the
+    synthetic CIFAR10-LT set, evaluation, checkpoint, then --resume/--test-only."""
+    from iif_amd import train
+    argv = ["--model", "resnet20", "--dset_name", "cifar10", "--classif", "iif", "--iif", "raw", "-b", "32", "--epochs", "1",
+            "--max-iters", "4", "-j", "0", "--print-freq", "2", "--mixup", "1.0", "--output-dir", str(tmp_path),
+            "--compute-dtype", "f32"]
+    args = train.get_args_parser().parse_args(argv)
+    train.main(args)
+    out = capsys.readouterr().out
+    assert "Acc@1" in out and "best acc is" in out
+    ckpt = torch.load(tmp_path / "checkpoint.pth", map_location="cpu", weights_only=False)
+    assert ckpt["epoch"] == 0 and "linear.weight" in ckpt["model"]
+    args2 = train.get_args_parser().parse_args(argv + ["--resume", str(tmp_path / "checkpoint.pth"), "--test-only"])
+    train.main(args2)
