@@ -53,6 +53,7 @@ class ConvTimer(object):
 
     def __init__(self):
         self.records = []      # (kind, flops, start_event, stop_event)
+        self.shapes = []
 
     def wrap(self, ops):
         timer = self
@@ -84,6 +85,7 @@ class ConvTimer(object):
             setattr(self._ops, k, v)
 
     def _timed(self, kind, flops, fn, *a, **kw):
+        self.shapes.append("%s %s x %s k%s s%s" % (kind, tuple(a[0].shape), tuple(a[1].shape), a[2], a[4]))
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -91,6 +93,13 @@ class ConvTimer(object):
         e1.record()
         self.records.append((kind, flops, e0, e1))
         return out
+
+    def per_shape(self):
+        agg = {}
+        for (kind, fl, e0, e1), sh in zip(self.records, self.shapes):
+            a = agg.setdefault(sh, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
+        return agg
 
     def summary(self):
         tot_ms, tot_fl, by = 0.0, 0.0, {}
@@ -144,6 +153,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--per-shape", action="store_true", help="print the per-shape conv table to stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,6 +243,9 @@ def main():
                                    "bs=%d/GPU, SGD momentum 0.9 wd 1e-4 with warm-up, random init" % (args.model, args.image, args.image, B),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4)},
         }
+        if timer is not None and args.per_shape:
+            for sh, (cnt, ms, fl) in sorted(timer.per_shape().items(), key=lambda kv: -kv[1][1]):
+                print("[conv] %-70s n=%3d  %8.3f ms/step  %7.1f TFLOP/s" % (sh, cnt // args.steps, ms / args.steps, fl / (ms * 1e-3) / 1e12), file=sys.stderr)
         if timer is not None:
             tot_ms, tot_fl, by = timer.summary()
             nl = len(timer.records)

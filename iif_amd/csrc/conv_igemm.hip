@@ -25,6 +25,8 @@
 //   makes every ds_read_b128 lane group hit 16 distinct 16-byte bank slots.
 //   blockIdx -> tile map is XCD-aware: the n-tiles of one pixel tile run
 //   back-to-back on the same XCD so the activation tile is re-read from its L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -40,6 +42,56 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+
+// epilogue: lane holds channels n0 + wn*BN/2 + ci*16 + fc*4 + {0..3} of pixel m0 + wm*64 + pj*16 + fr
+template <typename T, int BN, bool OUTF32>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BN / 32][4], int m0, int n0, int wm, int wn,
+                                              int fr, int fc) {
+    constexpr int CI = BN / 32;
+    using OT = typename std::conditional<OUTF32, float, T>::type;
+    const bool vec_ok = (a.Cd & 3) == 0;
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) {
+        const int m = m0 + wm * 64 + pj * 16 + fr;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+            const int n = n0 + wn * (BN / 2) + ci * 16 + fc * 4;
+            if (n >= a.Cd) continue;
+            float v[4] = {acc[ci][pj].x, acc[ci][pj].y, acc[ci][pj].z, acc[ci][pj].w};
+            const int64_t o = (int64_t)m * a.Cd + n;
+            const int cnt = a.Cd - n < 4 ? a.Cd - n : 4;
+            if (a.bias)
+                for (int q = 0; q < cnt; ++q) v[q] += a.bias[n + q];
+            OT* dp = reinterpret_cast<OT*>(a.dst) + o;
+            const OT* rp = reinterpret_cast<const OT*>(a.res) + o;
+            if (vec_ok) {
+                if constexpr (sizeof(OT) == 4) {
+                    if (a.res) { const f32x4 t = *reinterpret_cast<const f32x4*>(rp); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                    *reinterpret_cast<f32x4*>(dp) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    if (a.res) {
+                        const u32x2 t = *reinterpret_cast<const u32x2*>(rp);
+                        v[0] += bf16_bits_to_f32(t.x & 0xffffu); v[1] += __uint_as_float(t.x & 0xffff0000u);
+                        v[2] += bf16_bits_to_f32(t.y & 0xffffu); v[3] += __uint_as_float(t.y & 0xffff0000u);
+                    }
+                    u32x2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(dp) = w;
+                }
+            } else {
+                for (int q = 0; q < cnt; ++q) {
+                    if constexpr (sizeof(OT) == 4) {
+                        float t = v[q]; if (a.res) t += rp[q];
+                        dp[q] = t;
+                    } else {
+                        float t = v[q]; if (a.res) t += bf16_bits_to_f32(rp[q]);
+                        dp[q] = f32_to_bf16_bits(t);
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <typename T, int BN, bool OUTF32>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
@@ -177,54 +229,156 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds channels n0 + wn*BN/2 + ci*16 + fc*4 + {0..3} of pixel m0 + wm*64 + pj*16 + fr
-    using OT = typename std::conditional<OUTF32, float, T>::type;
-    const bool vec_ok = (a.Cd & 3) == 0;
+    conv_epilogue<T, BN, OUTF32>(a, acc, m0, n0, wm, wn, fr, fc);
+}
+
+// ------------------------------------------------------------------------------------------
+// Pipelined variant: operands go HBM/L2 -> LDS by buffer_load ... lds (LDS-DMA, no staging
+// registers), three LDS stages, loads of K step k+2 in flight while step k is multiplied, ONE
+// raw s_barrier per step behind a counted s_waitcnt vmcnt (never 0 inside the loop).
+//   * the DMA destination is lane-linear (wave base + lane*16), so the XOR swizzle is applied to
+//     the per-lane SOURCE chunk: lane l of a 16-row piece fetches chunk (l&3)^f(l>>4) of row l>>2;
+//     the ds_read side is unchanged;
+//   * out-of-image taps, rows >= M, channels >= Cd and the ragged K tail are addressed out of the
+//     buffer range: the hardware range check returns zeros, no predicated loads.
+// Same tile shape, fragment maps and epilogue as the register-staged kernel above.
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <typename T, int BN, bool OUTF32>
+__global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+    constexpr int BM = 128;
+    constexpr int PE = ET<T>::PE, KE = ET<T>::KE;
+    constexpr int NBI = BN / 64;        // weight DMA pieces per wave per stage
+    constexpr int CI = BN / 32;
+    constexpr int STAGE = (BM + BN) * 64;
+    constexpr int LPS = 2 + NBI;        // DMA instructions per wave per stage
+    constexpr unsigned OOB = 0xfffffff0u;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int mt = (j / a.ntiles) * 8 + xcd, nt = j % a.ntiles;
+    if (mt >= a.mtiles) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src), 0, src_bytes, 0x00020000);
+    const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wgt), 0, wgt_bytes, 0x00020000);
+
+    // ---- this lane's fixed role inside every 16-row DMA piece: row l>>2, source chunk (l&3)^f(l>>4)
+    const int prow = lane >> 2;
+    const int chunk = (lane & 3) ^ swz(prow);
+    int by[2], bx[2], ib[2];
+    bool mv[2];
+    const int HW = a.Hd * a.Wd;
 #pragma unroll
-    for (int pj = 0; pj < 4; ++pj) {
-        const int m = m0 + wm * 64 + pj * 16 + fr;
-        if (m >= a.M) continue;
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 16 * (2 * wave + i) + prow;
+        mv[i] = m < a.M;
+        const int mm = mv[i] ? m : 0;
+        const int n = mm / HW, rem = mm - n * HW;
+        const int y = rem / a.Wd, x = rem - y * a.Wd;
+        by[i] = a.transposed ? y + a.pad : (y << a.sshift) - a.pad;
+        bx[i] = a.transposed ? x + a.pad : (x << a.sshift) - a.pad;
+        ib[i] = n * a.Hs * a.Ws;
+    }
+    unsigned wrow[NBI];
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+        const int n = n0 + 16 * (NBI * wave + i) + prow;
+        wrow[i] = n < a.Cd ? (unsigned)n * (unsigned)a.ldw * (unsigned)sizeof(T) : OOB;
+    }
+    int e = chunk * PE;
+    int tap = e / a.Cs;
+    int c = e - tap * a.Cs;
+    int r = tap / a.S;
+    int s = tap - r * a.S;
+
+    auto issue = [&](int stage) {
+        unsigned char* A = smem + stage * STAGE;
+        unsigned char* B = A + BM * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int ys, xs;
+            bool ok = mv[i] && r < a.R;
+            if (a.transposed) {
+                const int ty = by[i] - r, tx = bx[i] - s;
+                ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & a.sshift) == 0;
+                ys = ty >> a.sshift; xs = tx >> a.sshift;
+                ok = ok && ys < a.Hs && xs < a.Ws;
+            } else {
+                ys = by[i] + r; xs = bx[i] + s;
+                ok = ok && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
+            }
+            const unsigned off = ok ? ((unsigned)(ib[i] + ys * a.Ws + xs) * (unsigned)a.Cs + (unsigned)c) * (unsigned)sizeof(T) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(A + (2 * wave + i) * 1024), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const unsigned off = (wrow[i] != OOB && e < a.K) ? wrow[i] + (unsigned)e * (unsigned)sizeof(T) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)(B + (NBI * wave + i) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    auto advance = [&]() {
+        e += KE;
+        c += KE;
+        while (c >= a.Cs) { c -= a.Cs; if (++s == a.S) { s = 0; ++r; } }
+    };
+
+    f32x4 acc[CI][4];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) acc[ci][pj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (a.K + KE - 1) / KE;
+    const int fr = lane & 15, fc = lane >> 4;
+    issue(0);
+    if (nk > 1) { advance(); issue(1); }
+    int stage = 0;
+    for (int k = 0; k < nk; ++k) {
+        // retire this wave's DMA of step k (leave step k+1's in flight), then meet the other waves
+        if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (k + 2 < nk) { advance(); issue(stage == 0 ? 2 : stage - 1); }   // stage (k+2)%3: last read in step k-1
+        const unsigned char* A = smem + stage * STAGE;
+        const unsigned char* B = A + BM * 64;
+        u32x4 wf[CI], xf[4];
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) {
-            const int n = n0 + wn * (BN / 2) + ci * 16 + fc * 4;
-            if (n >= a.Cd) continue;
-            float v[4] = {acc[ci][pj].x, acc[ci][pj].y, acc[ci][pj].z, acc[ci][pj].w};
-            const int64_t o = (int64_t)m * a.Cd + n;
-            const int cnt = a.Cd - n < 4 ? a.Cd - n : 4;
-            if (a.bias)
-                for (int q = 0; q < cnt; ++q) v[q] += a.bias[n + q];
-            OT* dp = reinterpret_cast<OT*>(a.dst) + o;
-            const OT* rp = reinterpret_cast<const OT*>(a.res) + o;
-            if (vec_ok) {
-                if constexpr (sizeof(OT) == 4) {
-                    if (a.res) { const f32x4 t = *reinterpret_cast<const f32x4*>(rp); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-                    *reinterpret_cast<f32x4*>(dp) = f32x4{v[0], v[1], v[2], v[3]};
+            const int row = wn * (BN / 2) + ci * 16 + fr;
+            wf[ci] = *reinterpret_cast<const u32x4*>(B + row * 64 + ((fc ^ swz(row)) << 4));
+        }
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) {
+            const int row = wm * 64 + pj * 16 + fr;
+            xf[pj] = *reinterpret_cast<const u32x4*>(A + row * 64 + ((fc ^ swz(row)) << 4));
+        }
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) {
+                if constexpr (sizeof(T) == 2) {
+                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wf[ci]), __builtin_bit_cast(bf16x8, xf[pj]), acc[ci][pj], 0, 0, 0);
                 } else {
-                    if (a.res) {
-                        const u32x2 t = *reinterpret_cast<const u32x2*>(rp);
-                        v[0] += bf16_bits_to_f32(t.x & 0xffffu); v[1] += __uint_as_float(t.x & 0xffff0000u);
-                        v[2] += bf16_bits_to_f32(t.y & 0xffffu); v[3] += __uint_as_float(t.y & 0xffff0000u);
-                    }
-                    u32x2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<u32x2*>(dp) = w;
-                }
-            } else {
-                for (int q = 0; q < cnt; ++q) {
-                    if constexpr (sizeof(OT) == 4) {
-                        float t = v[q]; if (a.res) t += rp[q];
-                        dp[q] = t;
-                    } else {
-                        float t = v[q]; if (a.res) t += bf16_bits_to_f32(rp[q]);
-                        dp[q] = f32_to_bf16_bits(t);
-                    }
+                    const f32x4 wv = __builtin_bit_cast(f32x4, wf[ci]), xv = __builtin_bit_cast(f32x4, xf[pj]);
+                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc[ci][pj], 0, 0, 0);
+                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc[ci][pj], 0, 0, 0);
+                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[ci][pj], 0, 0, 0);
+                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[ci][pj], 0, 0, 0);
                 }
             }
-        }
+        stage = stage == 2 ? 0 : stage + 1;
     }
+    conv_epilogue<T, BN, OUTF32>(a, acc, m0, n0, wm, wn, fr, fc);
 }
 
 template <typename T, bool OUTF32>
-int launch_conv(const ConvArgs& a0, hipStream_t st) {
+int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
     ConvArgs a = a0;
     a.mtiles = (a.M + 127) / 128;
     const bool narrow = a.Cd <= 64;
@@ -232,8 +386,18 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
     a.ntiles = (a.Cd + bn - 1) / bn;
     const int64_t blocks = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
     if (blocks > 0x7fffffff) return IIF_EUNSUPPORTED;
-    if (narrow) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, OUTF32>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<T, 128, OUTF32>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    static const bool force_v1 = getenv("IIF_CONV_REGSTAGE") != nullptr;
+    // LDS-DMA addressing is a 32-bit byte offset with a hardware range check: both operands must be < 2 GiB
+    const bool dma = !force_v1 && src_bytes < 0x7ffffff0LL && wgt_bytes < 0x7ffffff0LL;
+    const dim3 grid((unsigned)blocks), blk(256);
+    if (dma) {
+        const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
+        if (narrow) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 64, OUTF32>), grid, blk, 0, st, a, sb, wb);
+        else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 128, OUTF32>), grid, blk, 0, st, a, sb, wb);
+    } else {
+        if (narrow) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, OUTF32>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_kernel<T, 128, OUTF32>), grid, blk, 0, st, a);
+    }
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }
@@ -263,9 +427,12 @@ extern "C" int iif_conv_igemm(const iif_conv_desc* d, const void* src, const voi
     a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.transposed = d->transposed ? 1 : 0;
     a.ldw = d->ldw; a.M = (int)M; a.K = d->r * d->s * d->cs;
     hipStream_t st = as_stream(stream);
+    const int64_t esz = d->dtype == IIF_F32 ? 4 : 2;
+    const int64_t src_bytes = (int64_t)d->n * d->hs * d->ws * d->cs * esz;
+    const int64_t wgt_bytes = (int64_t)d->cd * d->ldw * esz;
     if (d->dtype == IIF_BF16) {
-        if (d->dst_dtype == IIF_F32) return launch_conv<unsigned short, true>(a, st);
-        return launch_conv<unsigned short, false>(a, st);
+        if (d->dst_dtype == IIF_F32) return launch_conv<unsigned short, true>(a, src_bytes, wgt_bytes, st);
+        return launch_conv<unsigned short, false>(a, src_bytes, wgt_bytes, st);
     }
-    return launch_conv<float, true>(a, st);
+    return launch_conv<float, true>(a, src_bytes, wgt_bytes, st);
 }

@@ -15,6 +15,8 @@
 // sums in fixed order: deterministic, no float atomics.
 // Replaces the cuDNN/MIOpen wgrad calls autograd issues for
 // classification/resnet_pytorch.py:46-62 and resnet_cifar.py:112-115.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -203,6 +205,196 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Pipelined variant: both tiles arrive by buffer_load ... lds (LDS-DMA), three LDS stages, one
+// raw s_barrier per step behind a counted vmcnt.  The DMA destination is lane-linear, so rows are
+// contiguous (no padding) and bank conflicts are removed by an XOR swizzle applied to the per-lane
+// SOURCE chunk and undone in the read address:
+//   bf16 (ds_read_b64_tr_b16, 8 rows x 32 B per half-wave): 32-B slot ^= row&7 (256-B rows) or
+//        (row>>1)&3 (128-B rows);   f32 (ds_read_b32 column reads): 64-B group ^= row&1.
+// Out-of-image taps / pixels >= M / channels >= Cd are addressed out of range (hardware zeros).
+typedef __attribute__((address_space(3))) void lds_void_w;
+
+template <typename T, int COLS> struct Swz {
+    static constexpr int RB = COLS * (int)sizeof(T);      // row bytes
+    // physical 16-byte chunk p of LDS row `row` holds logical chunk:
+    static __device__ __forceinline__ int logical(int p, int row) {
+        if constexpr (sizeof(T) == 2) {
+            const int key = RB == 256 ? (row & 7) : ((row >> 1) & 3);
+            return (((p >> 1) ^ key) << 1) | (p & 1);
+        } else {
+            return (((p >> 2) ^ (row & 1)) << 2) | (p & 3);
+        }
+    }
+    // byte address (within the tile) of logical byte column `colb` of row `row`
+    static __device__ __forceinline__ int addr(int row, int colb) {
+        if constexpr (sizeof(T) == 2) {
+            const int key = RB == 256 ? (row & 7) : ((row >> 1) & 3);
+            return row * RB + ((((colb >> 5) ^ key)) << 5) + (colb & 31);
+        } else {
+            return row * RB + ((((colb >> 6) ^ (row & 1))) << 6) + (colb & 63);
+        }
+    }
+};
+
+template <typename T, int BC>
+__global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(WgArgs a, unsigned x_bytes, unsigned dy_bytes) {
+    constexpr int PE = WT<T>::PE, ROWS = WT<T>::ROWS;
+    constexpr int BNW = 128;
+    using SX = Swz<T, BNW>;
+    using SY = Swz<T, BC>;
+    constexpr int XB = ROWS * SX::RB, YB = ROWS * SY::RB, STAGE = XB + YB;
+    constexpr int LPRX = SX::RB / 16, RPIX = 64 / LPRX, NIX = ROWS / RPIX / 4;   // X: lanes/row, rows/instr, instr/wave
+    constexpr int LPRY = SY::RB / 16, RPIY = 64 / LPRY, NIY = ROWS / RPIY / 4;
+    constexpr int LPS = NIX + NIY;
+    constexpr int KJ = BC / 32;
+    constexpr unsigned OOB = 0xfffffff0u;
+    static_assert(NIX == 2 && (NIY == 1 || NIY == 2), "tile geometry");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int kt = blockIdx.x % a.ktiles, ntile = blockIdx.x / a.ktiles;
+    const int k0 = kt * BC, n0 = ntile * BNW;
+    const int split = blockIdx.y;
+    const int step0 = split * a.steps_per_split;
+    int step1 = step0 + a.steps_per_split;
+    if (step1 > a.nsteps) step1 = a.nsteps;
+
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x), 0, x_bytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.dy), 0, dy_bytes, 0x00020000);
+
+    // ---- X pieces of this lane: instr i covers tile rows RPIX*(NIX*wave+i) .. +RPIX
+    int xr[NIX], py[NIX], px[NIX], pb[NIX], pm[NIX], ttr[NIX], tts[NIX], tch[NIX];
+    bool nval[NIX];
+    const int HW = a.Hd * a.Wd, HWs = a.Hs * a.Ws;
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+        xr[i] = RPIX * (NIX * wave + i) + lane / LPRX;
+        const int lc = SX::logical(lane % LPRX, xr[i]);
+        const int ncol = n0 + lc * PE;
+        nval[i] = ncol < a.K;
+        const int tap = ncol / a.Cs;
+        tch[i] = ncol - tap * a.Cs;
+        ttr[i] = tap / a.S; tts[i] = tap - ttr[i] * a.S;
+        const int m = step0 * ROWS + xr[i];
+        pm[i] = m;
+        const int n = m / HW, rem = m - n * HW;
+        py[i] = rem / a.Wd; px[i] = rem - py[i] * a.Wd; pb[i] = n * HWs;
+    }
+    int yr[NIY];
+    unsigned ycol[NIY];
+#pragma unroll
+    for (int i = 0; i < NIY; ++i) {
+        yr[i] = RPIY * (NIY * wave + i) + lane / LPRY;
+        const int lc = SY::logical(lane % LPRY, yr[i]);
+        const int kcol = k0 + lc * PE;
+        ycol[i] = kcol < a.Cd ? (unsigned)kcol * (unsigned)sizeof(T) : OOB;
+    }
+
+    auto issue = [&](int stage, int step) {
+        unsigned char* X = smem + stage * STAGE;
+        unsigned char* Y = X + XB;
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            const int ys = (py[i] << a.sshift) - a.pad + ttr[i], xs = (px[i] << a.sshift) - a.pad + tts[i];
+            const bool ok = nval[i] && pm[i] < a.M && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
+            const unsigned off = ok ? ((unsigned)(pb[i] + ys * a.Ws + xs) * (unsigned)a.Cs + (unsigned)tch[i]) * (unsigned)sizeof(T) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_w*)(X + (NIX * wave + i) * 1024), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NIY; ++i) {
+            const int m = step * ROWS + yr[i];
+            const unsigned off = (ycol[i] != OOB && m < a.M) ? (unsigned)m * (unsigned)a.Cd * (unsigned)sizeof(T) + ycol[i] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)(Y + (NIY * wave + i) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            pm[i] += ROWS;
+            px[i] += ROWS;
+            while (px[i] >= a.Wd) {
+                px[i] -= a.Wd;
+                if (++py[i] == a.Hd) { py[i] = 0; pb[i] += HWs; }
+            }
+        }
+    };
+
+    f32x4 acc[4][KJ];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int kj = 0; kj < KJ; ++kj) acc[ni][kj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, li = lane & 15;
+    const int nst = step1 - step0;
+    if (nst > 0) issue(0, step0);
+    if (nst > 1) { advance(); issue(1, step0 + 1); }
+    int stage = 0;
+    for (int t = 0; t < nst; ++t) {
+        if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nst) { advance(); issue(stage == 0 ? 2 : stage - 1, step0 + t + 2); }
+        const unsigned char* X = smem + stage * STAGE;
+        const unsigned char* Y = X + XB;
+        if constexpr (sizeof(T) == 2) {
+            const int q = li >> 2, p = li & 3;
+            s16x8 xf[4], yf[KJ];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int colb = (wn * 64 + ni * 16 + 4 * p) * 2;
+                const s16x4 lo = tr_read(X + SX::addr(4 * g + q, colb)), hi = tr_read(X + SX::addr(16 + 4 * g + q, colb));
+                xf[ni] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int kj = 0; kj < KJ; ++kj) {
+                const int colb = (wk * (BC / 2) + kj * 16 + 4 * p) * 2;
+                const s16x4 lo = tr_read(Y + SY::addr(4 * g + q, colb)), hi = tr_read(Y + SY::addr(16 + 4 * g + q, colb));
+                yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int kj = 0; kj < KJ; ++kj)
+                    acc[ni][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, xf[ni]), __builtin_bit_cast(bf16x8, yf[kj]), acc[ni][kj], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                float xf[4], yf[KJ];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    xf[ni] = *reinterpret_cast<const float*>(X + SX::addr(4 * qq + g, (wn * 64 + ni * 16 + li) * 4));
+#pragma unroll
+                for (int kj = 0; kj < KJ; ++kj)
+                    yf[kj] = *reinterpret_cast<const float*>(Y + SY::addr(4 * qq + g, (wk * (BC / 2) + kj * 16 + li) * 4));
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int kj = 0; kj < KJ; ++kj)
+                        acc[ni][kj] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[ni], yf[kj], acc[ni][kj], 0, 0, 0);
+            }
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+
+    float* out = a.out + (int64_t)split * a.slab;
+#pragma unroll
+    for (int kj = 0; kj < KJ; ++kj) {
+        const int k = k0 + wk * (BC / 2) + kj * 16 + li;
+        if (k >= a.Cd) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + g * 4;
+            if (n >= a.K) continue;
+            *reinterpret_cast<f32x4*>(out + (int64_t)k * a.ldw + n) = acc[ni][kj];
+        }
+    }
+}
+
 // dw[k][n] = sum_s slab[s][k][n] for n < K (pad columns untouched), fixed order
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int splits, int64_t slab, int Cd, int ldw,
                                                            int K, float* dw) {
@@ -218,7 +410,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int 
 }
 
 template <typename T>
-int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_req, hipStream_t st) {
+int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_req, int64_t x_bytes, int64_t dy_bytes,
+                 hipStream_t st) {
     constexpr int ROWS = WT<T>::ROWS;
     const int bc = a.Cd <= 64 ? 64 : 128;
     a.ktiles = (a.Cd + bc - 1) / bc;
@@ -227,7 +420,11 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     const int tiles = a.ktiles * a.ntiles;
     int splits = splits_req;
     if (splits <= 0) {
-        splits = (1024 + tiles - 1) / tiles;           // ~4 workgroups per CU
+        // one full co-resident round: 256 CUs x (3 | 4) workgroups (LDS 48 | 36 KB each), so every
+        // workgroup gets the same number of steps and there is no tail round
+        const int slots = 256 * (bc == 64 ? 4 : 3);
+        splits = slots / tiles;
+        if (splits < 1) splits = 1;
         const int max_by_work = a.nsteps / 8 > 0 ? a.nsteps / 8 : 1;
         if (splits > max_by_work) splits = max_by_work;
     }
@@ -243,8 +440,16 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     a.slab = splits > 1 ? slab : 0;
     a.out = splits > 1 ? ws : dw;
     const dim3 grid(tiles, splits);
-    if (bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, st, a);
+    static const bool force_v1 = getenv("IIF_CONV_REGSTAGE") != nullptr;
+    const bool dma = !force_v1 && x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL;
+    if (dma) {
+        const unsigned xb = (unsigned)x_bytes, yb = (unsigned)dy_bytes;
+        if (bc == 64) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64>), grid, dim3(256), 0, st, a, xb, yb);
+        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128>), grid, dim3(256), 0, st, a, xb, yb);
+    } else {
+        if (bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, st, a);
+    }
     IIF_LAUNCH_CHECK();
     if (splits > 1) {
         const int64_t total4 = slab / 4;
@@ -279,7 +484,9 @@ extern "C" int iif_conv_wgrad(const iif_conv_desc* d, const void* x, const void*
     a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.ldw = d->ldw; a.M = (int)M;
     a.K = d->r * d->s * d->cs;
     hipStream_t st = as_stream(stream);
+    const int64_t esz = d->dtype == IIF_F32 ? 4 : 2;
+    const int64_t x_bytes = (int64_t)d->n * d->hs * d->ws * d->cs * esz, dy_bytes = M * d->cd * esz;
     if (d->dtype == IIF_BF16)
-        return launch_wgrad<unsigned short>(a, dw, (float*)workspace, workspace_bytes, splits, st);
-    return launch_wgrad<float>(a, dw, (float*)workspace, workspace_bytes, splits, st);
+        return launch_wgrad<unsigned short>(a, dw, (float*)workspace, workspace_bytes, splits, x_bytes, dy_bytes, st);
+    return launch_wgrad<float>(a, dw, (float*)workspace, workspace_bytes, splits, x_bytes, dy_bytes, st);
 }
