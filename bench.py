@@ -57,7 +57,7 @@ class ConvTimer(object):
 
     def wrap(self, ops):
         timer = self
-        orig = {k: getattr(ops, k) for k in ("conv_forward", "conv_dgrad", "conv_wgrad")}
+        orig = {k: getattr(ops, k) for k in ("conv_forward", "conv_dgrad", "conv_wgrad", "conv_forward_bnstats")}
 
         def flops_fwd(x, w, r, s, stride, pad, **kw):
             n, h, wd, cin = x.shape
@@ -77,7 +77,11 @@ class ConvTimer(object):
             fl = 2.0 * n * ho * wo * cout * r * s * x.shape[3]
             return timer._timed("wgrad", fl, orig["conv_wgrad"], x, dy, r, s, stride, pad, **kw)
 
+        def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial):
+            return timer._timed("fwd", flops_fwd(x, w, r, s, stride, pad), orig["conv_forward_bnstats"], x, w, r, s, stride, pad, out, partial)
+
         ops.conv_forward, ops.conv_dgrad, ops.conv_wgrad = conv_forward, conv_dgrad, conv_wgrad
+        ops.conv_forward_bnstats = conv_forward_bnstats
         self._orig, self._ops = orig, ops
 
     def unwrap(self):

@@ -103,31 +103,34 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* x, Geo g, float*
     }
 }
 
-// Column sums of the [nblk][2][C] partials: a 256-thread block owns 32 channels, 8 lanes per channel
-// walk the partial rows (stride 8) in double and are combined in fixed order through LDS.
-__device__ __forceinline__ void reduce_partials(const float* partial, int nblk, int C, int c, int lane8,
-                                                double (&sh)[2][8][32], int cl, double& s, double& q) {
+// Column sums of the [nblk][2][C] partials: a 256-thread block owns CB channels with LN = 256/CB lanes
+// each; a lane walks the partial rows with stride LN in double, lanes are combined in fixed order via LDS.
+template <int CB>
+__device__ __forceinline__ void reduce_partials(const float* partial, int nblk, int C, int c, int ln,
+                                                double* sh /* [2][256] */, int cl, double& s, double& q) {
+    constexpr int LN = 256 / CB;
     double a = 0.0, b = 0.0;
     if (c < C)
-        for (int r = lane8; r < nblk; r += 8) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
-    sh[0][lane8][cl] = a; sh[1][lane8][cl] = b;
+        for (int r = ln; r < nblk; r += LN) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
+    sh[ln * CB + cl] = a; sh[256 + ln * CB + cl] = b;
     __syncthreads();
     s = 0.0; q = 0.0;
-    if (lane8 == 0)
-        for (int j = 0; j < 8; ++j) { s += sh[0][j][cl]; q += sh[1][j][cl]; }
+    if (ln == 0)
+        for (int j = 0; j < LN; ++j) { s += sh[j * CB + cl]; q += sh[256 + j * CB + cl]; }
 }
 
 // stats layout: [4][C] = mean, invstd, a (=gamma*invstd), b (=beta-mean*a)
+template <int CB>
 __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partial, int nblk, int C, double count,
                                                           const float* gamma, const float* beta, float eps,
                                                           float momentum, float* running_mean, float* running_var,
                                                           float* stats) {
-    __shared__ double sh[2][8][32];
-    const int cl = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double sh[512];
+    const int cl = threadIdx.x % CB, ln = threadIdx.x / CB;
+    const int c = blockIdx.x * CB + cl;
     double s, q;
-    reduce_partials(partial, nblk, C, c, lane8, sh, cl, s, q);
-    if (lane8 != 0 || c >= C) return;
+    reduce_partials<CB>(partial, nblk, C, c, ln, sh, cl, s, q);
+    if (ln != 0 || c >= C) return;
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -209,15 +212,16 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* g_, const T
 }
 
 // coef layout [3][C]: k1 = gamma*invstd, k2 = mean(dy), k3 = mean(dy*xhat)*invstd
+template <int CB>
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* partial, int nblk, int C, double count,
                                                               const float* gamma, const float* stats, float* dgamma,
                                                               float* dbeta, float* coef) {
-    __shared__ double sh[2][8][32];
-    const int cl = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double sh[512];
+    const int cl = threadIdx.x % CB, ln = threadIdx.x / CB;
+    const int c = blockIdx.x * CB + cl;
     double s1, s2;
-    reduce_partials(partial, nblk, C, c, lane8, sh, cl, s1, s2);
-    if (lane8 != 0 || c >= C) return;
+    reduce_partials<CB>(partial, nblk, C, c, ln, sh, cl, s1, s2);
+    if (ln != 0 || c >= C) return;
     dgamma[c] = (float)s2;
     dbeta[c] = (float)s1;
     const float invstd = stats[C + c];
@@ -248,6 +252,20 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T*
     }
 }
 
+// channels per finalize block: few channels x many lanes when there are many partial rows
+inline int finalize_cb(int nblk) { return nblk > 2048 ? 4 : (nblk > 256 ? 8 : 32); }
+
+inline int launch_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
+                              float eps, float momentum, float* rm, float* rv, float* stats, hipStream_t st) {
+    const int cb = finalize_cb(nblk);
+    const dim3 grid((C + cb - 1) / cb), blk(256);
+    if (cb == 4) hipLaunchKernelGGL(bn_finalize_kernel<4>, grid, blk, 0, st, partial, nblk, C, count, gamma, beta, eps, momentum, rm, rv, stats);
+    else if (cb == 8) hipLaunchKernelGGL(bn_finalize_kernel<8>, grid, blk, 0, st, partial, nblk, C, count, gamma, beta, eps, momentum, rm, rv, stats);
+    else hipLaunchKernelGGL(bn_finalize_kernel<32>, grid, blk, 0, st, partial, nblk, C, count, gamma, beta, eps, momentum, rm, rv, stats);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
 inline int stream_blocks(int64_t total_vec) {
     const int64_t b = (total_vec + 255) / 256;
     return (int)(b < 4096 ? b : 4096);
@@ -261,10 +279,7 @@ int bn_forward_t(const T* x, int64_t M, int C, const float* gamma, const float* 
     if ((int64_t)g.nblk * 2 * C * 4 > ws_bytes) return IIF_EINVAL;
     hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(g.nblk, g.colblocks), dim3(256), 0, st, x, g, ws);
     IIF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, ws, g.nblk, C, (double)M, gamma,
-                       beta, eps, momentum, rm, rv, stats);
-    IIF_LAUNCH_CHECK();
-    return IIF_OK;
+    return launch_bn_finalize(ws, g.nblk, C, (double)M, gamma, beta, eps, momentum, rm, rv, stats, st);
 }
 
 template <typename T>
@@ -295,8 +310,13 @@ int bn_backward_t(const T* gy, const T* ymask, const T* x, const float* stats, c
     if (ymask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), rgrid, blk, 0, st, gy, ymask, x, stats, g, ws);
     else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), rgrid, blk, 0, st, gy, ymask, x, stats, g, ws);
     IIF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), blk, 0, st, ws, g.nblk, C, (double)M, gamma, stats,
-                       dgamma, dbeta, coef);
+    {
+        const int cb = finalize_cb(g.nblk);
+        const dim3 fgrid((C + cb - 1) / cb);
+        if (cb == 4) hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, fgrid, blk, 0, st, ws, g.nblk, C, (double)M, gamma, stats, dgamma, dbeta, coef);
+        else if (cb == 8) hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, fgrid, blk, 0, st, ws, g.nblk, C, (double)M, gamma, stats, dgamma, dbeta, coef);
+        else hipLaunchKernelGGL(bn_bwd_finalize_kernel<32>, fgrid, blk, 0, st, ws, g.nblk, C, (double)M, gamma, stats, dgamma, dbeta, coef);
+    }
     IIF_LAUNCH_CHECK();
     const int cv = C / V;
     const int64_t tv = M * cv;
@@ -333,6 +353,13 @@ int iif_bn_forward_stats(const void* x, int dtype, int64_t m, int c, const float
                                             running_var, stats, (float*)workspace, workspace_bytes, as_stream(stream));
     }
     return IIF_EINVAL;
+}
+
+int iif_bn_finalize_stats(const float* partial, int n_partials, int64_t m, int c, const float* gamma, const float* beta,
+                          float eps, float momentum, float* running_mean, float* running_var, float* stats, void* stream) {
+    if (!partial || !gamma || !beta || !stats || n_partials <= 0 || m <= 0 || c <= 0) return IIF_EINVAL;
+    return launch_bn_finalize(partial, n_partials, c, (double)m, gamma, beta, eps, momentum, running_mean, running_var,
+                              stats, as_stream(stream));
 }
 
 int iif_bn_apply(const void* x, int dtype, int64_t m, int c, const float* stats, const void* residual,

@@ -38,6 +38,7 @@ template <> struct ET<float> { static constexpr int PE = 4, KE = 16; };
 struct ConvArgs {
     const unsigned char* src; const unsigned char* wgt; unsigned char* dst; const unsigned char* res;
     const float* bias;
+    float* bn_partial;     // nullable: [mtiles][2][Cd] per-tile (sum, sum of squares) of the stored output
     int N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, sshift, pad, transposed, ldw, M, K, mtiles, ntiles;
 };
 
@@ -242,6 +243,69 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
 //   * out-of-image taps, rows >= M, channels >= Cd and the ragged K tail are addressed out of the
 //     buffer range: the hardware range check returns zeros, no predicated loads.
 // Same tile shape, fragment maps and epilogue as the register-staged kernel above.
+// LDS-staged epilogue for bf16 outputs: the wave tiles are parked in LDS as [pixel][channel] rows and
+// written back with 16 B per lane, i.e. whole 128-B lines (the direct form writes 8 B per lane in 32-B
+// runs).  The residual is read the same way.  With bn_partial the per-channel (sum, sum of squares) of the
+// bf16-rounded tile are emitted too, so batch-norm statistics need no extra pass over the activation.
+template <int BN>
+__device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&acc)[BN / 32][4], unsigned char* smem,
+                                                     int m0, int n0, int mt, int wm, int wn, int fr, int fc) {
+    constexpr int CI = BN / 32;
+    constexpr int PITCH = BN * 2 + 16;
+    constexpr int CPR = BN / 8;                 // 16-byte chunks per row
+    constexpr int RPP = 256 / CPR;              // rows per pass
+    const int tid = threadIdx.x;
+    __syncthreads();                            // every wave is done reading the last stage
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj)
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+            const int row = wm * 64 + pj * 16 + fr, ch = wn * (BN / 2) + ci * 16 + fc * 4;
+            u32x2 w;
+            w.x = pack_bf16x2(acc[ci][pj].x, acc[ci][pj].y);
+            w.y = pack_bf16x2(acc[ci][pj].z, acc[ci][pj].w);
+            *reinterpret_cast<u32x2*>(smem + row * PITCH + ch * 2) = w;
+        }
+    __syncthreads();
+    const int chunk = tid % CPR, r0 = tid / CPR;
+    const int n = n0 + chunk * 8;
+    if (n < a.Cd) {
+#pragma unroll 4
+        for (int row = r0; row < 128; row += RPP) {
+            const int m = m0 + row;
+            if (m >= a.M) break;
+            u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PITCH + chunk * 16);
+            const int64_t o = ((int64_t)m * a.Cd + n) * 2;
+            if (a.res) {
+                const u32x4 rr = *reinterpret_cast<const u32x4*>(a.res + o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = bf16_bits_to_f32(v[q] & 0xffffu) + bf16_bits_to_f32(rr[q] & 0xffffu);
+                    const float hi = __uint_as_float(v[q] & 0xffff0000u) + __uint_as_float(rr[q] & 0xffff0000u);
+                    v[q] = pack_bf16x2(lo, hi);
+                }
+            }
+            *reinterpret_cast<u32x4*>(a.dst + o) = v;
+        }
+    }
+    if (a.bn_partial) {
+        // all 256 threads: channel tid % BN, row group tid / BN (256/BN groups of 128*BN/256 rows); every
+        // group is its own partial row, so no further synchronisation is needed
+        constexpr int GROUPS = 256 / BN, RPG = 128 / GROUPS;
+        const int ch = tid % BN, grp = tid / BN;
+        if (n0 + ch < a.Cd) {
+            float s = 0.f, q = 0.f;
+#pragma unroll 8
+            for (int row = grp * RPG; row < (grp + 1) * RPG; ++row) {
+                const float x = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(smem + row * PITCH + ch * 2));
+                s += x; q = fmaf(x, x, q);
+            }
+            float* p = a.bn_partial + ((int64_t)mt * GROUPS + grp) * 2 * a.Cd + n0 + ch;
+            p[0] = s; p[a.Cd] = q;
+        }
+    }
+}
+
 typedef __attribute__((address_space(3))) void lds_void;
 
 template <typename T, int BN, bool OUTF32>
@@ -374,6 +438,12 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs a, unsigne
             }
         stage = stage == 2 ? 0 : stage + 1;
     }
+    if constexpr (sizeof(T) == 2 && !OUTF32) {
+        if ((a.Cd & 7) == 0 && a.bias == nullptr) {     // wave-uniform
+            conv_epilogue_staged<BN>(a, acc, smem, m0, n0, mt, wm, wn, fr, fc);
+            return;
+        }
+    }
     conv_epilogue<T, BN, OUTF32>(a, acc, m0, n0, wm, wn, fr, fc);
 }
 
@@ -404,8 +474,18 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
 
 }  // namespace
 
+extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
+                                      const void* res, const float* bias, float* bn_partial, int64_t bn_partial_floats,
+                                      int32_t* n_partials, void* stream);
+
 extern "C" int iif_conv_igemm(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                               const float* bias, void* stream) {
+    return iif_conv_igemm_bnstats(d, src, wgt, dst, res, bias, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
+                                      const void* res, const float* bias, float* bn_partial, int64_t bn_partial_floats,
+                                      int32_t* n_partials, void* stream) {
     if (!d || !src || !wgt || !dst) return IIF_EINVAL;
     if (d->n <= 0 || d->hs <= 0 || d->ws <= 0 || d->cs <= 0 || d->hd <= 0 || d->wd <= 0 || d->cd <= 0 ||
         d->r <= 0 || d->s <= 0 || d->pad < 0)
@@ -423,6 +503,21 @@ extern "C" int iif_conv_igemm(const iif_conv_desc* d, const void* src, const voi
     ConvArgs a{};
     a.src = (const unsigned char*)src; a.wgt = (const unsigned char*)wgt; a.dst = (unsigned char*)dst;
     a.res = (const unsigned char*)res; a.bias = bias;
+    a.bn_partial = nullptr;
+    if (n_partials) *n_partials = 0;
+    if (bn_partial) {
+        // fused statistics need the LDS-staged bf16 epilogue of the pipelined kernel
+        const int64_t mt = (M + 127) / 128;
+        const int64_t esz0 = 2;
+        const int64_t groups = d->cd <= 64 ? 4 : 2;       // partial rows per pixel tile (256 / BN)
+        const bool ok = d->dtype == IIF_BF16 && d->dst_dtype == IIF_BF16 && (d->cd % 8) == 0 && !bias && !res &&
+                        getenv("IIF_CONV_REGSTAGE") == nullptr &&
+                        (int64_t)d->n * d->hs * d->ws * d->cs * esz0 < 0x7ffffff0LL &&
+                        bn_partial_floats >= mt * groups * 2 * d->cd;
+        if (!ok) return IIF_EUNSUPPORTED;
+        a.bn_partial = bn_partial;
+        if (n_partials) *n_partials = (int32_t)(mt * groups);
+    }
     a.N = d->n; a.Hs = d->hs; a.Ws = d->ws; a.Cs = d->cs; a.Hd = d->hd; a.Wd = d->wd; a.Cd = d->cd;
     a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.transposed = d->transposed ? 1 : 0;
     a.ldw = d->ldw; a.M = (int)M; a.K = d->r * d->s * d->cs;

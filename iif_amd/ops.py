@@ -31,6 +31,25 @@ def conv_forward(x, w, r, s, stride, pad, out=None, out_dtype=None, bias=None, r
     return out
 
 
+def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial):
+    """conv_forward (bf16) that also writes per-tile BN partial sums; returns the tile count."""
+    n, h, wd_, cin = x.shape
+    cout, ldw = w.shape
+    ho, wo = conv_out_hw(h, wd_, r, s, stride, pad)
+    d = _desc(n, h, wd_, cin, ho, wo, cout, r, s, stride, pad, 0, ldw, dtype_code(x), dtype_code(out))
+    nt = ctypes.c_int32(0)
+    check(lib().iif_conv_igemm_bnstats(ctypes.byref(d), ptr(x), ptr(w), ptr(out), 0, 0, ptr(partial), partial.numel(),
+                                       ctypes.byref(nt), stream_ptr()), "iif_conv_igemm_bnstats")
+    return nt.value
+
+
+def bn_finalize_stats(partial, n_partials, m, c, gamma, beta, running_mean, running_var, stats, eps=1e-5, momentum=0.1):
+    check(lib().iif_bn_finalize_stats(ptr(partial), n_partials, m, c, ptr(gamma), ptr(beta), eps, momentum,
+                                      ptr(running_mean), ptr(running_var), ptr(stats), stream_ptr()),
+          "iif_bn_finalize_stats")
+    return stats
+
+
 def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, out=None, res=None):
     """dy: [N,Ho,Wo,Cout]; wt: [Cin, ldw] rows of r*s*Cout (the CRSK transpose);
     returns dx [N,H,W,Cin] (+ res)."""

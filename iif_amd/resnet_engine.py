@@ -450,6 +450,8 @@ class _Plan(object):
         cmax = max(u.conv.cout for u in self.units)
         mmax = max(u.n * u.ho * u.wo for u in self.units)
         self.bn_ws = ops.bn_workspace(mmax, cmax, dev)
+        self.bn_partial = torch.empty(max(((u.n * u.ho * u.wo + 127) // 128) * 8 * u.conv.cout for u in self.units),
+                                      dtype=torch.float32, device=dev)
         wmax = max(max(u.conv.cout * u.conv.ldw for u in self.units), head.out_padded * head.in_features)
         self.wg_ws = torch.empty(min(16 * wmax * 4, 512 << 20), dtype=torch.uint8, device=dev)
         self._grad_pool = {}
@@ -489,12 +491,16 @@ class _Plan(object):
     # ---------------------------------------------------------------- forward
     def _conv_bn(self, u, training):
         cv = u.conv
-        if u.is_patch_gemm:
-            ops.conv_forward(u.src, u.w, 1, 1, 1, 0, out=u.x)
-        else:
-            ops.conv_forward(u.src, u.w, cv.k, cv.k, cv.stride, cv.pad, out=u.x)
+        k, st, pd = (1, 1, 0) if u.is_patch_gemm else (cv.k, cv.stride, cv.pad)
         m = u.n * u.ho * u.wo
         x2 = u.x.view(m, cv.cout)
+        if training and self.dt == torch.bfloat16 and cv.cout % 8 == 0:
+            # statistics come out of the convolution's epilogue: no extra pass over x
+            nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, self.bn_partial)
+            ops.bn_finalize_stats(self.bn_partial, nt, m, cv.cout, u.bn.weight, u.bn.bias, u.bn.running_mean,
+                                  u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM)
+            return x2
+        ops.conv_forward(u.src, u.w, k, k, st, pd, out=u.x)
         if training:
             ops.bn_forward_stats(x2, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var, u.stats, self.bn_ws,
                                  BN_EPS, BN_MOMENTUM)

@@ -133,3 +133,36 @@ def test_wgrad_is_deterministic():
     a = ops.conv_wgrad(x, dy, 3, 3, 1, 1, workspace=ws)
     b = ops.conv_wgrad(x, dy, 3, 3, 1, 1, workspace=ws)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 14, 14, 64, 3, 1, 1), (3, 128, 9, 9, 256, 1, 1, 0), (2, 64, 15, 13, 128, 3, 2, 1),
+                                  (1, 32, 7, 7, 1000, 1, 1, 0), (5, 8, 6, 6, 24, 3, 1, 1)])
+def test_conv_fused_bn_statistics(case):
+    """The epilogue's per-tile (sum, sumsq) + iif_bn_finalize_stats == the standalone statistics pass
+    over the stored bf16 output; the staged (coalesced) epilogue stores the same values as the oracle conv."""
+    from iif_amd import ops
+    n, cin, h, w, cout, r, stride, pad = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, cin, h, w, generator=g).to(dt)
+    wt = (torch.randn(cout, cin, r, r, generator=g) / (cin * r * r) ** 0.5).to(dt)
+    xd, wd = nhwc(x.float()).to(dt).to(DEV), krsc(wt.float(), 8).to(dt).to(DEV)
+    ho, wo = ops.conv_out_hw(h, w, r, r, stride, pad)
+    m = n * ho * wo
+    out = torch.empty(n, ho, wo, cout, dtype=dt, device=DEV)
+    partial = torch.full((((m + 127) // 128) * 8 * cout,), float("nan"), device=DEV)
+    nt = ops.conv_forward_bnstats(xd, wd, r, r, stride, pad, out, partial)
+    assert nt == ((m + 127) // 128) * (4 if cout <= 64 else 2)
+    ref = F.conv2d(x.float(), wt.float(), None, stride, pad)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    plain = ops.conv_forward(xd, wd, r, r, stride, pad)
+    assert torch.equal(plain, out)
+    gamma, beta = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV)
+    s_fused, s_ref = torch.empty(4, cout, device=DEV), torch.empty(4, cout, device=DEV)
+    rm1, rv1 = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    rm2, rv2 = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    ops.bn_finalize_stats(partial, nt, m, cout, gamma, beta, rm1, rv1, s_fused)
+    ops.bn_forward_stats(out.view(m, cout), gamma, beta, rm2, rv2, s_ref, ops.bn_workspace(m, cout, DEV))
+    for a_, b_ in ((s_fused, s_ref), (rm1, rm2), (rv1, rv2)):
+        assert (a_ - b_).abs().max().item() <= 1e-5 * max(1.0, b_.abs().max().item())
