@@ -252,6 +252,28 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T*
     }
 }
 
+// Stage 1 for many partial rows: slice `blockIdx.y` of the rows is summed (double, fixed order) by 32 channels
+// x 8 lanes per block into out[slice][2][C]; the finalize kernels then see only `slices` rows.
+__global__ void __launch_bounds__(256) bn_partial_reduce_kernel(const float* partial, int nblk, int C, int rows_per_slice,
+                                                                float* out) {
+    __shared__ double sh[512];
+    const int cl = threadIdx.x & 31, ln = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int r0 = blockIdx.y * rows_per_slice;
+    int r1 = r0 + rows_per_slice; if (r1 > nblk) r1 = nblk;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int r = r0 + ln; r < r1; r += 8) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
+    sh[ln * 32 + cl] = a; sh[256 + ln * 32 + cl] = b;
+    __syncthreads();
+    if (ln == 0 && c < C) {
+        double s = 0.0, q = 0.0;
+        for (int j = 0; j < 8; ++j) { s += sh[j * 32 + cl]; q += sh[256 + j * 32 + cl]; }
+        out[(int64_t)blockIdx.y * 2 * C + c] = (float)s;
+        out[(int64_t)blockIdx.y * 2 * C + C + c] = (float)q;
+    }
+}
+
 // channels per finalize block: few channels x many lanes when there are many partial rows
 inline int finalize_cb(int nblk) { return nblk > 2048 ? 4 : (nblk > 256 ? 8 : 32); }
 
@@ -356,10 +378,20 @@ int iif_bn_forward_stats(const void* x, int dtype, int64_t m, int c, const float
 }
 
 int iif_bn_finalize_stats(const float* partial, int n_partials, int64_t m, int c, const float* gamma, const float* beta,
-                          float eps, float momentum, float* running_mean, float* running_var, float* stats, void* stream) {
+                          float eps, float momentum, float* running_mean, float* running_var, float* stats,
+                          float* scratch, int64_t scratch_floats, void* stream) {
     if (!partial || !gamma || !beta || !stats || n_partials <= 0 || m <= 0 || c <= 0) return IIF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (n_partials > 512 && scratch && scratch_floats >= (int64_t)64 * 2 * c) {
+        const int slices = 64, rps = (n_partials + slices - 1) / slices;
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((c + 31) / 32, slices), dim3(256), 0, st, partial, n_partials, c,
+                           rps, scratch);
+        IIF_LAUNCH_CHECK();
+        return launch_bn_finalize(scratch, slices, c, (double)m, gamma, beta, eps, momentum, running_mean, running_var,
+                                  stats, st);
+    }
     return launch_bn_finalize(partial, n_partials, c, (double)m, gamma, beta, eps, momentum, running_mean, running_var,
-                              stats, as_stream(stream));
+                              stats, st);
 }
 
 int iif_bn_apply(const void* x, int dtype, int64_t m, int c, const float* stats, const void* residual,

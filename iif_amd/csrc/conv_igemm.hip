@@ -289,19 +289,25 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
         }
     }
     if (a.bn_partial) {
-        // all 256 threads: channel tid % BN, row group tid / BN (256/BN groups of 128*BN/256 rows); every
-        // group is its own partial row, so no further synchronisation is needed
+        // all 256 threads: channel tid % BN, row group tid / BN; groups are combined in fixed order through
+        // LDS scratch behind the tile, so each pixel tile contributes ONE partial row
         constexpr int GROUPS = 256 / BN, RPG = 128 / GROUPS;
+        float* scratch = reinterpret_cast<float*>(smem + 128 * PITCH);
         const int ch = tid % BN, grp = tid / BN;
-        if (n0 + ch < a.Cd) {
-            float s = 0.f, q = 0.f;
+        float sm = 0.f, q = 0.f;
 #pragma unroll 8
-            for (int row = grp * RPG; row < (grp + 1) * RPG; ++row) {
-                const float x = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(smem + row * PITCH + ch * 2));
-                s += x; q = fmaf(x, x, q);
-            }
-            float* p = a.bn_partial + ((int64_t)mt * GROUPS + grp) * 2 * a.Cd + n0 + ch;
-            p[0] = s; p[a.Cd] = q;
+        for (int row = grp * RPG; row < (grp + 1) * RPG; ++row) {
+            const float x = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(smem + row * PITCH + ch * 2));
+            sm += x; q = fmaf(x, x, q);
+        }
+        scratch[tid] = sm; scratch[256 + tid] = q;
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Cd) {
+            float s2 = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < GROUPS; ++gi) { s2 += scratch[gi * BN + tid]; q2 += scratch[256 + gi * BN + tid]; }
+            float* p = a.bn_partial + (int64_t)mt * 2 * a.Cd + n0 + tid;
+            p[0] = s2; p[a.Cd] = q2;
         }
     }
 }
@@ -509,7 +515,7 @@ extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, c
         // fused statistics need the LDS-staged bf16 epilogue of the pipelined kernel
         const int64_t mt = (M + 127) / 128;
         const int64_t esz0 = 2;
-        const int64_t groups = d->cd <= 64 ? 4 : 2;       // partial rows per pixel tile (256 / BN)
+        const int64_t groups = 1;                         // one partial row per 128-pixel tile
         const bool ok = d->dtype == IIF_BF16 && d->dst_dtype == IIF_BF16 && (d->cd % 8) == 0 && !bias && !res &&
                         getenv("IIF_CONV_REGSTAGE") == nullptr &&
                         (int64_t)d->n * d->hs * d->ws * d->cs * esz0 < 0x7ffffff0LL &&

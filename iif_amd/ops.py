@@ -43,9 +43,11 @@ def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial):
     return nt.value
 
 
-def bn_finalize_stats(partial, n_partials, m, c, gamma, beta, running_mean, running_var, stats, eps=1e-5, momentum=0.1):
+def bn_finalize_stats(partial, n_partials, m, c, gamma, beta, running_mean, running_var, stats, eps=1e-5, momentum=0.1,
+                      scratch=None):
     check(lib().iif_bn_finalize_stats(ptr(partial), n_partials, m, c, ptr(gamma), ptr(beta), eps, momentum,
-                                      ptr(running_mean), ptr(running_var), ptr(stats), stream_ptr()),
+                                      ptr(running_mean), ptr(running_var), ptr(stats), ptr(scratch),
+                                      0 if scratch is None else scratch.numel(), stream_ptr()),
           "iif_bn_finalize_stats")
     return stats
 

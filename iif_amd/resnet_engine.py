@@ -450,8 +450,9 @@ class _Plan(object):
         cmax = max(u.conv.cout for u in self.units)
         mmax = max(u.n * u.ho * u.wo for u in self.units)
         self.bn_ws = ops.bn_workspace(mmax, cmax, dev)
-        self.bn_partial = torch.empty(max(((u.n * u.ho * u.wo + 127) // 128) * 8 * u.conv.cout for u in self.units),
+        self.bn_partial = torch.empty(max(((u.n * u.ho * u.wo + 127) // 128) * 2 * u.conv.cout for u in self.units),
                                       dtype=torch.float32, device=dev)
+        self.bn_scratch = torch.empty(128 * cmax, dtype=torch.float32, device=dev)
         wmax = max(max(u.conv.cout * u.conv.ldw for u in self.units), head.out_padded * head.in_features)
         self.wg_ws = torch.empty(min(16 * wmax * 4, 512 << 20), dtype=torch.uint8, device=dev)
         self._grad_pool = {}
@@ -498,7 +499,7 @@ class _Plan(object):
             # statistics come out of the convolution's epilogue: no extra pass over x
             nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, self.bn_partial)
             ops.bn_finalize_stats(self.bn_partial, nt, m, cv.cout, u.bn.weight, u.bn.bias, u.bn.running_mean,
-                                  u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM)
+                                  u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM, scratch=self.bn_scratch)
             return x2
         ops.conv_forward(u.src, u.w, k, k, st, pd, out=u.x)
         if training:

@@ -140,10 +140,10 @@ int iif_conv_igemm(const iif_conv_desc* d, const void* src, const void* wgt, voi
 
 /* iif_conv_igemm that also emits batch-norm statistics of its (bf16) output from the
  * epilogue: bn_partial[t][0][k] / [t][1][k] = sum / sum of squares of the stored output
- * over pixel group t (32 or 64 consecutive pixels) for channel k; *n_partials (host int,
- * nullable) receives the group count.  Feed them to iif_bn_finalize_stats: no separate
+ * over pixel tile t (128 consecutive pixels) for channel k; *n_partials (host int,
+ * nullable) receives the tile count.  Feed them to iif_bn_finalize_stats: no separate
  * pass over the activation.  bf16 in/out, cd % 8 == 0, no bias/res; otherwise
- * IIF_EUNSUPPORTED.  bn_partial must hold >= ceil(m/128)*4*2*cd floats. */
+ * IIF_EUNSUPPORTED.  bn_partial must hold >= ceil(m/128)*2*cd floats. */
 int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
                            const void* res, const float* bias, float* bn_partial,
                            int64_t bn_partial_floats, int32_t* n_partials, void* stream);
@@ -185,10 +185,13 @@ int iif_bn_forward_stats(const void* x, int dtype, int64_t m, int c, const float
 int iif_bn_apply(const void* x, int dtype, int64_t m, int c, const float* stats,
                  const void* residual, const float* residual_stats, int relu, void* y, void* stream);
 /* second half of iif_bn_forward_stats on externally produced partial sums
- * (partial[t][0][k] = sum, [t][1][k] = sum of squares; fixed-order fp64 reduction) */
+ * (partial[t][0][k] = sum, [t][1][k] = sum of squares; fixed-order fp64 reduction).
+ * scratch (nullable, >= 128*c floats) lets > 512 partial rows be reduced in two
+ * parallel stages instead of one serial walk. */
 int iif_bn_finalize_stats(const float* partial, int n_partials, int64_t m, int c, const float* gamma,
                           const float* beta, float eps, float momentum, float* running_mean,
-                          float* running_var, float* stats, void* stream);
+                          float* running_var, float* stats, float* scratch, int64_t scratch_floats,
+                          void* stream);
 int iif_bn_backward(const void* gy, const void* y_mask, const void* x, int dtype, int64_t m, int c,
                     const float* stats, const float* gamma, float* dgamma, float* dbeta, void* dx,
                     void* gmasked, void* workspace, int64_t workspace_bytes, void* stream);
