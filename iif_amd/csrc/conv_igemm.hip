@@ -314,15 +314,19 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <typename T, int BN, bool OUTF32>
-__global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+// UTAP (Cs % KE == 0, <= 32 taps, not a stride-2 data gradient): every lane of a K step is in the same tap,
+// so the tap / channel-chunk displacement is a wave-uniform SCALAR (the buffer instruction's soffset) and
+// the per-lane voffset (pixel base + this lane's chunk) never changes: address generation costs ~3 VALU
+// instructions per row per step (a tap-validity bit test), instead of the general per-piece arithmetic.
+template <typename T, int BN, bool OUTF32, bool UTAP>
+__device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int BM = 128;
     constexpr int PE = ET<T>::PE, KE = ET<T>::KE;
     constexpr int NBI = BN / 64;        // weight DMA pieces per wave per stage
     constexpr int CI = BN / 32;
     constexpr int STAGE = (BM + BN) * 64;
     constexpr int LPS = 2 + NBI;        // DMA instructions per wave per stage
-    constexpr unsigned OOB = 0xfffffff0u;
+    constexpr unsigned OOB = UTAP ? 0x80000000u : 0xfffffff0u;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -334,67 +338,128 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs a, unsigne
     if (mt >= a.mtiles) return;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src), 0, src_bytes, 0x00020000);
-    const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wgt), 0, wgt_bytes, 0x00020000);
-
     // ---- this lane's fixed role inside every 16-row DMA piece: row l>>2, source chunk (l&3)^f(l>>4)
     const int prow = lane >> 2;
     const int chunk = (lane & 3) ^ swz(prow);
+    const int HW = a.Hd * a.Wd;
+    // fast-path state
+    unsigned vbase[2], vmask[2], vwf[NBI];
+    int dsign = a.transposed ? -1 : 1;                        // tap displacement sign
+    int shiftP = 0;                                           // bytes subtracted from the base so soffset >= 0
+    // general-path state
     int by[2], bx[2], ib[2];
     bool mv[2];
-    const int HW = a.Hd * a.Wd;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + 16 * (2 * wave + i) + prow;
-        mv[i] = m < a.M;
-        const int mm = mv[i] ? m : 0;
-        const int n = mm / HW, rem = mm - n * HW;
-        const int y = rem / a.Wd, x = rem - y * a.Wd;
-        by[i] = a.transposed ? y + a.pad : (y << a.sshift) - a.pad;
-        bx[i] = a.transposed ? x + a.pad : (x << a.sshift) - a.pad;
-        ib[i] = n * a.Hs * a.Ws;
-    }
     unsigned wrow[NBI];
+    int e = chunk * PE, c = 0, r = 0, s = 0;
+    if constexpr (UTAP) {
+        // most negative tap displacement, in pixels
+        const int dmin = a.transposed ? ((a.pad - a.R + 1) * a.Ws + (a.pad - a.S + 1)) : (-a.pad * a.Ws - a.pad);
+        shiftP = dmin < 0 ? -dmin * a.Cs * (int)sizeof(T) : 0;
 #pragma unroll
-    for (int i = 0; i < NBI; ++i) {
-        const int n = n0 + 16 * (NBI * wave + i) + prow;
-        wrow[i] = n < a.Cd ? (unsigned)n * (unsigned)a.ldw * (unsigned)sizeof(T) : OOB;
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + 16 * (2 * wave + i) + prow;
+            const bool valid = m < a.M;
+            const int mm = valid ? m : 0;
+            const int n = mm / HW, rem = mm - n * HW;
+            const int y = rem / a.Wd, x = rem - y * a.Wd;
+            const int y0 = a.transposed ? y : (y << a.sshift), x0 = a.transposed ? x : (x << a.sshift);
+            vbase[i] = ((unsigned)(n * a.Hs * a.Ws + y0 * a.Ws + x0) * (unsigned)a.Cs + (unsigned)(chunk * PE)) * (unsigned)sizeof(T);
+            unsigned mask = 0;
+            for (int rr = 0; rr < a.R; ++rr)
+                for (int ss = 0; ss < a.S; ++ss) {
+                    const int ys = a.transposed ? y + a.pad - rr : y0 - a.pad + rr;
+                    const int xs = a.transposed ? x + a.pad - ss : x0 - a.pad + ss;
+                    const bool ok = valid && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
+                    mask |= (ok ? 1u : 0u) << (rr * a.S + ss);
+                }
+            vmask[i] = mask;
+        }
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int n = n0 + 16 * (NBI * wave + i) + prow;
+            vwf[i] = n < a.Cd ? ((unsigned)n * (unsigned)a.ldw + (unsigned)(chunk * PE)) * (unsigned)sizeof(T) : OOB;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + 16 * (2 * wave + i) + prow;
+            mv[i] = m < a.M;
+            const int mm = mv[i] ? m : 0;
+            const int n = mm / HW, rem = mm - n * HW;
+            const int y = rem / a.Wd, x = rem - y * a.Wd;
+            by[i] = a.transposed ? y + a.pad : (y << a.sshift) - a.pad;
+            bx[i] = a.transposed ? x + a.pad : (x << a.sshift) - a.pad;
+            ib[i] = n * a.Hs * a.Ws;
+        }
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int n = n0 + 16 * (NBI * wave + i) + prow;
+            wrow[i] = n < a.Cd ? (unsigned)n * (unsigned)a.ldw * (unsigned)sizeof(T) : OOB;
+        }
+        const int tap = e / a.Cs;
+        c = e - tap * a.Cs;
+        r = tap / a.S;
+        s = tap - r * a.S;
     }
-    int e = chunk * PE;
-    int tap = e / a.Cs;
-    int c = e - tap * a.Cs;
-    int r = tap / a.S;
-    int s = tap - r * a.S;
+    // The range check is applied to voffset + soffset on gfx950 (measured: taps of the last image rows were
+    // zeroed with num_records = src_bytes), so the window is widened by the base shift; the out-of-range
+    // marker 0x80000000 cannot wrap below it whatever soffset is (both operands are < 2 GiB).
+    const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src) - shiftP, 0,
+                                                          src_bytes + (unsigned)shiftP + 16u, 0x00020000);
+    const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wgt), 0, wgt_bytes, 0x00020000);
+    // wave-uniform K-step state of the fast path: tap (ur, us), first channel uc, step index uk
+    int ur = 0, us = 0, uc = 0, uk = 0;
 
     auto issue = [&](int stage) {
         unsigned char* A = smem + stage * STAGE;
         unsigned char* B = A + BM * 64;
+        if constexpr (UTAP) {
+            const int t = ur * a.S + us;
+            const int disp = dsign * ((ur - a.pad) * a.Ws + (us - a.pad));          // pixels
+            const unsigned soff = (unsigned)((disp * a.Cs + uc) * (int)sizeof(T) + shiftP);
+            const unsigned soffw = (unsigned)(uk * KE * (int)sizeof(T));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int ys, xs;
-            bool ok = mv[i] && r < a.R;
-            if (a.transposed) {
-                const int ty = by[i] - r, tx = bx[i] - s;
-                ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & a.sshift) == 0;
-                ys = ty >> a.sshift; xs = tx >> a.sshift;
-                ok = ok && ys < a.Hs && xs < a.Ws;
-            } else {
-                ys = by[i] + r; xs = bx[i] + s;
-                ok = ok && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
+            for (int i = 0; i < 2; ++i) {
+                const unsigned off = ((vmask[i] >> t) & 1u) ? vbase[i] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(A + (2 * wave + i) * 1024), 16, off, soff, 0, 0);
             }
-            const unsigned off = ok ? ((unsigned)(ib[i] + ys * a.Ws + xs) * (unsigned)a.Cs + (unsigned)c) * (unsigned)sizeof(T) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(A + (2 * wave + i) * 1024), 16, off, 0, 0, 0);
-        }
 #pragma unroll
-        for (int i = 0; i < NBI; ++i) {
-            const unsigned off = (wrow[i] != OOB && e < a.K) ? wrow[i] + (unsigned)e * (unsigned)sizeof(T) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)(B + (NBI * wave + i) * 1024), 16, off, 0, 0, 0);
+            for (int i = 0; i < NBI; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)(B + (NBI * wave + i) * 1024), 16, vwf[i], soffw, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int ys, xs;
+                bool ok = mv[i] && r < a.R;
+                if (a.transposed) {
+                    const int ty = by[i] - r, tx = bx[i] - s;
+                    ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & a.sshift) == 0;
+                    ys = ty >> a.sshift; xs = tx >> a.sshift;
+                    ok = ok && ys < a.Hs && xs < a.Ws;
+                } else {
+                    ys = by[i] + r; xs = bx[i] + s;
+                    ok = ok && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
+                }
+                const unsigned off = ok ? ((unsigned)(ib[i] + ys * a.Ws + xs) * (unsigned)a.Cs + (unsigned)c) * (unsigned)sizeof(T) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(A + (2 * wave + i) * 1024), 16, off, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NBI; ++i) {
+                const unsigned off = (wrow[i] != OOB && e < a.K) ? wrow[i] + (unsigned)e * (unsigned)sizeof(T) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)(B + (NBI * wave + i) * 1024), 16, off, 0, 0, 0);
+            }
         }
     };
     auto advance = [&]() {
-        e += KE;
-        c += KE;
-        while (c >= a.Cs) { c -= a.Cs; if (++s == a.S) { s = 0; ++r; } }
+        if constexpr (UTAP) {
+            ++uk;
+            uc += KE;
+            if (uc >= a.Cs) { uc = 0; if (++us == a.S) { us = 0; ++ur; } }
+        } else {
+            e += KE;
+            c += KE;
+            while (c >= a.Cs) { c -= a.Cs; if (++s == a.S) { s = 0; ++r; } }
+        }
     };
 
     f32x4 acc[CI][4];
@@ -453,6 +518,17 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs a, unsigne
     conv_epilogue<T, BN, OUTF32>(a, acc, m0, n0, wm, wn, fr, fc);
 }
 
+// two kernel names instead of a fourth template flag (hipcc/ROCm 7.2 fails to emit the host stub of a
+// __global__ template whose body differs only by such a flag)
+template <typename T, int BN, bool OUTF32>
+__global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+    conv_igemm_dma_body<T, BN, OUTF32, false>(a, src_bytes, wgt_bytes);
+}
+template <typename T, int BN, bool OUTF32>
+__global__ void __launch_bounds__(256) conv_igemm_dma_utap_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+    conv_igemm_dma_body<T, BN, OUTF32, true>(a, src_bytes, wgt_bytes);
+}
+
 template <typename T, bool OUTF32>
 int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
     ConvArgs a = a0;
@@ -464,12 +540,19 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
     if (blocks > 0x7fffffff) return IIF_EUNSUPPORTED;
     static const bool force_v1 = getenv("IIF_CONV_REGSTAGE") != nullptr;
     // LDS-DMA addressing is a 32-bit byte offset with a hardware range check: both operands must be < 2 GiB
-    const bool dma = !force_v1 && src_bytes < 0x7ffffff0LL && wgt_bytes < 0x7ffffff0LL;
+    const bool dma = !force_v1 && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL;
     const dim3 grid((unsigned)blocks), blk(256);
     if (dma) {
         const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
-        if (narrow) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 64, OUTF32>), grid, blk, 0, st, a, sb, wb);
-        else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 128, OUTF32>), grid, blk, 0, st, a, sb, wb);
+        static const bool no_fast = getenv("IIF_CONV_GENERAL_ADDR") != nullptr;
+        const bool fast = !no_fast && (a.Cs % ET<T>::KE) == 0 && a.R * a.S <= 32 && !(a.transposed && a.sshift);
+        if (fast) {
+            if (narrow) hipLaunchKernelGGL((conv_igemm_dma_utap_kernel<T, 64, OUTF32>), grid, blk, 0, st, a, sb, wb);
+            else hipLaunchKernelGGL((conv_igemm_dma_utap_kernel<T, 128, OUTF32>), grid, blk, 0, st, a, sb, wb);
+        } else {
+            if (narrow) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 64, OUTF32>), grid, blk, 0, st, a, sb, wb);
+            else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 128, OUTF32>), grid, blk, 0, st, a, sb, wb);
+        }
     } else {
         if (narrow) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, OUTF32>), grid, blk, 0, st, a);
         else hipLaunchKernelGGL((conv_igemm_kernel<T, 128, OUTF32>), grid, blk, 0, st, a);

@@ -24,7 +24,7 @@ namespace {
 struct WgArgs {
     const unsigned char* x; const unsigned char* dy; float* out;
     int N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, sshift, pad, ldw, M, K;
-    int ktiles, ntiles, steps_per_split, nsteps;
+    int ktiles, ntiles, steps_per_split, nsteps, nsplits;
     int64_t slab;          // elements between split slabs (0 when writing dW directly)
 };
 
@@ -255,9 +255,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(WgArgs a, unsigned 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;
-    const int kt = blockIdx.x % a.ktiles, ntile = blockIdx.x / a.ktiles;
+    // XCD-aware map (workgroups are dealt round-robin over the 8 XCDs): all tiles of one pixel split run
+    // back-to-back on ONE XCD, so the split's pixel rows of x / dy are fetched from HBM once and re-read
+    // from that XCD's L2 by the other tiles.
+    const int tiles = a.ktiles * a.ntiles;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int split = (jj / tiles) * 8 + xcd, tile = jj % tiles;
+    if (split >= a.nsplits) return;
+    const int kt = tile % a.ktiles, ntile = tile / a.ktiles;
     const int k0 = kt * BC, n0 = ntile * BNW;
-    const int split = blockIdx.y;
     const int step0 = split * a.steps_per_split;
     int step1 = step0 + a.steps_per_split;
     if (step1 > a.nsteps) step1 = a.nsteps;
@@ -395,17 +401,22 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(WgArgs a, unsigned 
     }
 }
 
-// dw[k][n] = sum_s slab[s][k][n] for n < K (pad columns untouched), fixed order
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int splits, int64_t slab, int Cd, int ldw,
-                                                           int K, float* dw) {
+// dw[k][n] = sum_s slab[s][k][n] for n < K (pad columns untouched), fixed order.  blockIdx.y selects a chunk
+// of `chunk` consecutive slabs; with gridDim.y > 1 the chunk sums go to out + blockIdx.y*slab (second stage
+// then runs with the chunk sums as its slabs).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int splits, int chunk, int64_t slab, int Cd,
+                                                           int ldw, int K, float* out, int64_t out_stride) {
     const int64_t total4 = (int64_t)Cd * ldw / 4;
+    const int s0 = blockIdx.y * chunk;
+    int s1 = s0 + chunk; if (s1 > splits) s1 = splits;
+    float* dst = out + (int64_t)blockIdx.y * out_stride;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int64_t e = i * 4;
         const int n = (int)(e % ldw);
         if (n >= K) continue;
-        f32x4 s = *reinterpret_cast<const f32x4*>(ws + e);
-        for (int j = 1; j < splits; ++j) s += *reinterpret_cast<const f32x4*>(ws + j * slab + e);
-        *reinterpret_cast<f32x4*>(dw + e) = s;
+        f32x4 s = *reinterpret_cast<const f32x4*>(ws + (int64_t)s0 * slab + e);
+        for (int j = s0 + 1; j < s1; ++j) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)j * slab + e);
+        *reinterpret_cast<f32x4*>(dst + e) = s;
     }
 }
 
@@ -439,13 +450,15 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     if (splits < 1) splits = 1;
     a.slab = splits > 1 ? slab : 0;
     a.out = splits > 1 ? ws : dw;
+    a.nsplits = splits;
     const dim3 grid(tiles, splits);
+    const dim3 grid1d((unsigned)(tiles * ((splits + 7) / 8) * 8));
     static const bool force_v1 = getenv("IIF_CONV_REGSTAGE") != nullptr;
     const bool dma = !force_v1 && x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL;
     if (dma) {
         const unsigned xb = (unsigned)x_bytes, yb = (unsigned)dy_bytes;
-        if (bc == 64) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64>), grid, dim3(256), 0, st, a, xb, yb);
-        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128>), grid, dim3(256), 0, st, a, xb, yb);
+        if (bc == 64) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64>), grid1d, dim3(256), 0, st, a, xb, yb);
+        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128>), grid1d, dim3(256), 0, st, a, xb, yb);
     } else {
         if (bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, st, a);
@@ -454,7 +467,24 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     if (splits > 1) {
         const int64_t total4 = slab / 4;
         const int blocks = (int)(cdiv64(total4, 256) < 2048 ? cdiv64(total4, 256) : 2048);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, splits, slab, a.Cd, a.ldw, a.K, dw);
+        // few elements x many slabs: sum chunks of 16 slabs in parallel first (into the slab area itself:
+        // chunk c writes slab c, which only chunk 0 reads, and chunk 0's own slab 0 is read before written
+        // by the same thread), then one pass over the <= ceil(splits/16) chunk sums
+        if (splits > 32 && blocks * 256 < 65536) {
+            const int chunk = 16, nch = (splits + chunk - 1) / chunk;
+            float* stage = ws + (int64_t)splits * slab;       // needs nch more slabs of workspace
+            if ((int64_t)(splits + nch) * slab * 4 <= ws_bytes) {
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, nch), dim3(256), 0, st, ws, splits, chunk, slab, a.Cd,
+                                   a.ldw, a.K, stage, slab);
+                IIF_LAUNCH_CHECK();
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, stage, nch, nch, slab, a.Cd,
+                                   a.ldw, a.K, dw, (int64_t)0);
+                IIF_LAUNCH_CHECK();
+                return IIF_OK;
+            }
+        }
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, ws, splits, splits, slab, a.Cd, a.ldw,
+                           a.K, dw, (int64_t)0);
         IIF_LAUNCH_CHECK();
     }
     return IIF_OK;
