@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--per-shape", action="store_true", help="print the per-shape conv table to stderr")
+    ap.add_argument("--force-reducer", action="store_true", help="drive the bucketed all-reduce path even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,7 +168,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or (args.force_reducer and "RANK" in os.environ):
         dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
@@ -185,7 +186,9 @@ def main():
     net.train()
     broadcast_parameters(net)
     crit = IIFLoss(_Counts(counts), variant="raw", reduction="mean", device=dev)
-    reducer = net.make_reducer() if world > 1 else None
+    reducer = net.make_reducer() if (world > 1 or args.force_reducer) else None
+    if reducer is not None and args.force_reducer:
+        reducer.force = True
     g = torch.Generator().manual_seed(1234 + rank)
     B = args.batch
     x = torch.randn(B, 3, args.image, args.image, generator=g).to(dev)
@@ -268,7 +271,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(counts, args.cpu_batch, args.cpu_steps)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -407,17 +407,18 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src) - shiftP, 0,
                                                           src_bytes + (unsigned)shiftP + 16u, 0x00020000);
     const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wgt), 0, wgt_bytes, 0x00020000);
-    // wave-uniform K-step state of the fast path: tap (ur, us), first channel uc, step index uk
-    int ur = 0, us = 0, uc = 0, uk = 0;
+    // wave-uniform K-step state of the uniform-tap path, kept incrementally: tap (ur, us), first channel uc,
+    // tap bit index ut, source soffset usoff (bytes), weight soffset uwoff (bytes)
+    int ur = 0, us = 0, uc = 0, ut = 0;
+    unsigned usoff = (unsigned)(dsign * (-a.pad * a.Ws - a.pad) * a.Cs * (int)sizeof(T) + shiftP), uwoff = 0;
 
-    auto issue = [&](int stage) {
+    auto issue = [&](auto stage_c) {
+        constexpr int stage = decltype(stage_c)::value;
         unsigned char* A = smem + stage * STAGE;
         unsigned char* B = A + BM * 64;
         if constexpr (UTAP) {
-            const int t = ur * a.S + us;
-            const int disp = dsign * ((ur - a.pad) * a.Ws + (us - a.pad));          // pixels
-            const unsigned soff = (unsigned)((disp * a.Cs + uc) * (int)sizeof(T) + shiftP);
-            const unsigned soffw = (unsigned)(uk * KE * (int)sizeof(T));
+            const int t = ut;
+            const unsigned soff = usoff, soffw = uwoff;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const unsigned off = ((vmask[i] >> t) & 1u) ? vbase[i] : OOB;
@@ -452,9 +453,14 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     };
     auto advance = [&]() {
         if constexpr (UTAP) {
-            ++uk;
+            uwoff += KE * (unsigned)sizeof(T);
+            usoff += KE * (unsigned)sizeof(T);
             uc += KE;
-            if (uc >= a.Cs) { uc = 0; if (++us == a.S) { us = 0; ++ur; } }
+            if (uc >= a.Cs) {
+                uc = 0; ++ut;
+                if (++us == a.S) { us = 0; ++ur; }
+                usoff = (unsigned)(dsign * ((ur - a.pad) * a.Ws + (us - a.pad)) * a.Cs * (int)sizeof(T) + shiftP);
+            }
         } else {
             e += KE;
             c += KE;
@@ -470,28 +476,35 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
 
     const int nk = (a.K + KE - 1) / KE;
     const int fr = lane & 15, fc = lane >> 4;
-    issue(0);
-    if (nk > 1) { advance(); issue(1); }
-    int stage = 0;
-    for (int k = 0; k < nk; ++k) {
-        // retire this wave's DMA of step k (leave step k+1's in flight), then meet the other waves
+    // per-lane fragment offsets inside a stage (stage bases are compile-time immediates below)
+    int wofs[CI], xofs[4];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+        const int row = wn * (BN / 2) + ci * 16 + fr;
+        wofs[ci] = BM * 64 + row * 64 + ((fc ^ swz(row)) << 4);
+    }
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) {
+        const int row = wm * 64 + pj * 16 + fr;
+        xofs[pj] = row * 64 + ((fc ^ swz(row)) << 4);
+    }
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    // one K step on LDS stage S: retire this wave's DMA of step k (leave step k+1's in flight), meet the
+    // other waves, refill the stage that was read in step k-1 with step k+2, multiply stage S
+    auto step = [&](auto stage_c, auto refill_c, int k) {
+        constexpr int S = decltype(stage_c)::value;
         if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (k + 2 < nk) { advance(); issue(stage == 0 ? 2 : stage - 1); }   // stage (k+2)%3: last read in step k-1
-        const unsigned char* A = smem + stage * STAGE;
-        const unsigned char* B = A + BM * 64;
+        if (k + 2 < nk) { advance(); issue(refill_c); }
+        const unsigned char* base = smem + S * STAGE;
         u32x4 wf[CI], xf[4];
 #pragma unroll
-        for (int ci = 0; ci < CI; ++ci) {
-            const int row = wn * (BN / 2) + ci * 16 + fr;
-            wf[ci] = *reinterpret_cast<const u32x4*>(B + row * 64 + ((fc ^ swz(row)) << 4));
-        }
+        for (int ci = 0; ci < CI; ++ci) wf[ci] = *reinterpret_cast<const u32x4*>(base + wofs[ci]);
 #pragma unroll
-        for (int pj = 0; pj < 4; ++pj) {
-            const int row = wm * 64 + pj * 16 + fr;
-            xf[pj] = *reinterpret_cast<const u32x4*>(A + row * 64 + ((fc ^ swz(row)) << 4));
-        }
+        for (int pj = 0; pj < 4; ++pj) xf[pj] = *reinterpret_cast<const u32x4*>(base + xofs[pj]);
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
@@ -507,7 +520,13 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
                     acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[ci][pj], 0, 0, 0);
                 }
             }
-        stage = stage == 2 ? 0 : stage + 1;
+    };
+    issue(S0{});
+    if (nk > 1) { advance(); issue(S1{}); }
+    for (int k = 0; k < nk; k += 3) {
+        step(S0{}, S2{}, k);
+        if (k + 1 < nk) step(S1{}, S0{}, k + 1);
+        if (k + 2 < nk) step(S2{}, S1{}, k + 2);
     }
     if constexpr (sizeof(T) == 2 && !OUTF32) {
         if ((a.Cd & 7) == 0 && a.bias == nullptr) {     // wave-uniform
