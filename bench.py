@@ -154,10 +154,11 @@ def main():
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--per-shape", action="store_true", help="print the per-shape conv table to stderr")
+    ap.add_argument("--trace-loss", action="store_true", help="record the loss of every step (one tiny copy per step)")
     ap.add_argument("--force-reducer", action="store_true", help="drive the bucketed all-reduce path even with one rank")
     args = ap.parse_args()
 
@@ -196,10 +197,14 @@ def main():
     y = torch.multinomial(prior / prior.sum(), B, replacement=True, generator=g).to(dev)
     scale = reducer.grad_scale if reducer is not None else 1.0
 
+    trace = []
+
     def step(it):
         lr = 0.1 * (1e-3 * (1 - min(it, 1000) / 1000.0) + min(it, 1000) / 1000.0)      # train.py:52-56 warm-up
         loss, _ = net.loss_and_backward(x, y, crit, reducer=reducer)
         net.sgd_step(lr, 0.9, 1e-4, grad_scale=scale)
+        if args.trace_loss:
+            trace.append(loss.clone())
         return loss
 
     def note(msg):
@@ -236,6 +241,8 @@ def main():
         dt = float(t.item())
     final_loss = float(loss.item())
     note("timed region: %.3f s for %d steps" % (dt, args.steps))
+    if trace:
+        note("loss trace: " + " ".join("%.4f" % t.item() for t in trace))
 
     if rank == 0:
         out = {
