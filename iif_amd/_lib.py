@@ -48,6 +48,10 @@ SIGNATURES = {
     "iif_shortcut_a_backward_acc": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "iif_colsum_f32": [_P, _I, _I, _L, _P, _P],
     "iif_sgd_step": [_P, _P, _P, _L, _F, _P, _F, _F, _I, _F, _P],
+    "iif_rowmap_forward": [_P, _I, _I, _I, _L, _I, _F, _F, _P, _I, _L, _P, _P],
+    "iif_rowmap_backward": [_P, _I, _P, _P, _I, _I, _I, _L, _L, _I, _F, _F, _P, _I, _L, _P],
+    "iif_transpose_f32": [_P, _I, _I, _L, _P, _L, _P],
+    "iif_dot_window_f32": [_P, _P, _I, _I, _L, _L, _F, _P, _P, _P],
 }
 
 

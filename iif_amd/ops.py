@@ -194,3 +194,32 @@ def colsum_f32(a, rows, cols, ld, out):
 def sgd_step(params, grads, bufs, lr, momentum, weight_decay, nesterov=False, grad_scale=1.0, d_lr=None):
     check(lib().iif_sgd_step(ptr(params), ptr(grads), ptr(bufs), params.numel(), float(lr), ptr(d_lr), float(momentum),
                              float(weight_decay), 1 if nesterov else 0, float(grad_scale), stream_ptr()), "iif_sgd_step")
+
+
+# ------------------------------------------------------- cosine / normed heads
+def rowmap_forward(x, mode, scale, out, norms=None, eps=1e-12):
+    rows, cols = x.shape
+    check(lib().iif_rowmap_forward(ptr(x), dtype_code(x), rows, cols, x.stride(0), mode, float(scale), eps, ptr(out),
+                                   dtype_code(out), out.stride(0), ptr(norms), stream_ptr()), "iif_rowmap_forward")
+    return out
+
+
+def rowmap_backward(x, norms, g, mode, scale, dx, eps=1e-12):
+    rows, cols = x.shape
+    check(lib().iif_rowmap_backward(ptr(x), dtype_code(x), ptr(norms), ptr(g), dtype_code(g), rows, cols, x.stride(0),
+                                    g.stride(0), mode, float(scale), eps, ptr(dx), dtype_code(dx), dx.stride(0),
+                                    stream_ptr()), "iif_rowmap_backward")
+    return dx
+
+
+def transpose_f32(src, dst):
+    rows, cols = src.shape
+    check(lib().iif_transpose_f32(ptr(src), rows, cols, src.stride(0), ptr(dst), dst.stride(0), stream_ptr()),
+          "iif_transpose_f32")
+    return dst
+
+
+def dot_window_f32(a, b, rows, cols, alpha, out, alpha_div=None):
+    check(lib().iif_dot_window_f32(ptr(a), ptr(b), rows, cols, a.stride(0), b.stride(0), float(alpha), ptr(alpha_div),
+                                   ptr(out), stream_ptr()), "iif_dot_window_f32")
+    return out

@@ -11,10 +11,9 @@ __all__ = ["ResNet_s", "resnet20", "resnet32", "resnet44", "resnet56", "resnet11
 
 
 def ResNet_s(block, num_blocks, num_classes=10, use_norm=None, device="cuda", compute_dtype=torch.bfloat16):
-    if not (use_norm is None or use_norm == "None"):
-        raise NotImplementedError("classifier normalisation %r (cosine / norm heads) is not built yet; "
-                                  "SURVEY §8(f) rank 1" % (use_norm,))
-    return NativeResNet("cifar", "basic", list(num_blocks), num_classes, device=device, compute_dtype=compute_dtype)
+    un = use_norm if use_norm in ("cosine", "lr_cosine", "norm") else None
+    return NativeResNet("cifar", "basic", list(num_blocks), num_classes, device=device, compute_dtype=compute_dtype,
+                        use_norm=un)
 
 
 def resnet20(num_classes=10, use_norm=None, **kw):

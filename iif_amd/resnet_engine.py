@@ -73,6 +73,34 @@ class LinearParam(nn.Module):
         self.bias = nn.Parameter(torch.empty(out_features))
 
 
+class CosNormParam(nn.Module):
+    """Cosine classifier (resnet_cifar.py:50-78): weight [out, in]; ``scale`` is 16, or a learnable
+    parameter initialised to 5 and used squared (``lr_scale``)."""
+
+    def __init__(self, in_dims, out_dims, scale=16, lr_scale=False):
+        super().__init__()
+        self.in_features, self.out_features, self.out_dims = in_dims, out_dims, out_dims
+        self.out_padded = _round_up(out_dims, 8)
+        self.lr_scale = lr_scale
+        self.weight = nn.Parameter(torch.empty(out_dims, in_dims))
+        if lr_scale:
+            self.scale = nn.Parameter(5.0 * torch.ones(1))
+        else:
+            self.scale = scale
+
+
+class NormedLinearParam(nn.Module):
+    """NormedLinear (resnet_cifar.py:38-48): weight [in, out], column-normalised in forward; the
+    reference also registers an (unused) bias."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.out_padded = _round_up(out_features, 8)
+        self.weight = nn.Parameter(torch.empty(in_features, out_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+
+
 class BlockParam(nn.Module):
     """conv/bn pairs of one residual block, registered in the reference's order."""
 
@@ -103,7 +131,7 @@ class NativeResNet(nn.Module):
     """ImageNet-style (``style='imagenet'``) or CIFAR-style (``style='cifar'``) ResNet."""
 
     def __init__(self, style, block, layers, num_classes, groups=1, width_per_group=64, device="cuda",
-                 compute_dtype=torch.bfloat16, zero_init_residual=False):
+                 compute_dtype=torch.bfloat16, zero_init_residual=False, use_norm=None):
         super().__init__()
         if groups != 1:
             raise NotImplementedError("grouped 3x3 convolutions (ResNeXt) are not built yet (SURVEY §8 a10)")
@@ -128,7 +156,7 @@ class NativeResNet(nn.Module):
                     inpl = planes * exp
                 stages.append(nn.Sequential(*blocks))
             self.layer1, self.layer2, self.layer3, self.layer4 = stages
-            self.fc = LinearParam(inpl, num_classes)
+            self.fc = self._make_head(use_norm, inpl, num_classes)
             self._stages = stages
         else:
             self.conv1 = ConvParam(3, 16, 3, 1, 1); self.bn1 = BNParam(16)
@@ -143,12 +171,23 @@ class NativeResNet(nn.Module):
                     inpl = planes
                 stages.append(nn.Sequential(*blocks))
             self.layer1, self.layer2, self.layer3 = stages
-            self.linear = LinearParam(inpl, num_classes)
+            self.linear = self._make_head(use_norm, inpl, num_classes)
             self._stages = stages
         # the stem runs as a GEMM over gathered patches: K padded to a multiple of 32
         self.conv1.ldw = _round_up(self.conv1.kdim, 32)
         self._init_parameters(zero_init_residual)
         self._flatten(torch.device(device))
+
+    @staticmethod
+    def _make_head(use_norm, in_features, num_classes):
+        """resnet_pytorch.py:212-219 / resnet_cifar.py:185-192."""
+        if use_norm == "cosine":
+            return CosNormParam(in_features, num_classes)
+        if use_norm == "lr_cosine":
+            return CosNormParam(in_features, num_classes, lr_scale=True)
+        if use_norm == "norm":
+            return NormedLinearParam(in_features, num_classes)
+        return LinearParam(in_features, num_classes)
 
     @property
     def _head(self):
@@ -163,6 +202,13 @@ class NativeResNet(nn.Module):
                 else:                             # resnet_cifar.py:33-36 kaiming_normal_ (fan_in)
                     std = math.sqrt(2.0 / (m.cin * m.k * m.k))
                 nn.init.normal_(m.weight, 0.0, std)
+            elif isinstance(m, CosNormParam):     # resnet_cifar.py:63-65 uniform(+-1/sqrt(in))
+                bound = 1.0 / math.sqrt(m.in_features)
+                nn.init.uniform_(m.weight, -bound, bound)
+            elif isinstance(m, NormedLinearParam):  # resnet_cifar.py:42-44
+                with torch.no_grad():
+                    m.weight.uniform_(-1, 1).renorm_(2, 1, 1e-5).mul_(1e5)
+                    m.bias.normal_()
             elif isinstance(m, LinearParam):
                 if self.style == "imagenet":      # nn.Linear default
                     nn.init.kaiming_uniform_(m.weight, a=math.sqrt(5))
@@ -186,6 +232,13 @@ class NativeResNet(nn.Module):
                 specs.append((m, "bias", 1, m.num_features))
             elif isinstance(m, LinearParam):
                 specs.append((m, "weight", m.out_padded, m.in_features))
+                specs.append((m, "bias", 1, m.out_padded))
+            elif isinstance(m, CosNormParam):
+                specs.append((m, "weight", m.out_padded, m.in_features))
+                if m.lr_scale:
+                    specs.append((m, "scale", 1, 16))
+            elif isinstance(m, NormedLinearParam):
+                specs.append((m, "weight", m.in_features, m.out_padded))
                 specs.append((m, "bias", 1, m.out_padded))
         return specs
 
@@ -213,6 +266,19 @@ class NativeResNet(nn.Module):
                     else:
                         view = flat.view(-1)[:m.out_features]
                         m._b1d = flat.view(-1)
+                elif isinstance(m, CosNormParam):
+                    if attr == "weight":
+                        view = flat[:m.out_features]
+                        m._w2d = flat
+                    else:
+                        view = flat.view(-1)[:1]
+                        m._s1d = flat.view(-1)
+                elif isinstance(m, NormedLinearParam):
+                    if attr == "weight":
+                        view = flat[:, :m.out_features]
+                        m._w2d = flat
+                    else:
+                        view = flat.view(-1)[:m.out_features]
                 else:
                     view = flat.view(-1)
                 view.copy_(old.detach().to(device))
@@ -252,6 +318,16 @@ class NativeResNet(nn.Module):
                     gv = gflat[:m.out_features]; m._g2d = gflat
                 else:
                     gv = gflat.view(-1)[:m.out_features]; m._gb1d = gflat.view(-1)
+            elif isinstance(m, CosNormParam):
+                if attr == "weight":
+                    gv = gflat[:m.out_features]; m._g2d = gflat
+                else:
+                    gv = gflat.view(-1)[:1]; m._gs1d = gflat.view(-1)
+            elif isinstance(m, NormedLinearParam):
+                if attr == "weight":
+                    gv = gflat[:, :m.out_features]; m._g2d = gflat
+                else:
+                    gv = gflat.view(-1)[:m.out_features]
             else:
                 gv = gflat.view(-1)
                 if attr == "weight":
@@ -444,8 +520,26 @@ class _Plan(object):
         self.dlogits_t = torch.zeros((n, head.out_padded), dtype=dt, device=dev)
         self.loss_rows = torch.zeros(n, dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
-        self.head_w = head._w2d if dt == torch.float32 else torch.empty_like(head._w2d, dtype=dt)
-        self.head_wt = torch.zeros((head.in_features, _round_up(head.out_padded, 16)), dtype=dt, device=dev)
+        op, D = head.out_padded, head.in_features
+        self.head_kind = ("linear" if isinstance(head, LinearParam) else
+                          "norm" if isinstance(head, NormedLinearParam) else "cosine")
+        F32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)   # noqa: E731
+        if self.head_kind == "linear":
+            self.head_wsrc = head._w2d                       # fp32 [op, D] matrix the GEMM weights come from
+        else:
+            self.head_wsrc = F32(op, D)                      # normalised weights (fp32)
+            self.head_wnorm = F32(op)
+            self.head_ex = E(n, D)                           # mapped features fed to the GEMM
+            self.head_xnorm = F32(n)
+            self.head_dwn = F32(op, D)                       # gradient w.r.t. the normalised weights
+            self.head_dex = E(n, D)
+            if self.head_kind == "norm":
+                self.head_wT = F32(op, D)                    # W^T: [out, in] rows of the [in, out] parameter
+                self.head_dwT = F32(op, D)
+            if self.head_kind == "cosine" and head.lr_scale:
+                self.head_s2 = F32(1)
+        self.head_w = self.head_wsrc if dt == torch.float32 else torch.empty((op, D), dtype=dt, device=dev)
+        self.head_wt = torch.zeros((D, _round_up(op, 16)), dtype=dt, device=dev)
         # ---- scratch
         cmax = max(u.conv.cout for u in self.units)
         mmax = max(u.n * u.ho * u.wo for u in self.units)
@@ -484,10 +578,15 @@ class _Plan(object):
             if need_transposed and u.wt is not None:
                 ops.weight_transpose(u.conv._w2d, u.conv.cout, u.conv.cin, u.conv.k * u.conv.k, u.wt)
         head = self.net._head
+        if self.head_kind == "cosine":           # ew = W / |W_row|   (resnet_cifar.py:73)
+            ops.rowmap_forward(head._w2d, 1, 1.0, self.head_wsrc, self.head_wnorm, eps=0.0)
+        elif self.head_kind == "norm":           # ew = W / |W_col|, W is [in, out]   (resnet_cifar.py:47)
+            ops.transpose_f32(head._w2d, self.head_wT)
+            ops.rowmap_forward(self.head_wT, 1, 1.0, self.head_wsrc, self.head_wnorm)
         if self.dt != torch.float32:
-            ops.cast(head._w2d, self.head_w)
+            ops.cast(self.head_wsrc, self.head_w)
         if need_transposed:
-            ops.weight_transpose(head._w2d, head.out_padded, head.in_features, 1, self.head_wt)
+            ops.weight_transpose(self.head_wsrc, head.out_padded, head.in_features, 1, self.head_wt)
 
     # ---------------------------------------------------------------- forward
     def _conv_bn(self, u, training):
@@ -537,8 +636,23 @@ class _Plan(object):
                 ops.bn_apply(x2, last.stats, last.y.view(x2.shape), relu=True, residual=b["inp"].view(x2.shape))
         ops.avgpool_forward(self.final, out=self.pooled)
         head = net._head
-        ops.conv_forward(self.pooled.view(self.n, 1, 1, head.in_features), self.head_w, 1, 1, 1, 0,
-                         out=self.logits.view(self.n, 1, 1, head.out_padded), bias=head._b1d)
+        feat, bias = self.pooled, None
+        if self.head_kind == "linear":
+            bias = head._b1d
+        elif self.head_kind == "norm":           # F.normalize(x, dim=1)
+            feat = ops.rowmap_forward(self.pooled, 1, 1.0, self.head_ex, self.head_xnorm)
+        else:                                    # scale * x / (1 + |x|)
+            if head.lr_scale:                    # learnable scale, used squared; applied on the device
+                ops.rowmap_forward(self.pooled, 0, 1.0, self.head_ex, self.head_xnorm)
+                torch.mul(head._s1d[:1], head._s1d[:1], out=self.head_s2)
+                _lib.check(_lib.lib().iif_scale_by_device_scalar(_lib.ptr(self.head_ex), _lib.dtype_code(self.head_ex),
+                                                                 self.head_ex.numel(), _lib.ptr(self.head_s2),
+                                                                 _lib.stream_ptr()), "iif_scale_by_device_scalar")
+            else:
+                ops.rowmap_forward(self.pooled, 0, float(head.scale), self.head_ex, self.head_xnorm)
+            feat = self.head_ex
+        ops.conv_forward(feat.view(self.n, 1, 1, head.in_features), self.head_w, 1, 1, 1, 0,
+                         out=self.logits.view(self.n, 1, 1, head.out_padded), bias=bias)
         if training:
             net._nbt += 1
 
@@ -587,19 +701,43 @@ class _Plan(object):
         offs = net.block_offsets() if reducer is not None else None
         if reducer is not None:
             reducer.begin()
-        # ---- head: dlogits (fp32, pad columns are zero) -> fc grads -> pooled grad -> final activation grad
-        ops.colsum_f32(self.dlogits, n, head.out_padded, head.out_padded, head._gb1d)
+        # ---- head: dlogits (fp32, pad columns are zero) -> head grads -> pooled grad -> final activation grad
+        op, D = head.out_padded, head.in_features
         if self.dt == torch.float32:
             dl = self.dlogits
         else:
             dl = ops.cast(self.dlogits, self.dlogits_t)
-        ops.conv_wgrad(self.pooled.view(n, 1, 1, head.in_features), dl.view(n, 1, 1, head.out_padded), 1, 1, 1, 0,
-                       ldw=head.in_features, out=head._g2d, workspace=self.wg_ws)
-        dpooled = self._gbuf(("dpooled",), (n, 1, 1, head.in_features))
-        ops.conv_dgrad(dl.view(n, 1, 1, head.out_padded), self.head_wt, 1, 1, 1, 0, (1, 1), out=dpooled)
+        dpooled = self._gbuf(("dpooled",), (n, 1, 1, D))
+        if self.head_kind == "linear":
+            ops.colsum_f32(self.dlogits, n, op, op, head._gb1d)
+            ops.conv_wgrad(self.pooled.view(n, 1, 1, D), dl.view(n, 1, 1, op), 1, 1, 1, 0, ldw=D, out=head._g2d,
+                           workspace=self.wg_ws)
+            ops.conv_dgrad(dl.view(n, 1, 1, op), self.head_wt, 1, 1, 1, 0, (1, 1), out=dpooled)
+        else:
+            # d(normalised weights) = dlogits^T @ ex, then back through the row normalisation
+            ops.conv_wgrad(self.head_ex.view(n, 1, 1, D), dl.view(n, 1, 1, op), 1, 1, 1, 0, ldw=D, out=self.head_dwn,
+                           workspace=self.wg_ws)
+            if self.head_kind == "cosine":
+                ops.rowmap_backward(head._w2d, self.head_wnorm, self.head_dwn, 1, 1.0, head._g2d, eps=0.0)
+            else:
+                ops.rowmap_backward(self.head_wT, self.head_wnorm, self.head_dwn, 1, 1.0, self.head_dwT)
+                ops.transpose_f32(self.head_dwT, head._g2d)
+            ops.conv_dgrad(dl.view(n, 1, 1, op), self.head_wt, 1, 1, 1, 0, (1, 1), out=self.head_dex.view(n, 1, 1, D))
+            dp2 = dpooled.view(n, D)
+            if self.head_kind == "norm":
+                ops.rowmap_backward(self.pooled, self.head_xnorm, self.head_dex, 1, 1.0, dp2)
+            elif head.lr_scale:
+                # logits = s^2 * L0  ->  dL/ds = (2/s) * <dlogits, logits>;  d(ex0) = s^2 * d(ex)
+                ops.dot_window_f32(self.dlogits, self.logits, n, head.out_features, 2.0, head._gs1d, alpha_div=head._s1d)
+                _lib.check(_lib.lib().iif_scale_by_device_scalar(_lib.ptr(self.head_dex), _lib.dtype_code(self.head_dex),
+                                                                 self.head_dex.numel(), _lib.ptr(self.head_s2),
+                                                                 _lib.stream_ptr()), "iif_scale_by_device_scalar")
+                ops.rowmap_backward(self.pooled, self.head_xnorm, self.head_dex, 0, 1.0, dp2)
+            else:
+                ops.rowmap_backward(self.pooled, self.head_xnorm, self.head_dex, 0, float(head.scale), dp2)
         fh, fw, fc = self.final.shape[1], self.final.shape[2], self.final.shape[3]
         g = self._gbuf(("g", self.final.shape), self.final.shape)
-        ops.avgpool_backward(dpooled.view(n, head.in_features), fh * fw, out=g.view(n, fh * fw, fc))
+        ops.avgpool_backward(dpooled.view(n, D), fh * fw, out=g.view(n, fh * fw, fc))
         if reducer is not None:
             reducer.gradients_ready_from(offs["head"])
         # ---- blocks in reverse

@@ -23,11 +23,11 @@ def _absent(v):
 
 def ResNet(block, layers, use_norm=None, num_classes=1000, zero_init_residual=False, groups=1, width_per_group=64,
            device="cuda", compute_dtype=torch.bfloat16):
-    if not _absent(use_norm):
-        raise NotImplementedError("classifier normalisation %r (cosine / norm heads) is not built yet; "
-                                  "SURVEY §8(f) rank 1" % (use_norm,))
+    un = None if _absent(use_norm) else use_norm
+    if un not in (None, "cosine", "lr_cosine", "norm"):
+        un = None                       # the reference falls through to nn.Linear for any other string
     return NativeResNet("imagenet", block, list(layers), num_classes, groups=groups, width_per_group=width_per_group,
-                        device=device, compute_dtype=compute_dtype, zero_init_residual=zero_init_residual)
+                        device=device, compute_dtype=compute_dtype, zero_init_residual=zero_init_residual, use_norm=un)
 
 
 def _resnet(block, layers, pretrained, use_norm, **kwargs):

@@ -244,6 +244,27 @@ int iif_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t
                  const float* d_lr, float momentum, float weight_decay, int nesterov,
                  float grad_scale, void* stream);
 
+/* Cosine / normed classifier heads (resnet_cifar.py:38-78 CosNorm_Classifier,
+ * NormedLinear; mmdet normed_predictor.py).  Row maps and their backward; the
+ * products run on iif_conv_igemm / iif_conv_wgrad.
+ *   mode 0: out = x * scale/(1+|x|)           (cosine feature squashing)
+ *   mode 1: out = x / max(|x|, eps)           (F.normalize; zero rows stay zero)
+ * norms (nullable in forward) receives |x| per row, fp32.
+ * backward: dx = d(out)/dx^T g given the forward input x and its stored norms. */
+int iif_rowmap_forward(const void* x, int x_dtype, int rows, int cols, int64_t ldx, int mode,
+                       float scale, float eps, void* out, int out_dtype, int64_t ldo, float* norms,
+                       void* stream);
+int iif_rowmap_backward(const void* x, int x_dtype, const float* norms, const void* g, int g_dtype,
+                        int rows, int cols, int64_t ldx, int64_t ldg, int mode, float scale, float eps,
+                        void* dx, int dx_dtype, int64_t lddx, void* stream);
+/* out[c][r] = in[r][c] (fp32); NormedLinear keeps its weight [in][out]. */
+int iif_transpose_f32(const float* in, int rows, int cols, int64_t ldi, float* out, int64_t ldo,
+                      void* stream);
+/* out[0] = alpha / (*d_alpha_div or 1) * sum_{r<rows,c<cols} a[r][c]*b[r][c], fixed order
+ * (gradient of the learnable cosine scale). */
+int iif_dot_window_f32(const float* a, const float* b, int rows, int cols, int64_t lda, int64_t ldb,
+                       float alpha, const float* d_alpha_div, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

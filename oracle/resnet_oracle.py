@@ -174,7 +174,26 @@ def _count_bn(sd, prefix, training):
         sd[prefix + ".num_batches_tracked"] += 1
 
 
-def forward_imagenet(sd, x, arch, training=True, q=_id):
+def head_forward(sd, prefix, x, head="linear", q=_id):
+    """Classifier heads.  linear: resnet_pytorch.py:219 / resnet_cifar.py:192.
+    cosine / lr_cosine: CosNorm_Classifier.forward, resnet_cifar.py:68-78
+    (scale 16, or the learnable ``scale`` parameter squared).  norm:
+    NormedLinear.forward, resnet_cifar.py:46-48 (weight stored [in, out])."""
+    w = sd[prefix + ".weight"]
+    if head == "linear":
+        return F.linear(x, q(w), sd[prefix + ".bias"])
+    if head in ("cosine", "lr_cosine"):
+        norm_x = torch.norm(x, 2, 1, keepdim=True)
+        ex = (norm_x / (1 + norm_x)) * (x / norm_x)
+        ew = w / torch.norm(w, 2, 1, keepdim=True)
+        scale = sd[prefix + ".scale"] ** 2 if head == "lr_cosine" else 16
+        return torch.mm(scale * ex, ew.t())
+    if head == "norm":
+        return F.normalize(x, dim=1).mm(F.normalize(w, dim=0))
+    raise ValueError(head)
+
+
+def forward_imagenet(sd, x, arch, training=True, q=_id, head="linear"):
     """resnet_pytorch.py:279-295 (stem, 4 stages, GAP, fc); blocks :95-111 and
     :149-169 (stride on the 3x3 = v1.5).  ``q`` (identity by default) is applied
     wherever the MI355X product STORES a tensor (input, weights, conv outputs,
@@ -207,10 +226,10 @@ def forward_imagenet(sd, x, arch, training=True, q=_id):
                 _count_bn(sd, p + ".downsample.1", training)
             x = q(_relu(o + idt))
     x = q(torch.flatten(F.adaptive_avg_pool2d(x, 1), 1))
-    return F.linear(x, q(sd["fc.weight"]), sd["fc.bias"])
+    return head_forward(sd, "fc", x, head, q)
 
 
-def forward_cifar(sd, x, arch="resnet32", training=True, q=_id):
+def forward_cifar(sd, x, arch="resnet32", training=True, q=_id, head="linear"):
     """resnet_cifar.py:204-212; blocks :133-138; option-A shortcut :125-126
     (spatial ::2 subsample, planes//4 zero channels on each side).  ``q``: see
     forward_imagenet."""
@@ -232,17 +251,37 @@ def forward_cifar(sd, x, arch="resnet32", training=True, q=_id):
             x = q(_relu(o + sc))
             inpl = planes
     x = q(F.avg_pool2d(x, x.size(3)).view(x.size(0), -1))
-    return F.linear(x, q(sd["linear.weight"]), sd["linear.bias"])
+    return head_forward(sd, "linear", x, head, q)
 
 
-def forward(sd, x, arch, training=True, q=_id):
+def forward(sd, x, arch, training=True, q=_id, head="linear"):
     if arch in CIFAR_ARCHS:
-        return forward_cifar(sd, x, arch, training, q)
-    return forward_imagenet(sd, x, arch, training, q)
+        return forward_cifar(sd, x, arch, training, q, head)
+    return forward_imagenet(sd, x, arch, training, q, head)
+
+
+def set_head(sd, arch, num_classes, head, seed=0):
+    """Replace the linear classifier entries by the ones of another head type
+    (init laws of resnet_cifar.py:42-44 and :63-65)."""
+    prefix = "linear" if arch in CIFAR_ARCHS else "fc"
+    d = sd[prefix + ".weight"].shape[1]
+    g = torch.Generator().manual_seed(seed + 17)
+    if head == "norm":
+        w = torch.empty(d, num_classes).uniform_(-1, 1, generator=g)
+        sd[prefix + ".weight"] = w.renorm_(2, 1, 1e-5).mul_(1e5)
+        sd[prefix + ".bias"] = torch.randn(num_classes, generator=g)
+    elif head in ("cosine", "lr_cosine"):
+        bound = 1.0 / math.sqrt(d)
+        sd[prefix + ".weight"] = torch.empty(num_classes, d).uniform_(-bound, bound, generator=g)
+        del sd[prefix + ".bias"]
+        if head == "lr_cosine":
+            sd[prefix + ".scale"] = 5.0 * torch.ones(1)
+    return sd
 
 
 # ----------------------------------------------------------------- train step
-def loss_and_grads(sd, x, y, table, arch, class_weight=None, reduction="mean", q=_id, relu_masks=None):
+def loss_and_grads(sd, x, y, table, arch, class_weight=None, reduction="mean", q=_id, relu_masks=None,
+                   head="linear"):
     """Forward (train mode, running stats updated in ``sd``), IIF loss
     (custom.py:28-36) and autograd gradients for every trainable key.
     Returns (loss, logits, {key: grad})."""
@@ -253,23 +292,24 @@ def loss_and_grads(sd, x, y, table, arch, class_weight=None, reduction="mean", q
     if relu_masks is not None:
         _RELU[0] = relu_masks
     try:
-        logits = forward(work, x, arch, training=True, q=q)
+        logits = forward(work, x, arch, training=True, q=q, head=head)
     finally:
         _RELU[0] = F.relu
     for k in sd:                                   # running stats / counters
         if k not in leaves:
             sd[k] = work[k]
     loss = iif_oracle.iif_ce(logits, y, table, class_weight, reduction)
-    grads = torch.autograd.grad(loss, [leaves[k] for k in keys])
+    grads = torch.autograd.grad(loss, [leaves[k] for k in keys], allow_unused=True)
+    grads = [torch.zeros_like(leaves[k]) if g is None else g for k, g in zip(keys, grads)]   # e.g. NormedLinear.bias
     return loss.detach(), logits.detach(), dict(zip(keys, grads))
 
 
 def train_step(sd, bufs, x, y, table, arch, lr, momentum=0.9, weight_decay=1e-4,
-               nesterov=False, class_weight=None, reduction="mean", q=_id, relu_masks=None):
+               nesterov=False, class_weight=None, reduction="mean", q=_id, relu_masks=None, head="linear"):
     """One iteration of classification/train.py:60-78 without the logging:
     forward, loss, backward, SGD.  ``bufs`` is a dict key -> momentum buffer
     (missing = first step).  Updates ``sd`` and ``bufs`` in place."""
-    loss, logits, grads = loss_and_grads(sd, x, y, table, arch, class_weight, reduction, q, relu_masks)
+    loss, logits, grads = loss_and_grads(sd, x, y, table, arch, class_weight, reduction, q, relu_masks, head)
     keys = list(grads.keys())
     params = [sd[k] for k in keys]
     blist = [bufs.get(k) for k in keys]

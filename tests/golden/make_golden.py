@@ -301,6 +301,48 @@ def g7_nets():
     return out
 
 
+# --------------------------------------------------------------------------- G9
+def g9_heads():
+    """Classifier heads run from the reference's own forward code.  CosNorm_Classifier.__init__
+    hard-codes .cuda() (resnet_cifar.py:57,61), so the module is allocated without __init__ and its
+    attributes set by hand; forward() itself is device-agnostic."""
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    B, D, C = 6, 64, 10
+    x = torch.randn(B, D, generator=g) * 2.0
+    gy = torch.randn(B, C, generator=g)
+    out["x"], out["gy"] = x.numpy(), gy.numpy()
+    for head in ("cosine", "lr_cosine", "norm"):
+        sd = R.set_head({"linear.weight": torch.zeros(C, D), "linear.bias": torch.zeros(C)}, "resnet20", C, head, seed=3)
+        if head == "norm":
+            m = resnet_cifar.NormedLinear(D, C)
+            with torch.no_grad():
+                m.weight.copy_(sd["linear.weight"]); m.bias.copy_(sd["linear.bias"])
+        else:
+            m = resnet_cifar.CosNorm_Classifier.__new__(resnet_cifar.CosNorm_Classifier)
+            torch.nn.Module.__init__(m)
+            m.lr_scale = head == "lr_cosine"
+            m.scale = torch.nn.Parameter(sd["linear.scale"].clone()) if m.lr_scale else 16
+            m.weight = torch.nn.Parameter(sd["linear.weight"].clone())
+        xr = x.clone().requires_grad_(True)
+        y = m(xr)
+        y.backward(gy)
+        out[head + "_weight"] = sd["linear.weight"].numpy()
+        out[head + "_logits"] = y.detach().numpy()
+        out[head + "_dx"] = xr.grad.numpy()
+        out[head + "_dw"] = m.weight.grad.numpy()
+        if head == "lr_cosine":
+            out[head + "_dscale"] = m.scale.grad.numpy()
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xo = x.clone().requires_grad_(True)
+        yo = R.head_forward(leaves, "linear", xo, head)
+        yo.backward(gy)
+        close(yo, y.detach(), 1e-6, head + " logits")
+        close(xo.grad, xr.grad, 1e-6, head + " dx")
+        close(leaves["linear.weight"].grad, m.weight.grad, 1e-6, head + " dw")
+    return out
+
+
 # --------------------------------------------------------------------------- G8
 def g8_warmup():
     opt = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=0.1)
@@ -316,7 +358,10 @@ def g8_warmup():
 
 def main():
     sets = {"g1_class_counts": g1_class_counts, "g2_class_map": g2_class_map, "g3_tables": g3_tables,
-            "g4_loss": g4_loss, "g7_nets": g7_nets, "g8_warmup": g8_warmup}
+            "g4_loss": g4_loss, "g7_nets": g7_nets, "g8_warmup": g8_warmup, "g9_heads": g9_heads}
+    only = sys.argv[1:]
+    if only:
+        sets = {k: v for k, v in sets.items() if k in only}
     for name, fn in sets.items():
         data = fn()
         path = os.path.join(HERE, name + ".npz")

@@ -197,3 +197,21 @@ def test_mmdet_csv_tables_match_formulas(tmp_path):
     assert tb.shape == (1, 5) and tb[0, -1].item() == 1.0
     assert torch.equal(tb[:, :4], tabs["raw"])
     assert torch.equal(M.read_table(str(p), "smooth")[:, :4], tabs["smooth"])
+
+
+@pytest.mark.parametrize("head", ["cosine", "lr_cosine", "norm"])
+def test_g9_classifier_heads(golden, head):
+    """Cosine / normed heads of the oracle against vectors from the reference's own forward code."""
+    g = golden("g9_heads")
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    gy = torch.from_numpy(g["gy"])
+    sd = {"linear.weight": torch.from_numpy(g[head + "_weight"]).clone().requires_grad_(True)}
+    if head == "lr_cosine":
+        sd["linear.scale"] = (5.0 * torch.ones(1)).requires_grad_(True)
+    y = R.head_forward(sd, "linear", x, head)
+    y.backward(gy)
+    for got, key in ((y, "_logits"), (x.grad, "_dx"), (sd["linear.weight"].grad, "_dw")):
+        ref = torch.from_numpy(g[head + key])
+        assert (got.detach() - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item()), (head, key)
+    if head == "lr_cosine":
+        assert abs(sd["linear.scale"].grad.item() - float(g[head + "_dscale"])) <= 1e-5 * abs(float(g[head + "_dscale"]))

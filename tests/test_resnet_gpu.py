@@ -204,3 +204,65 @@ def test_train_cli_runs_natively(tmp_path, capsys):
     assert ckpt["epoch"] == 0 and "linear.weight" in ckpt["model"]
     args2 = train.get_args_parser().parse_args(argv + ["--resume", str(tmp_path / "checkpoint.pth"), "--test-only"])
     train.main(args2)
+
+
+@pytest.mark.parametrize("head", ["cosine", "lr_cosine", "norm"])
+@pytest.mark.parametrize("arch,C,B,hw", [("resnet20", 10, 6, 32), ("resnet18", 100, 4, 64)])
+def test_fp32_cosine_and_normed_heads(head, arch, C, B, hw):
+    """--classif_norm {cosine, lr_cosine, norm} (resnet_cifar.py:38-78): logits, loss and every
+    gradient (incl. the learnable scale) against the oracle, fp32 parity mode, same ReLU decisions."""
+    from iif_amd import resnet_cifar, resnet_pytorch
+    from iif_amd.custom import IIFLoss
+    counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
+    cifar = arch in R.CIFAR_ARCHS
+    sd = (R.init_cifar if cifar else R.init_imagenet)(arch, C, seed=3)
+    sd = R.set_head(sd, arch, C, head, seed=1)
+    if not cifar:
+        damp_residual_branches(sd, arch)
+    mod = resnet_cifar if cifar else resnet_pytorch
+    kw = {} if cifar else {"pretrained": "None"}
+    net = getattr(mod, arch)(num_classes=C, use_norm=head, compute_dtype=torch.float32, **kw)
+    assert list(net.state_dict().keys()) == list(sd.keys()) or set(net.state_dict().keys()) == set(sd.keys())
+    net.load_state_dict(sd)
+    x, y = _data(B, hw, counts, seed=21)
+    table = O.iif_tables(counts)["raw"]
+    crit = IIFLoss(DS(counts), variant="raw")
+    net.train()
+    logits = net(x.to(DEV))
+    loss = crit(logits, y.to(DEV))
+    loss.backward()
+    masks = R.ReluMasks(gpu_relu_masks(net))
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    ref_loss, ref_logits, ref_grads = R.loss_and_grads(ref_sd, x, y, table, arch, relu_masks=masks, head=head)
+    assert masks.disagree <= 1e-4 * masks.total and masks.worst <= 1e-4
+    assert relerr(logits, ref_logits) <= 1e-4 and relerr(loss, ref_loss) <= 1e-4
+    for k, p in net.named_parameters():
+        a, b = p.grad.double().cpu(), ref_grads[k].double()
+        e = (a - b).norm().item() / max(b.norm().item(), 1e-12)
+        assert e <= 2e-4 or b.norm().item() == 0 and a.norm().item() == 0, (k, e)
+    # two fused steps keep tracking the oracle
+    bufs = {}
+    ref2 = {k: v.clone() for k, v in sd.items()}
+    net.load_state_dict(sd)
+    net._mom_arena.zero_()
+    for it in range(2):
+        l, _ = net.loss_and_backward(x.to(DEV), y.to(DEV), crit)
+        m2 = R.ReluMasks(gpu_relu_masks(net))
+        net.sgd_step(0.01, 0.9, 1e-4)
+        rl, _ = R.train_step(ref2, bufs, x, y, table, arch, 0.01, relu_masks=m2, head=head)
+        assert relerr(l, rl) <= 1e-4, (it, l.item(), rl.item())
+
+
+def test_bf16_cosine_head_runs():
+    from iif_amd import resnet_pytorch
+    from iif_amd.custom import IIFLoss
+    C = 1000
+    counts = [max(int(1280 * (5 / 1280) ** (i / (C - 1.0))), 1) for i in range(C)]
+    net = resnet_pytorch.resnet50(num_classes=C, use_norm="cosine", pretrained="None")
+    x, y = _data(8, 64, counts, seed=2)
+    crit = IIFLoss(DS(counts))
+    net.train()
+    l0, _ = net.loss_and_backward(x.to(DEV), y.to(DEV), crit)
+    net.sgd_step(0.01, 0.9, 1e-4)
+    l1, lg = net.loss_and_backward(x.to(DEV), y.to(DEV), crit)
+    assert torch.isfinite(l0).item() and torch.isfinite(l1).item() and lg.abs().max().item() <= 16.0 + 1e-2
