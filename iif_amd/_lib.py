@@ -48,6 +48,8 @@ SIGNATURES = {
     "iif_shortcut_a_backward_acc": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "iif_colsum_f32": [_P, _I, _I, _L, _P, _P],
     "iif_sgd_step": [_P, _P, _P, _L, _F, _P, _F, _F, _I, _F, _P],
+    "iif_group_pack": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "iif_group_unpack_grad": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "iif_rowmap_forward": [_P, _I, _I, _I, _L, _I, _F, _F, _P, _I, _L, _P, _P],
     "iif_rowmap_backward": [_P, _I, _P, _P, _I, _I, _I, _L, _L, _I, _F, _F, _P, _I, _L, _P],
     "iif_transpose_f32": [_P, _I, _I, _L, _P, _L, _P],
@@ -59,7 +61,7 @@ SIGNATURES = {
 class ConvDesc(ctypes.Structure):
     """Mirror of ``iif_conv_desc`` (include/iif_amd.h)."""
     _fields_ = [(k, ctypes.c_int32) for k in ("n", "hs", "ws", "cs", "hd", "wd", "cd", "r", "s", "stride", "pad",
-                                               "transposed", "ldw", "dtype", "dst_dtype")]
+                                               "transposed", "ldw", "dtype", "dst_dtype", "groups")]
 
 
 _lib = None

@@ -40,6 +40,7 @@ struct ConvArgs {
     const float* bias;
     float* bn_partial;     // nullable: [mtiles][2][Cd] per-tile (sum, sum of squares) of the stored output
     int N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, sshift, pad, transposed, ldw, M, K, mtiles, ntiles;
+    int spitch, dpitch, groups;   // channels per pixel of the source / destination TENSORS (= groups * Cs / Cd)
 };
 
 __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
@@ -47,10 +48,10 @@ __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) 
 // epilogue: lane holds channels n0 + wn*BN/2 + ci*16 + fc*4 + {0..3} of pixel m0 + wm*64 + pj*16 + fr
 template <typename T, int BN, bool OUTF32>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BN / 32][4], int m0, int n0, int wm, int wn,
-                                              int fr, int fc) {
+                                              int fr, int fc, int goff = 0) {
     constexpr int CI = BN / 32;
     using OT = typename std::conditional<OUTF32, float, T>::type;
-    const bool vec_ok = (a.Cd & 3) == 0;
+    const bool vec_ok = ((a.Cd | a.dpitch) & 3) == 0;
 #pragma unroll
     for (int pj = 0; pj < 4; ++pj) {
         const int m = m0 + wm * 64 + pj * 16 + fr;
@@ -60,7 +61,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BN
             const int n = n0 + wn * (BN / 2) + ci * 16 + fc * 4;
             if (n >= a.Cd) continue;
             float v[4] = {acc[ci][pj].x, acc[ci][pj].y, acc[ci][pj].z, acc[ci][pj].w};
-            const int64_t o = (int64_t)m * a.Cd + n;
+            const int64_t o = (int64_t)m * a.dpitch + goff + n;
             const int cnt = a.Cd - n < 4 ? a.Cd - n : 4;
             if (a.bias)
                 for (int q = 0; q < cnt; ++q) v[q] += a.bias[n + q];
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
 // bf16-rounded tile are emitted too, so batch-norm statistics need no extra pass over the activation.
 template <int BN>
 __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&acc)[BN / 32][4], unsigned char* smem,
-                                                     int m0, int n0, int mt, int wm, int wn, int fr, int fc) {
+                                                     int m0, int n0, int mt, int wm, int wn, int fr, int fc, int goff) {
     constexpr int CI = BN / 32;
     constexpr int PITCH = BN * 2 + 16;
     constexpr int CPR = BN / 8;                 // 16-byte chunks per row
@@ -275,7 +276,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
             const int m = m0 + row;
             if (m >= a.M) break;
             u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PITCH + chunk * 16);
-            const int64_t o = ((int64_t)m * a.Cd + n) * 2;
+            const int64_t o = ((int64_t)m * a.dpitch + goff + n) * 2;
             if (a.res) {
                 const u32x4 rr = *reinterpret_cast<const u32x4*>(a.res + o);
 #pragma unroll
@@ -306,8 +307,8 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
             float s2 = 0.f, q2 = 0.f;
 #pragma unroll
             for (int gi = 0; gi < GROUPS; ++gi) { s2 += scratch[gi * BN + tid]; q2 += scratch[256 + gi * BN + tid]; }
-            float* p = a.bn_partial + (int64_t)mt * 2 * a.Cd + n0 + tid;
-            p[0] = s2; p[a.Cd] = q2;
+            float* p = a.bn_partial + (int64_t)mt * 2 * a.dpitch + goff + n0 + tid;
+            p[0] = s2; p[a.dpitch] = q2;
         }
     }
 }
@@ -337,6 +338,10 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     const int mt = (j / a.ntiles) * 8 + xcd, nt = j % a.ntiles;
     if (mt >= a.mtiles) return;
     const int m0 = mt * BM, n0 = nt * BN;
+    // grouped convolution: blockIdx.y selects the channel group; a.Cs / a.Cd are per-group widths
+    const int grp = blockIdx.y;
+    const unsigned gsrc = (unsigned)(grp * a.Cs) * (unsigned)sizeof(T);          // byte offset inside a source pixel
+    const unsigned char* wgt_g = a.wgt + (int64_t)grp * a.Cd * a.ldw * (int64_t)sizeof(T);
 
     // ---- this lane's fixed role inside every 16-row DMA piece: row l>>2, source chunk (l&3)^f(l>>4)
     const int prow = lane >> 2;
@@ -354,7 +359,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     if constexpr (UTAP) {
         // most negative tap displacement, in pixels
         const int dmin = a.transposed ? ((a.pad - a.R + 1) * a.Ws + (a.pad - a.S + 1)) : (-a.pad * a.Ws - a.pad);
-        shiftP = dmin < 0 ? -dmin * a.Cs * (int)sizeof(T) : 0;
+        shiftP = dmin < 0 ? -dmin * a.spitch * (int)sizeof(T) : 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + 16 * (2 * wave + i) + prow;
@@ -363,7 +368,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
             const int n = mm / HW, rem = mm - n * HW;
             const int y = rem / a.Wd, x = rem - y * a.Wd;
             const int y0 = a.transposed ? y : (y << a.sshift), x0 = a.transposed ? x : (x << a.sshift);
-            vbase[i] = ((unsigned)(n * a.Hs * a.Ws + y0 * a.Ws + x0) * (unsigned)a.Cs + (unsigned)(chunk * PE)) * (unsigned)sizeof(T);
+            vbase[i] = ((unsigned)(n * a.Hs * a.Ws + y0 * a.Ws + x0) * (unsigned)a.spitch + (unsigned)(chunk * PE)) * (unsigned)sizeof(T) + gsrc;
             unsigned mask = 0;
             for (int rr = 0; rr < a.R; ++rr)
                 for (int ss = 0; ss < a.S; ++ss) {
@@ -406,11 +411,11 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     // marker 0x80000000 cannot wrap below it whatever soffset is (both operands are < 2 GiB).
     const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src) - shiftP, 0,
                                                           src_bytes + (unsigned)shiftP + 16u, 0x00020000);
-    const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wgt), 0, wgt_bytes, 0x00020000);
+    const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wgt_g), 0, wgt_bytes, 0x00020000);
     // wave-uniform K-step state of the uniform-tap path, kept incrementally: tap (ur, us), first channel uc,
     // tap bit index ut, source soffset usoff (bytes), weight soffset uwoff (bytes)
     int ur = 0, us = 0, uc = 0, ut = 0;
-    unsigned usoff = (unsigned)(dsign * (-a.pad * a.Ws - a.pad) * a.Cs * (int)sizeof(T) + shiftP), uwoff = 0;
+    unsigned usoff = (unsigned)(dsign * (-a.pad * a.Ws - a.pad) * a.spitch * (int)sizeof(T) + shiftP), uwoff = 0;
 
     auto issue = [&](auto stage_c) {
         constexpr int stage = decltype(stage_c)::value;
@@ -441,7 +446,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
                     ys = by[i] + r; xs = bx[i] + s;
                     ok = ok && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
                 }
-                const unsigned off = ok ? ((unsigned)(ib[i] + ys * a.Ws + xs) * (unsigned)a.Cs + (unsigned)c) * (unsigned)sizeof(T) : OOB;
+                const unsigned off = ok ? ((unsigned)(ib[i] + ys * a.Ws + xs) * (unsigned)a.spitch + (unsigned)c) * (unsigned)sizeof(T) + gsrc : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(A + (2 * wave + i) * 1024), 16, off, 0, 0, 0);
             }
 #pragma unroll
@@ -459,7 +464,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
             if (uc >= a.Cs) {
                 uc = 0; ++ut;
                 if (++us == a.S) { us = 0; ++ur; }
-                usoff = (unsigned)(dsign * ((ur - a.pad) * a.Ws + (us - a.pad)) * a.Cs * (int)sizeof(T) + shiftP);
+                usoff = (unsigned)(dsign * ((ur - a.pad) * a.Ws + (us - a.pad)) * a.spitch * (int)sizeof(T) + shiftP);
             }
         } else {
             e += KE;
@@ -530,11 +535,11 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     }
     if constexpr (sizeof(T) == 2 && !OUTF32) {
         if ((a.Cd & 7) == 0 && a.bias == nullptr) {     // wave-uniform
-            conv_epilogue_staged<BN>(a, acc, smem, m0, n0, mt, wm, wn, fr, fc);
+            conv_epilogue_staged<BN>(a, acc, smem, m0, n0, mt, wm, wn, fr, fc, grp * a.Cd);
             return;
         }
     }
-    conv_epilogue<T, BN, OUTF32>(a, acc, m0, n0, wm, wn, fr, fc);
+    conv_epilogue<T, BN, OUTF32>(a, acc, m0, n0, wm, wn, fr, fc, grp * a.Cd);
 }
 
 // two kernel names instead of a fourth template flag (hipcc/ROCm 7.2 fails to emit the host stub of a
@@ -560,7 +565,8 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
     static const bool force_v1 = getenv("IIF_CONV_REGSTAGE") != nullptr;
     // LDS-DMA addressing is a 32-bit byte offset with a hardware range check: both operands must be < 2 GiB
     const bool dma = !force_v1 && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL;
-    const dim3 grid((unsigned)blocks), blk(256);
+    if (a.groups > 1 && !dma) return IIF_EUNSUPPORTED;     // grouped convolutions exist on the pipelined kernels only
+    const dim3 grid((unsigned)blocks, (unsigned)a.groups), blk(256);
     if (dma) {
         const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
         static const bool no_fast = getenv("IIF_CONV_GENERAL_ADDR") != nullptr;
@@ -620,8 +626,8 @@ extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, c
         const int64_t groups = 1;                         // one partial row per 128-pixel tile
         const bool ok = d->dtype == IIF_BF16 && d->dst_dtype == IIF_BF16 && (d->cd % 8) == 0 && !bias && !res &&
                         getenv("IIF_CONV_REGSTAGE") == nullptr &&
-                        (int64_t)d->n * d->hs * d->ws * d->cs * esz0 < 0x7ffffff0LL &&
-                        bn_partial_floats >= mt * groups * 2 * d->cd;
+                        (int64_t)d->n * d->hs * d->ws * d->cs * (d->groups > 1 ? d->groups : 1) * esz0 < 0x7f000000LL &&
+                        bn_partial_floats >= mt * groups * 2 * d->cd * (d->groups > 1 ? d->groups : 1);
         if (!ok) return IIF_EUNSUPPORTED;
         a.bn_partial = bn_partial;
         if (n_partials) *n_partials = (int32_t)(mt * groups);
@@ -629,10 +635,13 @@ extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, c
     a.N = d->n; a.Hs = d->hs; a.Ws = d->ws; a.Cs = d->cs; a.Hd = d->hd; a.Wd = d->wd; a.Cd = d->cd;
     a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.transposed = d->transposed ? 1 : 0;
     a.ldw = d->ldw; a.M = (int)M; a.K = d->r * d->s * d->cs;
+    a.groups = d->groups > 1 ? d->groups : 1;
+    a.spitch = a.groups * d->cs; a.dpitch = a.groups * d->cd;
+    if (a.groups > 65535) return IIF_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
     const int64_t esz = d->dtype == IIF_F32 ? 4 : 2;
-    const int64_t src_bytes = (int64_t)d->n * d->hs * d->ws * d->cs * esz;
-    const int64_t wgt_bytes = (int64_t)d->cd * d->ldw * esz;
+    const int64_t src_bytes = (int64_t)d->n * d->hs * d->ws * a.spitch * esz;
+    const int64_t wgt_bytes = (int64_t)d->cd * d->ldw * esz;          // one group's weight matrix
     if (d->dtype == IIF_BF16) {
         if (d->dst_dtype == IIF_F32) return launch_conv<unsigned short, true>(a, src_bytes, wgt_bytes, st);
         return launch_conv<unsigned short, false>(a, src_bytes, wgt_bytes, st);

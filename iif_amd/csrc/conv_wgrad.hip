@@ -25,6 +25,7 @@ struct WgArgs {
     const unsigned char* x; const unsigned char* dy; float* out;
     int N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, sshift, pad, ldw, M, K;
     int ktiles, ntiles, steps_per_split, nsteps, nsplits;
+    int xpitch, ypitch, groups;   // channels per pixel of the x / dy TENSORS (= groups * Cs / Cd)
     int64_t slab;          // elements between split slabs (0 when writing dW directly)
 };
 
@@ -270,6 +271,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(WgArgs a, unsigned 
 
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x), 0, x_bytes, 0x00020000);
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.dy), 0, dy_bytes, 0x00020000);
+    const int grp = blockIdx.y;                              // channel group (grouped convolution)
+    const unsigned gx = (unsigned)(grp * a.Cs) * (unsigned)sizeof(T), gy = (unsigned)(grp * a.Cd) * (unsigned)sizeof(T);
 
     // ---- X pieces of this lane: instr i covers tile rows RPIX*(NIX*wave+i) .. +RPIX
     int xr[NIX], py[NIX], px[NIX], pb[NIX], pm[NIX], ttr[NIX], tts[NIX], tch[NIX];
@@ -306,13 +309,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(WgArgs a, unsigned 
         for (int i = 0; i < NIX; ++i) {
             const int ys = (py[i] << a.sshift) - a.pad + ttr[i], xs = (px[i] << a.sshift) - a.pad + tts[i];
             const bool ok = nval[i] && pm[i] < a.M && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
-            const unsigned off = ok ? ((unsigned)(pb[i] + ys * a.Ws + xs) * (unsigned)a.Cs + (unsigned)tch[i]) * (unsigned)sizeof(T) : OOB;
+            const unsigned off = ok ? ((unsigned)(pb[i] + ys * a.Ws + xs) * (unsigned)a.xpitch + (unsigned)tch[i]) * (unsigned)sizeof(T) + gx : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_w*)(X + (NIX * wave + i) * 1024), 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NIY; ++i) {
             const int m = step * ROWS + yr[i];
-            const unsigned off = (ycol[i] != OOB && m < a.M) ? (unsigned)m * (unsigned)a.Cd * (unsigned)sizeof(T) + ycol[i] : OOB;
+            const unsigned off = (ycol[i] != OOB && m < a.M) ? (unsigned)m * (unsigned)a.ypitch * (unsigned)sizeof(T) + ycol[i] + gy : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)(Y + (NIY * wave + i) * 1024), 16, off, 0, 0, 0);
         }
     };
@@ -387,7 +390,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(WgArgs a, unsigned 
         stage = stage == 2 ? 0 : stage + 1;
     }
 
-    float* out = a.out + (int64_t)split * a.slab;
+    float* out = a.out + (int64_t)split * a.slab + (int64_t)grp * a.Cd * a.ldw;
 #pragma unroll
     for (int kj = 0; kj < KJ; ++kj) {
         const int k = k0 + wk * (BC / 2) + kj * 16 + li;
@@ -434,12 +437,12 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
         // one full co-resident round: 256 CUs x (3 | 4) workgroups (LDS 48 | 36 KB each), so every
         // workgroup gets the same number of steps and there is no tail round
         const int slots = 256 * (bc == 64 ? 4 : 3);
-        splits = slots / tiles;
+        splits = slots / (tiles * a.groups);
         if (splits < 1) splits = 1;
         const int max_by_work = a.nsteps / 8 > 0 ? a.nsteps / 8 : 1;
         if (splits > max_by_work) splits = max_by_work;
     }
-    const int64_t slab = (int64_t)a.Cd * a.ldw;
+    const int64_t slab = (int64_t)a.groups * a.Cd * a.ldw;
     const int64_t fit = ws ? ws_bytes / (slab * 4) : 0;
     if (splits > fit) splits = (int)fit;
     if (splits < 1) splits = 1;
@@ -452,7 +455,9 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     a.out = splits > 1 ? ws : dw;
     a.nsplits = splits;
     const dim3 grid(tiles, splits);
-    const dim3 grid1d((unsigned)(tiles * ((splits + 7) / 8) * 8));
+    const dim3 grid1d((unsigned)(tiles * ((splits + 7) / 8) * 8), (unsigned)a.groups);
+    if (a.groups > 1 && !(x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL && getenv("IIF_CONV_REGSTAGE") == nullptr))
+        return IIF_EUNSUPPORTED;
     static const bool force_v1 = getenv("IIF_CONV_REGSTAGE") != nullptr;
     const bool dma = !force_v1 && x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL;
     if (dma) {
@@ -474,17 +479,17 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
             const int chunk = 16, nch = (splits + chunk - 1) / chunk;
             float* stage = ws + (int64_t)splits * slab;       // needs nch more slabs of workspace
             if ((int64_t)(splits + nch) * slab * 4 <= ws_bytes) {
-                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, nch), dim3(256), 0, st, ws, splits, chunk, slab, a.Cd,
-                                   a.ldw, a.K, stage, slab);
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, nch), dim3(256), 0, st, ws, splits, chunk, slab,
+                                   a.groups * a.Cd, a.ldw, a.K, stage, slab);
                 IIF_LAUNCH_CHECK();
-                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, stage, nch, nch, slab, a.Cd,
-                                   a.ldw, a.K, dw, (int64_t)0);
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, stage, nch, nch, slab,
+                                   a.groups * a.Cd, a.ldw, a.K, dw, (int64_t)0);
                 IIF_LAUNCH_CHECK();
                 return IIF_OK;
             }
         }
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, ws, splits, splits, slab, a.Cd, a.ldw,
-                           a.K, dw, (int64_t)0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, ws, splits, splits, slab,
+                           a.groups * a.Cd, a.ldw, a.K, dw, (int64_t)0);
         IIF_LAUNCH_CHECK();
     }
     return IIF_OK;
@@ -513,9 +518,12 @@ extern "C" int iif_conv_wgrad(const iif_conv_desc* d, const void* x, const void*
     a.N = d->n; a.Hs = d->hs; a.Ws = d->ws; a.Cs = d->cs; a.Hd = d->hd; a.Wd = d->wd; a.Cd = d->cd;
     a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.ldw = d->ldw; a.M = (int)M;
     a.K = d->r * d->s * d->cs;
+    a.groups = d->groups > 1 ? d->groups : 1;
+    a.xpitch = a.groups * d->cs; a.ypitch = a.groups * d->cd;
+    if (a.groups > 65535) return IIF_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
     const int64_t esz = d->dtype == IIF_F32 ? 4 : 2;
-    const int64_t x_bytes = (int64_t)d->n * d->hs * d->ws * d->cs * esz, dy_bytes = M * d->cd * esz;
+    const int64_t x_bytes = (int64_t)d->n * d->hs * d->ws * a.xpitch * esz, dy_bytes = M * a.ypitch * esz;
     if (d->dtype == IIF_BF16)
         return launch_wgrad<unsigned short>(a, dw, (float*)workspace, workspace_bytes, splits, x_bytes, dy_bytes, st);
     return launch_wgrad<float>(a, dw, (float*)workspace, workspace_bytes, splits, x_bytes, dy_bytes, st);

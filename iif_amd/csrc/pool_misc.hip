@@ -437,3 +437,66 @@ int iif_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- grouped-convolution weight packing
+// A grouped KxK convolution (ResNeXt, resnet_pytorch.py:137,141) runs on the MFMA kernels as a dense
+// convolution inside channel CHUNKS of `ch` (= 64) channels: chunk weights are block-diagonal over the
+// groups they contain.  master: fp32 [cout][ldm] rows of (tap, cin_local<cg);  packed: [cout][ldp] rows of
+// (tap, chunk-local input channel < ch).  transposed = rows are INPUT channels, columns (tap, chunk-local
+// output channel): the data-gradient operand.
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256) group_pack_kernel(const float* m, int C, int cg, int ch, int rs, int ldm, int ldp,
+                                                         int transposed, T* out) {
+    const int64_t total = (int64_t)C * ldp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int col = (int)(i % ldp), row = (int)(i / ldp);
+        float v = 0.f;
+        if (col < rs * ch) {
+            const int tap = col / ch, loc = col - tap * ch;
+            const int other = (row / ch) * ch + loc;          // the channel on the other side of the weight
+            if (other / cg == row / cg) {
+                const int k = transposed ? other : row, c = transposed ? row : other;
+                v = m[(int64_t)k * ldm + tap * cg + (c % cg)];
+            }
+        }
+        PT<T>::store1(out + i, v);
+    }
+}
+// dense-in-chunk weight gradient [cout][ldp] -> master layout [cout][ldm] (only the in-group entries exist)
+__global__ void __launch_bounds__(256) group_unpack_kernel(const float* p, int C, int cg, int ch, int rs, int ldp, int ldm,
+                                                           float* m) {
+    const int64_t total = (int64_t)C * rs * cg;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cl = (int)(i % cg);
+        const int tap = (int)((i / cg) % rs);
+        const int k = (int)(i / ((int64_t)cg * rs));
+        const int c = (k / cg) * cg + cl;                     // global input channel
+        m[(int64_t)k * ldm + tap * cg + cl] = p[(int64_t)k * ldp + tap * ch + (c % ch)];
+    }
+}
+}  // namespace
+
+extern "C" int iif_group_pack(const float* master, int channels, int cg, int chunk, int rs, int ldm, int ldp, int transposed,
+                              int out_dtype, void* out, void* stream) {
+    if (!master || !out || channels <= 0 || cg <= 0 || chunk <= 0 || rs <= 0) return IIF_EINVAL;
+    if (channels % chunk || chunk % cg || ldm < rs * cg || ldp < rs * chunk) return IIF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = (int64_t)channels * ldp;
+    IIF_BY_DTYPE(out_dtype,
+        hipLaunchKernelGGL(group_pack_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, master, channels, cg, chunk, rs, ldm, ldp, transposed, (float*)out),
+        hipLaunchKernelGGL(group_pack_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, master, channels, cg, chunk, rs, ldm, ldp, transposed, (unsigned short*)out))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+extern "C" int iif_group_unpack_grad(const float* packed, int channels, int cg, int chunk, int rs, int ldp, int ldm,
+                                     float* master, void* stream) {
+    if (!packed || !master || channels <= 0 || cg <= 0 || chunk <= 0 || rs <= 0) return IIF_EINVAL;
+    if (channels % chunk || chunk % cg || ldm < rs * cg || ldp < rs * chunk) return IIF_EINVAL;
+    const int64_t tot = (int64_t)channels * rs * cg;
+    hipLaunchKernelGGL(group_unpack_kernel, dim3(sblocks(tot)), dim3(256), 0, as_stream(stream), packed, channels, cg, chunk,
+                       rs, ldp, ldm, master);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}

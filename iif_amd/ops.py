@@ -9,16 +9,17 @@ from . import _lib
 from ._lib import ConvDesc, check, dtype_code, lib, ptr, require_gpu, stream_ptr
 
 
-def _desc(n, hs, ws, cs, hd, wd, cd, r, s, stride, pad, transposed, ldw, dtype, dst_dtype):
-    return ConvDesc(n, hs, ws, cs, hd, wd, cd, r, s, stride, pad, transposed, ldw, dtype, dst_dtype)
+def _desc(n, hs, ws, cs, hd, wd, cd, r, s, stride, pad, transposed, ldw, dtype, dst_dtype, groups=1):
+    return ConvDesc(n, hs, ws, cs, hd, wd, cd, r, s, stride, pad, transposed, ldw, dtype, dst_dtype, groups)
 
 
 def conv_out_hw(h, w, r, s, stride, pad):
     return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
 
 
-def conv_forward(x, w, r, s, stride, pad, out=None, out_dtype=None, bias=None, res=None):
-    """x: [N,H,W,Cin] NHWC; w: [Cout, ldw] (rows = r*s*Cin K-contiguous, KRSC)."""
+def conv_forward(x, w, r, s, stride, pad, out=None, out_dtype=None, bias=None, res=None, groups=1):
+    """x: [N,H,W,Cin] NHWC; w: [Cout, ldw] (rows = r*s*Cin K-contiguous, KRSC).  groups > 1: the
+    channels split into `groups` chunks, w holds the chunk matrices one after the other."""
     require_gpu(x, w, bias, res)
     n, h, wd_, cin = x.shape
     cout, ldw = w.shape
@@ -26,17 +27,19 @@ def conv_forward(x, w, r, s, stride, pad, out=None, out_dtype=None, bias=None, r
     odt = out_dtype or x.dtype
     if out is None:
         out = torch.empty((n, ho, wo, cout), dtype=odt, device=x.device)
-    d = _desc(n, h, wd_, cin, ho, wo, cout, r, s, stride, pad, 0, ldw, dtype_code(x), dtype_code(out))
+    d = _desc(n, h, wd_, cin // groups, ho, wo, cout // groups, r, s, stride, pad, 0, ldw, dtype_code(x), dtype_code(out),
+              groups)
     check(lib().iif_conv_igemm(ctypes.byref(d), ptr(x), ptr(w), ptr(out), ptr(res), ptr(bias), stream_ptr()), "iif_conv_igemm")
     return out
 
 
-def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial):
+def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial, groups=1):
     """conv_forward (bf16) that also writes per-tile BN partial sums; returns the tile count."""
     n, h, wd_, cin = x.shape
     cout, ldw = w.shape
     ho, wo = conv_out_hw(h, wd_, r, s, stride, pad)
-    d = _desc(n, h, wd_, cin, ho, wo, cout, r, s, stride, pad, 0, ldw, dtype_code(x), dtype_code(out))
+    d = _desc(n, h, wd_, cin // groups, ho, wo, cout // groups, r, s, stride, pad, 0, ldw, dtype_code(x), dtype_code(out),
+              groups)
     nt = ctypes.c_int32(0)
     check(lib().iif_conv_igemm_bnstats(ctypes.byref(d), ptr(x), ptr(w), ptr(out), 0, 0, ptr(partial), partial.numel(),
                                        ctypes.byref(nt), stream_ptr()), "iif_conv_igemm_bnstats")
@@ -52,7 +55,7 @@ def bn_finalize_stats(partial, n_partials, m, c, gamma, beta, running_mean, runn
     return stats
 
 
-def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, out=None, res=None):
+def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, out=None, res=None, groups=1):
     """dy: [N,Ho,Wo,Cout]; wt: [Cin, ldw] rows of r*s*Cout (the CRSK transpose);
     returns dx [N,H,W,Cin] (+ res)."""
     require_gpu(dy, wt, res)
@@ -61,21 +64,22 @@ def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, out=None, res=None):
     h, w_ = in_hw
     if out is None:
         out = torch.empty((n, h, w_, cin), dtype=dy.dtype, device=dy.device)
-    d = _desc(n, ho, wo, cout, h, w_, cin, r, s, stride, pad, 1, ldw, dtype_code(dy), dtype_code(out))
+    d = _desc(n, ho, wo, cout // groups, h, w_, cin // groups, r, s, stride, pad, 1, ldw, dtype_code(dy), dtype_code(out),
+              groups)
     check(lib().iif_conv_igemm(ctypes.byref(d), ptr(dy), ptr(wt), ptr(out), ptr(res), 0, stream_ptr()), "iif_conv_igemm(dgrad)")
     return out
 
 
-def conv_wgrad(x, dy, r, s, stride, pad, ldw=None, out=None, workspace=None, splits=0):
+def conv_wgrad(x, dy, r, s, stride, pad, ldw=None, out=None, workspace=None, splits=0, groups=1):
     """x: [N,H,W,Cin], dy: [N,Ho,Wo,Cout] -> dw float32 [Cout, ldw] (KRSC rows)."""
     require_gpu(x, dy, out, workspace)
     n, h, w_, cin = x.shape
     _, ho, wo, cout = dy.shape
-    k = r * s * cin
+    k = r * s * (cin // groups)
     ldw = ldw or k
     if out is None:
         out = torch.zeros((cout, ldw), dtype=torch.float32, device=x.device)
-    d = _desc(n, h, w_, cin, ho, wo, cout, r, s, stride, pad, 0, ldw, dtype_code(x), _lib.IIF_F32)
+    d = _desc(n, h, w_, cin // groups, ho, wo, cout // groups, r, s, stride, pad, 0, ldw, dtype_code(x), _lib.IIF_F32, groups)
     wsb = 0 if workspace is None else workspace.numel() * workspace.element_size()
     check(lib().iif_conv_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), ptr(workspace), wsb, splits, stream_ptr()),
           "iif_conv_wgrad")
@@ -223,3 +227,16 @@ def dot_window_f32(a, b, rows, cols, alpha, out, alpha_div=None):
     check(lib().iif_dot_window_f32(ptr(a), ptr(b), rows, cols, a.stride(0), b.stride(0), float(alpha), ptr(alpha_div),
                                    ptr(out), stream_ptr()), "iif_dot_window_f32")
     return out
+
+
+# ------------------------------------------------------------ grouped convs
+def group_pack(master, channels, cg, chunk, rs, out, transposed=False):
+    check(lib().iif_group_pack(ptr(master), channels, cg, chunk, rs, master.shape[1], out.shape[1], 1 if transposed else 0,
+                               dtype_code(out), ptr(out), stream_ptr()), "iif_group_pack")
+    return out
+
+
+def group_unpack_grad(packed, channels, cg, chunk, rs, master_grad):
+    check(lib().iif_group_unpack_grad(ptr(packed), channels, cg, chunk, rs, packed.shape[1], master_grad.shape[1],
+                                      ptr(master_grad), stream_ptr()), "iif_group_unpack_grad")
+    return master_grad

@@ -42,12 +42,17 @@ def _round_up(v, m):
 class ConvParam(nn.Module):
     """Holds one convolution's weight (reference name ``<prefix>.weight``)."""
 
-    def __init__(self, cin, cout, k, stride, pad):
+    def __init__(self, cin, cout, k, stride, pad, groups=1):
         super().__init__()
-        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
-        self.kdim = k * k * cin                   # GEMM K of the forward contraction
+        self.cin, self.cout, self.k, self.stride, self.pad, self.groups = cin, cout, k, stride, pad, groups
+        self.cg = cin // groups                   # input channels per group
+        self.kdim = k * k * self.cg               # GEMM K of one output channel's row
         self.ldw = _round_up(self.kdim, 16)       # row pitch of the stored [cout][ldw] matrix
-        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        if groups > 1:
+            assert cin == cout and cin % groups == 0, "grouped convolutions are width -> width (ResNeXt)"
+            self.chunk = max(64, self.cg)         # channels per dense chunk on the MFMA path
+            assert cin % self.chunk == 0 and self.chunk % self.cg == 0
+        self.weight = nn.Parameter(torch.empty(cout, self.cg, k, k))
 
     def forward(self, *a, **k):
         raise RuntimeError("ConvParam is a parameter holder; NativeResNet.forward runs the network")
@@ -104,13 +109,13 @@ class NormedLinearParam(nn.Module):
 class BlockParam(nn.Module):
     """conv/bn pairs of one residual block, registered in the reference's order."""
 
-    def __init__(self, kind, inplanes, planes, stride, width, out_planes, downsample, shortcut_a=False):
+    def __init__(self, kind, inplanes, planes, stride, width, out_planes, downsample, shortcut_a=False, groups=1):
         super().__init__()
         self.kind, self.stride, self.shortcut_a = kind, stride, shortcut_a
         self.inplanes, self.out_planes = inplanes, out_planes
         if kind == "bottleneck":
             self.conv1 = ConvParam(inplanes, width, 1, 1, 0); self.bn1 = BNParam(width)
-            self.conv2 = ConvParam(width, width, 3, stride, 1); self.bn2 = BNParam(width)
+            self.conv2 = ConvParam(width, width, 3, stride, 1, groups); self.bn2 = BNParam(width)
             self.conv3 = ConvParam(width, out_planes, 1, 1, 0); self.bn3 = BNParam(out_planes)
         else:
             self.conv1 = ConvParam(inplanes, planes, 3, stride, 1); self.bn1 = BNParam(planes)
@@ -133,8 +138,6 @@ class NativeResNet(nn.Module):
     def __init__(self, style, block, layers, num_classes, groups=1, width_per_group=64, device="cuda",
                  compute_dtype=torch.bfloat16, zero_init_residual=False, use_norm=None):
         super().__init__()
-        if groups != 1:
-            raise NotImplementedError("grouped 3x3 convolutions (ResNeXt) are not built yet (SURVEY §8 a10)")
         assert compute_dtype in (torch.bfloat16, torch.float32)
         self.style, self.block_kind = style, block
         self.compute_dtype = compute_dtype
@@ -152,7 +155,8 @@ class NativeResNet(nn.Module):
                     stride = 2 if (b == 0 and li > 0) else 1
                     width = int(planes * (width_per_group / 64.0)) * groups
                     ds = b == 0 and (stride != 1 or inpl != planes * exp)
-                    blocks.append(BlockParam(block, inpl, planes, stride, width, planes * exp, ds))
+                    blocks.append(BlockParam(block, inpl, planes, stride, width, planes * exp, ds,
+                                             groups=groups if block == "bottleneck" else 1))
                     inpl = planes * exp
                 stages.append(nn.Sequential(*blocks))
             self.layer1, self.layer2, self.layer3, self.layer4 = stages
@@ -200,7 +204,7 @@ class NativeResNet(nn.Module):
                 if self.style == "imagenet":      # resnet_pytorch.py:221-223 kaiming_normal_(fan_out, relu)
                     std = math.sqrt(2.0 / (m.cout * m.k * m.k))
                 else:                             # resnet_cifar.py:33-36 kaiming_normal_ (fan_in)
-                    std = math.sqrt(2.0 / (m.cin * m.k * m.k))
+                    std = math.sqrt(2.0 / (m.cg * m.k * m.k))
                 nn.init.normal_(m.weight, 0.0, std)
             elif isinstance(m, CosNormParam):     # resnet_cifar.py:63-65 uniform(+-1/sqrt(in))
                 bound = 1.0 / math.sqrt(m.in_features)
@@ -257,7 +261,7 @@ class NativeResNet(nn.Module):
                 flat = arena[o:o + rows * pitch].view(rows, pitch)
                 old = getattr(m, attr)
                 if isinstance(m, ConvParam):
-                    view = flat[:, :m.kdim].view(m.cout, m.k, m.k, m.cin).permute(0, 3, 1, 2)
+                    view = flat[:, :m.kdim].view(m.cout, m.k, m.k, m.cg).permute(0, 3, 1, 2)
                     m._w2d = flat
                 elif isinstance(m, LinearParam):
                     if attr == "weight":
@@ -311,7 +315,7 @@ class NativeResNet(nn.Module):
         for (m, attr, rows, pitch), o2 in zip(specs, offs):
             gflat = self._grad_arena[o2:o2 + rows * pitch].view(rows, pitch)
             if isinstance(m, ConvParam):
-                gv = gflat[:, :m.kdim].view(m.cout, m.k, m.k, m.cin).permute(0, 3, 1, 2)
+                gv = gflat[:, :m.kdim].view(m.cout, m.k, m.k, m.cg).permute(0, 3, 1, 2)
                 m._g2d = gflat
             elif isinstance(m, LinearParam):
                 if attr == "weight":
@@ -462,7 +466,8 @@ class _NetFunction(torch.autograd.Function):
 # ------------------------------------------------------------------- the plan
 class _ConvUnit(object):
     """Buffers of one conv+BN unit inside a plan."""
-    __slots__ = ("conv", "bn", "src", "x", "stats", "y", "w", "wt", "n", "hi", "wi", "ho", "wo", "is_patch_gemm")
+    __slots__ = ("conv", "bn", "src", "x", "stats", "y", "w", "wt", "n", "hi", "wi", "ho", "wo", "is_patch_gemm",
+                 "groups", "dwp")
 
 
 class _Plan(object):
@@ -547,7 +552,8 @@ class _Plan(object):
         self.bn_partial = torch.empty(max(((u.n * u.ho * u.wo + 127) // 128) * 2 * u.conv.cout for u in self.units),
                                       dtype=torch.float32, device=dev)
         self.bn_scratch = torch.empty(128 * cmax, dtype=torch.float32, device=dev)
-        wmax = max(max(u.conv.cout * u.conv.ldw for u in self.units), head.out_padded * head.in_features)
+        wmax = max(max(u.conv.cout * (u.dwp.shape[1] if u.dwp is not None else u.conv.ldw) for u in self.units),
+                   head.out_padded * head.in_features)
         self.wg_ws = torch.empty(min(16 * wmax * 4, 512 << 20), dtype=torch.uint8, device=dev)
         self._grad_pool = {}
         self._bwd_ready = False
@@ -562,21 +568,34 @@ class _Plan(object):
         u.x = torch.empty((n, ho, wo, conv.cout), dtype=dt, device=dev)
         u.y = torch.empty((n, ho, wo, conv.cout), dtype=dt, device=dev) if need_y else None
         u.stats = torch.empty((4, conv.cout), dtype=torch.float32, device=dev)
-        u.w = conv._w2d if dt == torch.float32 else torch.empty((conv.cout, conv.ldw), dtype=dt, device=dev)
-        if patch:
-            u.wt = None
+        u.groups, u.dwp = 1, None
+        if conv.groups > 1:
+            # grouped conv: dense inside chunks of conv.chunk channels, block-diagonal packed weights
+            ldp = conv.k * conv.k * conv.chunk
+            u.groups = conv.cin // conv.chunk
+            u.w = torch.empty((conv.cout, ldp), dtype=dt, device=dev)
+            u.wt = torch.empty((conv.cin, ldp), dtype=dt, device=dev)
+            u.dwp = torch.empty((conv.cout, ldp), dtype=torch.float32, device=dev)
         else:
-            u.wt = torch.zeros((conv.cin, _round_up(conv.k * conv.k * conv.cout, 16)), dtype=dt, device=dev)
+            u.w = conv._w2d if dt == torch.float32 else torch.empty((conv.cout, conv.ldw), dtype=dt, device=dev)
+            u.wt = None if patch else torch.zeros((conv.cin, _round_up(conv.k * conv.k * conv.cout, 16)), dtype=dt,
+                                                  device=dev)
         self.units.append(u)
         return u
 
     # ---------------------------------------------------------------- weights
     def prepare_weights(self, need_transposed):
         for u in self.units:
+            cv = u.conv
+            if cv.groups > 1:
+                ops.group_pack(cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.w)
+                if need_transposed:
+                    ops.group_pack(cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.wt, transposed=True)
+                continue
             if self.dt != torch.float32:
-                ops.cast(u.conv._w2d, u.w)
+                ops.cast(cv._w2d, u.w)
             if need_transposed and u.wt is not None:
-                ops.weight_transpose(u.conv._w2d, u.conv.cout, u.conv.cin, u.conv.k * u.conv.k, u.wt)
+                ops.weight_transpose(cv._w2d, cv.cout, cv.cin, cv.k * cv.k, u.wt)
         head = self.net._head
         if self.head_kind == "cosine":           # ew = W / |W_row|   (resnet_cifar.py:73)
             ops.rowmap_forward(head._w2d, 1, 1.0, self.head_wsrc, self.head_wnorm, eps=0.0)
@@ -596,11 +615,11 @@ class _Plan(object):
         x2 = u.x.view(m, cv.cout)
         if training and self.dt == torch.bfloat16 and cv.cout % 8 == 0:
             # statistics come out of the convolution's epilogue: no extra pass over x
-            nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, self.bn_partial)
+            nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, self.bn_partial, groups=u.groups)
             ops.bn_finalize_stats(self.bn_partial, nt, m, cv.cout, u.bn.weight, u.bn.bias, u.bn.running_mean,
                                   u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM, scratch=self.bn_scratch)
             return x2
-        ops.conv_forward(u.src, u.w, k, k, st, pd, out=u.x)
+        ops.conv_forward(u.src, u.w, k, k, st, pd, out=u.x, groups=u.groups)
         if training:
             ops.bn_forward_stats(x2, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var, u.stats, self.bn_ws,
                                  BN_EPS, BN_MOMENTUM)
@@ -689,10 +708,16 @@ class _Plan(object):
         if u.is_patch_gemm:
             ops.conv_wgrad(u.src, dx4, 1, 1, 1, 0, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws)
             return None
-        ops.conv_wgrad(u.src, dx4, cv.k, cv.k, cv.stride, cv.pad, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws)
+        if u.groups > 1:
+            ops.conv_wgrad(u.src, dx4, cv.k, cv.k, cv.stride, cv.pad, ldw=u.dwp.shape[1], out=u.dwp, workspace=self.wg_ws,
+                           groups=u.groups)
+            ops.group_unpack_grad(u.dwp, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, cv._g2d)
+        else:
+            ops.conv_wgrad(u.src, dx4, cv.k, cv.k, cv.stride, cv.pad, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws)
         if not need_dgrad:
             return None
-        return ops.conv_dgrad(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), out=dgrad_out, res=dgrad_res)
+        return ops.conv_dgrad(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), out=dgrad_out, res=dgrad_res,
+                              groups=u.groups)
 
     def backward(self, reducer=None):
         net = self.net

@@ -123,6 +123,10 @@ typedef struct iif_conv_desc {
     int32_t ldw;             /* weight row pitch in elements (>= r*s*cs, 16-B mult) */
     int32_t dtype;           /* IIF_F32 / IIF_BF16 of src and wgt                  */
     int32_t dst_dtype;       /* dtype of dst / res: == dtype, or IIF_F32           */
+    int32_t groups;          /* 0/1: dense.  G > 1: cs / cd are PER-GROUP widths, the   */
+                             /* tensors hold G*cs / G*cd channels per pixel, wgt is G   */
+                             /* consecutive [cd][ldw] matrices (grouped convolution,    */
+                             /* resnet_pytorch.py:137,141 ResNeXt)                      */
 } iif_conv_desc;
 
 /* Implicit-GEMM convolution on the matrix cores:
@@ -264,6 +268,18 @@ int iif_transpose_f32(const float* in, int rows, int cols, int64_t ldi, float* o
  * (gradient of the learnable cosine scale). */
 int iif_dot_window_f32(const float* a, const float* b, int rows, int cols, int64_t lda, int64_t ldb,
                        float alpha, const float* d_alpha_div, float* out, void* stream);
+
+/* Grouped convolution (ResNeXt, resnet_pytorch.py:137,141) on the MFMA kernels: channels are
+ * cut into chunks of `chunk` (64) and each chunk runs as a dense convolution whose weights are
+ * block-diagonal over the groups inside it (iif_conv_desc.groups = channels/chunk, cs = cd = chunk).
+ * iif_group_pack: fp32 master weights [channels][ldm] (rows of (tap, cin_local < cg)) -> packed
+ * [channels][ldp] rows of (tap, chunk-local channel); transposed=1 gives the data-gradient operand
+ * (rows = input channels, columns = (tap, chunk-local output channel)).
+ * iif_group_unpack_grad: dense-in-chunk weight gradient -> master layout (in-group entries). */
+int iif_group_pack(const float* master, int channels, int cg, int chunk, int rs, int ldm, int ldp,
+                   int transposed, int out_dtype, void* out, void* stream);
+int iif_group_unpack_grad(const float* packed, int channels, int cg, int chunk, int rs, int ldp,
+                          int ldm, float* master, void* stream);
 
 #ifdef __cplusplus
 }

@@ -173,3 +173,55 @@ def test_conv_fused_bn_statistics(case):
     ops.bn_forward_stats(out.view(m, cout), gamma, beta, rm2, rv2, s_ref, ops.bn_workspace(m, cout, DEV))
     for a_, b_ in ((s_fused, s_ref), (rm1, rm2), (rv1, rv2)):
         assert (a_ - b_).abs().max().item() <= 1e-5 * max(1.0, b_.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(2, 128, 14, 14, 32, 1), (2, 256, 15, 13, 32, 2), (1, 512, 7, 7, 32, 1), (2, 64, 9, 9, 8, 1),
+                                  (2, 512, 8, 8, 8, 1)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_grouped_conv3x3(case, dt):
+    """ResNeXt-style grouped 3x3 (width -> width, `groups` groups): forward, data gradient and weight
+    gradient through the chunk-64 block-diagonal MFMA path against torch's grouped conv2d."""
+    from iif_amd import ops
+    n, width, h, w, groups, stride = case
+    cg = width // groups
+    ch = max(64, cg)
+    g = torch.Generator().manual_seed(width + groups)
+    x = torch.randn(n, width, h, w, generator=g).to(dt).float()
+    wt = (torch.randn(width, cg, 3, 3, generator=g) / (9 * cg) ** 0.5).to(dt).float()
+    ref = F.conv2d(x, wt, None, stride, 1, 1, groups)
+    ldm = (9 * cg + 15) // 16 * 16
+    master = torch.zeros(width, ldm)
+    master[:, :9 * cg] = wt.permute(0, 2, 3, 1).reshape(width, 9 * cg)
+    ldp = 9 * ch
+    wp = torch.empty(width, ldp, dtype=dt, device=DEV)
+    wpt = torch.empty(width, ldp, dtype=dt, device=DEV)
+    ops.group_pack(master.to(DEV), width, cg, ch, 9, wp)
+    ops.group_pack(master.to(DEV), width, cg, ch, 9, wpt, transposed=True)
+    G = width // ch
+    tol = 2e-5 if dt == torch.float32 else 2.0 ** -7
+    xd = nhwc(x).to(dt).to(DEV)
+    y = ops.conv_forward(xd, wp, 3, 3, stride, 1, groups=G)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= tol * ref.abs().max().item()
+    if dt == torch.bfloat16:      # fused statistics on the grouped path
+        m = y.shape[0] * y.shape[1] * y.shape[2]
+        partial = torch.empty(((m + 127) // 128) * 2 * width, device=DEV)
+        y2 = torch.empty_like(y)
+        nt = ops.conv_forward_bnstats(xd, wp, 3, 3, stride, 1, y2, partial, groups=G)
+        assert torch.equal(y2, y)
+        s = partial[:nt * 2 * width].view(nt, 2, width).sum(0)
+        yf = y.float().view(m, width)
+        assert (s[0] - yf.sum(0)).abs().max().item() <= 1e-3 * max(1.0, yf.sum(0).abs().max().item())
+        assert (s[1] - (yf * yf).sum(0)).abs().max().item() <= 1e-3 * (yf * yf).sum(0).abs().max().item()
+    dy = torch.randn(ref.shape, generator=g).to(dt).float()
+    dyd = nhwc(dy).to(dt).to(DEV)
+    refdx = torch.nn.grad.conv2d_input(x.shape, wt, dy, stride, 1, 1, groups)
+    dx = ops.conv_dgrad(dyd, wpt, 3, 3, stride, 1, (h, w), groups=G)
+    assert (dx.float().cpu().permute(0, 3, 1, 2) - refdx).abs().max().item() <= tol * refdx.abs().max().item()
+    refdw = torch.nn.grad.conv2d_weight(x, wt.shape, dy, stride, 1, 1, groups).permute(0, 2, 3, 1).reshape(width, 9 * cg)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    dwp = ops.conv_wgrad(xd, dyd, 3, 3, stride, 1, ldw=ldp, workspace=ws, groups=G)
+    dwm = torch.zeros(width, ldm, device=DEV)
+    ops.group_unpack_grad(dwp, width, cg, ch, 9, dwm)
+    wtol = 2e-5 if dt == torch.float32 else 1e-4
+    assert (dwm[:, :9 * cg].cpu() - refdw).abs().max().item() <= wtol * refdw.abs().max().item()

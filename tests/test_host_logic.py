@@ -79,9 +79,13 @@ def test_cli_flags_cover_the_reference_surface():
     assert not [f for f in ref_flags if f not in have]
 
 
-def test_unbuilt_rows_fail_loudly():
+def test_model_zoo_parameter_counts():
+    """Constructors of the reference's zoo (resnet_pytorch.py:421-551) build with the reference's
+    parameter counts (25 557 032 / 470 004 / 42 876 589 @365)."""
     from iif_amd import resnet_pytorch, resnet_cifar
-    with pytest.raises(NotImplementedError):
-        resnet_pytorch.resnext50_32x4d(num_classes=10, device="cpu")
-    with pytest.raises(NotImplementedError):
-        resnet_cifar.resnet32(num_classes=10, use_norm="cosine", device="cpu")
+    count = lambda m: sum(p.numel() for p in m.parameters())   # noqa: E731
+    assert count(resnet_pytorch.resnet50(num_classes=1000, device="cpu")) == 25557032
+    assert count(resnet_cifar.resnet32(num_classes=100, device="cpu")) == 470004
+    assert count(resnet_pytorch.resnext101_32x4d(num_classes=365, device="cpu")) == 42876589
+    m = resnet_cifar.resnet32(num_classes=10, use_norm="lr_cosine", device="cpu")
+    assert m.linear.scale.item() == 5.0
