@@ -59,26 +59,27 @@ class ConvTimer(object):
         timer = self
         orig = {k: getattr(ops, k) for k in ("conv_forward", "conv_dgrad", "conv_wgrad", "conv_forward_bnstats")}
 
-        def flops_fwd(x, w, r, s, stride, pad, **kw):
+        def flops_fwd(x, w, r, s, stride, pad, groups=1, **kw):
+            # algorithmic FLOPs: a chunked grouped conv is charged for its in-chunk MACs only
             n, h, wd, cin = x.shape
             ho, wo = ops.conv_out_hw(h, wd, r, s, stride, pad)
-            return 2.0 * n * ho * wo * w.shape[0] * r * s * cin
+            return 2.0 * n * ho * wo * w.shape[0] * r * s * cin / groups
 
         def conv_forward(x, w, r, s, stride, pad, **kw):
-            return timer._timed("fwd", flops_fwd(x, w, r, s, stride, pad), orig["conv_forward"], x, w, r, s, stride, pad, **kw)
+            return timer._timed("fwd", flops_fwd(x, w, r, s, stride, pad, **kw), orig["conv_forward"], x, w, r, s, stride, pad, **kw)
 
         def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, **kw):
             n, ho, wo, cout = dy.shape
-            fl = 2.0 * n * ho * wo * cout * r * s * wt.shape[0]
+            fl = 2.0 * n * ho * wo * cout * r * s * wt.shape[0] / kw.get("groups", 1)
             return timer._timed("dgrad", fl, orig["conv_dgrad"], dy, wt, r, s, stride, pad, in_hw, **kw)
 
         def conv_wgrad(x, dy, r, s, stride, pad, **kw):
             n, ho, wo, cout = dy.shape
-            fl = 2.0 * n * ho * wo * cout * r * s * x.shape[3]
+            fl = 2.0 * n * ho * wo * cout * r * s * x.shape[3] / kw.get("groups", 1)
             return timer._timed("wgrad", fl, orig["conv_wgrad"], x, dy, r, s, stride, pad, **kw)
 
-        def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial):
-            return timer._timed("fwd", flops_fwd(x, w, r, s, stride, pad), orig["conv_forward_bnstats"], x, w, r, s, stride, pad, out, partial)
+        def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial, **kw):
+            return timer._timed("fwd", flops_fwd(x, w, r, s, stride, pad, **kw), orig["conv_forward_bnstats"], x, w, r, s, stride, pad, out, partial, **kw)
 
         ops.conv_forward, ops.conv_dgrad, ops.conv_wgrad = conv_forward, conv_dgrad, conv_wgrad
         ops.conv_forward_bnstats = conv_forward_bnstats
@@ -152,6 +153,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--image", type=int, default=224)
+    ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -178,8 +180,8 @@ def main():
     from iif_amd.custom import IIFLoss
     from iif_amd.ddp import broadcast_parameters
 
-    C = 1000
-    counts = lt_counts(C, 1280)                      # ImageNet-LT-shaped profile
+    C = args.classes
+    counts = lt_counts(C, 1280 if C == 1000 else 4980)   # ImageNet-LT / Places-LT shaped profiles
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
     net = getattr(resnet_pytorch, args.model)(num_classes=C, use_norm="None", pretrained="None", device=dev,
@@ -253,8 +255,8 @@ def main():
             "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if cdt == torch.bfloat16 else "f32", "data": "synthetic",
-            "config": {"workload": "%s + IIF(raw) training step, synthetic ImageNet-LT %dx%d, C=1000 (counts 1280..5), "
-                                   "bs=%d/GPU, SGD momentum 0.9 wd 1e-4 with warm-up, random init" % (args.model, args.image, args.image, B),
+            "config": {"workload": "%s + IIF(raw) training step, synthetic long-tailed %dx%d, C=%d (counts %d..5), "
+                                   "bs=%d/GPU, SGD momentum 0.9 wd 1e-4 with warm-up, random init" % (args.model, args.image, args.image, C, counts[0], B),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4)},
         }
         if timer is not None and args.per_shape:

@@ -69,6 +69,19 @@ class ArenaReducer(object):
                 w.wait()
         self._works = []
 
+    def finish_tail(self, offset):
+        """Frozen-backbone step: only arena[offset:] carries gradients; reduce exactly that slice."""
+        if self.world == 1 and not self.force:
+            return
+        self._launch((int(offset), self.arena.numel()))
+        self._next = len(self.buckets)
+        if self.use_streams:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        else:
+            for w in self._works:
+                w.wait()
+        self._works = []
+
     # ---- internals ------------------------------------------------------------
     def _launch(self, bucket):
         lo, hi = bucket

@@ -144,6 +144,7 @@ class NativeResNet(nn.Module):
         self.num_classes = num_classes
         self._plans = {}
         self._saved = None
+        self._head_only = False
         if style == "imagenet":
             self.conv1 = ConvParam(3, 64, 7, 2, 3); self.bn1 = BNParam(64)
             exp = 4 if block == "bottleneck" else 1
@@ -397,8 +398,29 @@ class NativeResNet(nn.Module):
 
     # -------------------------------------------------- fused training step
     def sgd_step(self, lr, momentum=0.9, weight_decay=1e-4, nesterov=False, grad_scale=1.0):
-        """ONE launch over the whole parameter arena (classification/train.py:199-204,78)."""
-        ops.sgd_step(self._arena, self._grad_arena, self._mom_arena, lr, momentum, weight_decay, nesterov, grad_scale)
+        """ONE launch over the whole parameter arena (classification/train.py:199-204,78); with a
+        frozen backbone only the classifier's slice (the tail of the arena) is stepped, as
+        torch.optim.SGD skips parameters without gradients."""
+        lo = self.block_offsets()["head"] if self._head_only else 0
+        ops.sgd_step(self._arena[lo:], self._grad_arena[lo:], self._mom_arena[lo:], lr, momentum, weight_decay, nesterov,
+                     grad_scale)
+
+    def select_training_param(self):
+        """Decoupled classifier stage (classification/train.py:123-145): freeze everything, re-initialise
+        the classifier (xavier-uniform weight, bias 0.01) and train only it.  BN layers keep running in
+        training mode, exactly as in the reference (it never switches the backbone to eval)."""
+        for p in self.parameters():
+            p.requires_grad = False
+        head = self._head
+        with torch.no_grad():
+            nn.init.xavier_uniform_(head.weight)
+            if isinstance(head, LinearParam):
+                head.bias.fill_(0.01)
+        head.weight.requires_grad = True
+        if getattr(head, "bias", None) is not None and isinstance(head, LinearParam):
+            head.bias.requires_grad = True
+        self._head_only = True
+        return self
 
     def make_reducer(self, bucket_bytes=32 << 20, process_group=None):
         """Bucketed, backward-overlapped all-reduce of the gradient arena (see iif_amd.ddp)."""
@@ -761,6 +783,10 @@ class _Plan(object):
             else:
                 ops.rowmap_backward(self.pooled, self.head_xnorm, self.head_dex, 0, float(head.scale), dp2)
         fh, fw, fc = self.final.shape[1], self.final.shape[2], self.final.shape[3]
+        if net._head_only:              # frozen backbone: the classifier's gradients are all that is needed
+            if reducer is not None:
+                reducer.finish_tail(offs["head"])
+            return
         g = self._gbuf(("g", self.final.shape), self.final.shape)
         ops.avgpool_backward(dpooled.view(n, D), fh * fw, out=g.view(n, fh * fw, fc))
         if reducer is not None:

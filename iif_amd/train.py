@@ -121,7 +121,7 @@ def main(args):
     if args.opt.lower() not in ("sgd", "nesterov"):
         raise RuntimeError("Invalid optimizer {}. Only SGD and RMSprop are supported.".format(args.opt))
     if args.decoup:
-        raise NotImplementedError("--decoup (classifier-only stage) is SURVEY §8(f) rank 2, not built yet")
+        model.select_training_param()       # train.py:123-145: classifier-only stage
     reducer = None
     if args.distributed:
         broadcast_parameters(model)

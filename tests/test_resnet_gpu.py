@@ -267,3 +267,38 @@ def test_bf16_cosine_head_runs():
     net.sgd_step(0.01, 0.9, 1e-4)
     l1, lg = net.loss_and_backward(x.to(DEV), y.to(DEV), crit)
     assert torch.isfinite(l0).item() and torch.isfinite(l1).item() and lg.abs().max().item() <= 16.0 + 1e-2
+
+
+def test_decoupled_classifier_stage():
+    """--decoup (classification/train.py:123-145): only the classifier trains; the backbone's weights and
+    momentum stay untouched, BN keeps using batch statistics, the loss sequence follows the oracle."""
+    from iif_amd import resnet_cifar
+    from iif_amd.custom import IIFLoss
+    arch, C, B = "resnet20", 10, 8
+    counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
+    net, sd = _build(arch, C, torch.float32)
+    net.select_training_param()
+    assert [k for k, p in net.named_parameters() if p.requires_grad] == ["linear.weight", "linear.bias"]
+    assert (net.linear.bias == 0.01).all()
+    ref = {k: v.clone() for k, v in net.state_dict().items()}
+    ref = {k: v.cpu() for k, v in ref.items()}
+    frozen_before = net.param_arena[:net.block_offsets()["head"]].clone()
+    x, y = _data(B, 32, counts, seed=4)
+    table = O.iif_tables(counts)["raw"]
+    crit = IIFLoss(DS(counts))
+    net.train()
+    hb = {}
+    for it in range(3):
+        loss, _ = net.loss_and_backward(x.to(DEV), y.to(DEV), crit)
+        net.sgd_step(0.05, 0.9, 1e-4)
+        rl, _, grads = R.loss_and_grads(ref, x, y, table, arch)
+        keys = ["linear.weight", "linear.bias"]
+        params, bl = [ref[k] for k in keys], [hb.get(k) for k in keys]
+        with torch.no_grad():
+            O.sgd_step(params, [grads[k] for k in keys], bl, 0.05, 0.9, 1e-4)
+        for k, b in zip(keys, bl):
+            hb[k] = b
+        assert relerr(loss, rl) <= 1e-4, (it, loss.item(), rl.item())
+    assert torch.equal(net.param_arena[:net.block_offsets()["head"]], frozen_before)
+    assert relerr(net.linear.weight, ref["linear.weight"]) <= 1e-4
+    assert relerr(net.bn1.running_mean, ref["bn1.running_mean"]) <= 1e-5
