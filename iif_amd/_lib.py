@@ -35,8 +35,8 @@ SIGNATURES = {
     "iif_bn_finalize_stats": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _P],
     "iif_bn_workspace_bytes": [_L, _I],
     "iif_bn_forward_stats": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _P],
-    "iif_bn_apply": [_P, _I, _L, _I, _P, _P, _P, _I, _P, _P],
-    "iif_bn_backward": [_P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P],
+    "iif_bn_apply": [_P, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P],
+    "iif_bn_backward": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "iif_maxpool_forward": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "iif_maxpool_backward": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "iif_avgpool_forward": [_P, _I, _I, _I, _I, _P, _P],

@@ -147,30 +147,35 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partial, 
     }
 }
 
+// relu_bits (nullable): one byte per channel vector, bit k = [pre-activation k > 0].  The backward passes read
+// this byte instead of the 16-byte activated vector: 1/16 of the mask traffic.
 template <typename T, bool RELU, int RES>   // RES 0: none, 1: + r, 2: + a2*r + b2
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* x, const float* stats, const T* r, const float* stats2,
-                                                       T* y, int64_t total_vec, int cv, int C) {
+                                                       T* y, int64_t total_vec, int cv, int C, unsigned char* relu_bits) {
     constexpr int V = VT<T>::V;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
         const int c0 = (int)(i % cv) * V;
         float v[V], w[V];
         VT<T>::load(x + i * V, v);
         if (RES) VT<T>::load(r + i * V, w);
+        unsigned bits = 0;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             float t = fmaf(stats[2 * C + c0 + k], v[k], stats[3 * C + c0 + k]);   // one rounding, as vec fmadd
             if (RES == 1) t += w[k];
             if (RES == 2) t += fmaf(stats2[2 * C + c0 + k], w[k], stats2[3 * C + c0 + k]);
+            bits |= (t > 0.f ? 1u : 0u) << k;
             v[k] = RELU ? fmaxf(t, 0.f) : t;
         }
         VT<T>::store(y + i * V, v);
+        if (RELU && relu_bits) relu_bits[i] = (unsigned char)bits;
     }
 }
 
 // ----------------------------------------------------------------- backward
-template <typename T, bool MASK>
-__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* g_, const T* ymask, const T* x, const float* stats,
-                                                            Geo g, float* partial) {
+template <typename T, int MASK>     // 0: no ReLU, 1: mask from the activated tensor, 2: mask from the bit bytes
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* g_, const T* ymask, const unsigned char* bits,
+                                                            const T* x, const float* stats, Geo g, float* partial) {
     constexpr int V = VT<T>::V;
     __shared__ float sh[2][256 * V];
     const int tid = threadIdx.x;
@@ -189,10 +194,13 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* g_, const T
             float dy[V], xv[V], yv[V];
             VT<T>::load(g_ + o, dy);
             VT<T>::load(x + o, xv);
-            if (MASK) VT<T>::load(ymask + o, yv);
+            if (MASK == 1) VT<T>::load(ymask + o, yv);
+            unsigned mb = 0;
+            if (MASK == 2) mb = bits[(int64_t)r * g.cv + cvec];
 #pragma unroll
             for (int i = 0; i < V; ++i) {
-                const float d = MASK ? (yv[i] > 0.f ? dy[i] : 0.f) : dy[i];
+                const bool on = MASK == 0 ? true : (MASK == 1 ? yv[i] > 0.f : ((mb >> i) & 1u) != 0);
+                const float d = on ? dy[i] : 0.f;
                 s1[i] += d;
                 s2[i] += d * ((xv[i] - mean[i]) * istd[i]);
             }
@@ -230,20 +238,23 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* parti
     coef[2 * C + c] = (float)(s2 / count) * invstd;
 }
 
-template <typename T, bool MASK, bool GMOUT>
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T* ymask, const T* x, const float* stats,
-                                                           const float* coef, T* dx, T* gm, int64_t total_vec, int cv,
-                                                           int C) {
+template <typename T, int MASK, bool GMOUT>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T* ymask, const unsigned char* bits, const T* x,
+                                                           const float* stats, const float* coef, T* dx, T* gm,
+                                                           int64_t total_vec, int cv, int C) {
     constexpr int V = VT<T>::V;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
         const int c0 = (int)(i % cv) * V;
         float dy[V], xv[V], yv[V];
         VT<T>::load(g_ + i * V, dy);
         VT<T>::load(x + i * V, xv);
-        if (MASK) VT<T>::load(ymask + i * V, yv);
+        if (MASK == 1) VT<T>::load(ymask + i * V, yv);
+        unsigned mb = 0;
+        if (MASK == 2) mb = bits[i];
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const float d = MASK ? (yv[k] > 0.f ? dy[k] : 0.f) : dy[k];
+            const bool on = MASK == 0 ? true : (MASK == 1 ? yv[k] > 0.f : ((mb >> k) & 1u) != 0);
+            const float d = on ? dy[k] : 0.f;
             dy[k] = d;
             xv[k] = coef[c0 + k] * (d - coef[C + c0 + k] - (xv[k] - stats[c0 + k]) * coef[2 * C + c0 + k]);
         }
@@ -306,13 +317,13 @@ int bn_forward_t(const T* x, int64_t M, int C, const float* gamma, const float* 
 
 template <typename T>
 int bn_apply_t(const T* x, const float* stats, const T* r, const float* stats2, T* y, int64_t M, int C, int relu,
-               hipStream_t st) {
+               unsigned char* relu_bits, hipStream_t st) {
     constexpr int V = VT<T>::V;
     const int cv = C / V;
     const int64_t tv = M * cv;
     const dim3 grid(stream_blocks(tv)), blk(256);
     const int res = r ? (stats2 ? 2 : 1) : 0;
-#define IIF_APPLY(RL, RS) hipLaunchKernelGGL((bn_apply_kernel<T, RL, RS>), grid, blk, 0, st, x, stats, r, stats2, y, tv, cv, C)
+#define IIF_APPLY(RL, RS) hipLaunchKernelGGL((bn_apply_kernel<T, RL, RS>), grid, blk, 0, st, x, stats, r, stats2, y, tv, cv, C, relu_bits)
     if (relu) { if (res == 0) IIF_APPLY(true, 0); else if (res == 1) IIF_APPLY(true, 1); else IIF_APPLY(true, 2); }
     else { if (res == 0) IIF_APPLY(false, 0); else if (res == 1) IIF_APPLY(false, 1); else IIF_APPLY(false, 2); }
 #undef IIF_APPLY
@@ -321,16 +332,17 @@ int bn_apply_t(const T* x, const float* stats, const T* r, const float* stats2, 
 }
 
 template <typename T>
-int bn_backward_t(const T* gy, const T* ymask, const T* x, const float* stats, const float* gamma, int64_t M, int C,
-                  float* dgamma, float* dbeta, T* dx, T* gm, float* ws, int64_t ws_bytes, hipStream_t st) {
+int bn_backward_t(const T* gy, const T* ymask, const unsigned char* bits, const T* x, const float* stats, const float* gamma,
+                  int64_t M, int C, float* dgamma, float* dbeta, T* dx, T* gm, float* ws, int64_t ws_bytes, hipStream_t st) {
     constexpr int V = VT<T>::V;
     Geo g = make_geo(M, C, V, 512);
     const int64_t need = ((int64_t)g.nblk * 2 * C + 3 * C) * 4;
     if (need > ws_bytes) return IIF_EINVAL;
     float* coef = ws + (int64_t)g.nblk * 2 * C;
     const dim3 rgrid(g.nblk, g.colblocks), blk(256);
-    if (ymask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), rgrid, blk, 0, st, gy, ymask, x, stats, g, ws);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), rgrid, blk, 0, st, gy, ymask, x, stats, g, ws);
+    if (bits) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
+    else if (ymask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
     IIF_LAUNCH_CHECK();
     {
         const int cb = finalize_cb(g.nblk);
@@ -343,9 +355,10 @@ int bn_backward_t(const T* gy, const T* ymask, const T* x, const float* stats, c
     const int cv = C / V;
     const int64_t tv = M * cv;
     const dim3 agrid(stream_blocks(tv));
-#define IIF_BAPPLY(MK, GO) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MK, GO>), agrid, blk, 0, st, gy, ymask, x, stats, coef, dx, gm, tv, cv, C)
-    if (ymask) { if (gm) IIF_BAPPLY(true, true); else IIF_BAPPLY(true, false); }
-    else { if (gm) IIF_BAPPLY(false, true); else IIF_BAPPLY(false, false); }
+#define IIF_BAPPLY(MK, GO) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MK, GO>), agrid, blk, 0, st, gy, ymask, bits, x, stats, coef, dx, gm, tv, cv, C)
+    if (bits) { if (gm) IIF_BAPPLY(2, true); else IIF_BAPPLY(2, false); }
+    else if (ymask) { if (gm) IIF_BAPPLY(1, true); else IIF_BAPPLY(1, false); }
+    else { if (gm) IIF_BAPPLY(0, true); else IIF_BAPPLY(0, false); }
 #undef IIF_BAPPLY
     IIF_LAUNCH_CHECK();
     return IIF_OK;
@@ -395,37 +408,37 @@ int iif_bn_finalize_stats(const float* partial, int n_partials, int64_t m, int c
 }
 
 int iif_bn_apply(const void* x, int dtype, int64_t m, int c, const float* stats, const void* residual,
-                 const float* residual_stats, int relu, void* y, void* stream) {
+                 const float* residual_stats, int relu, void* y, uint8_t* relu_bits, void* stream) {
     if (!x || !stats || !y || m <= 0 || c <= 0) return IIF_EINVAL;
     if (bad_align(x) || bad_align(y) || bad_align(residual)) return IIF_EUNSUPPORTED;
     if (dtype == IIF_F32) {
         if (c % 4) return IIF_EUNSUPPORTED;
         return bn_apply_t<float>((const float*)x, stats, (const float*)residual, residual_stats, (float*)y, m, c, relu,
-                                 as_stream(stream));
+                                 relu_bits, as_stream(stream));
     }
     if (dtype == IIF_BF16) {
         if (c % 8) return IIF_EUNSUPPORTED;
         return bn_apply_t<unsigned short>((const unsigned short*)x, stats, (const unsigned short*)residual,
-                                          residual_stats, (unsigned short*)y, m, c, relu, as_stream(stream));
+                                          residual_stats, (unsigned short*)y, m, c, relu, relu_bits, as_stream(stream));
     }
     return IIF_EINVAL;
 }
 
-int iif_bn_backward(const void* gy, const void* y_mask, const void* x, int dtype, int64_t m, int c, const float* stats,
-                    const float* gamma, float* dgamma, float* dbeta, void* dx, void* gmasked, void* workspace,
-                    int64_t workspace_bytes, void* stream) {
+int iif_bn_backward(const void* gy, const void* y_mask, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,
+                    const float* stats, const float* gamma, float* dgamma, float* dbeta, void* dx, void* gmasked,
+                    void* workspace, int64_t workspace_bytes, void* stream) {
     if (!gy || !x || !stats || !gamma || !dgamma || !dbeta || !dx || !workspace || m <= 0 || c <= 0) return IIF_EINVAL;
     if (m > 0x7fffff00LL || bad_align(gy) || bad_align(x) || bad_align(dx) || bad_align(y_mask) || bad_align(gmasked))
         return IIF_EUNSUPPORTED;
     if (dtype == IIF_F32) {
         if (c % 4) return IIF_EUNSUPPORTED;
-        return bn_backward_t<float>((const float*)gy, (const float*)y_mask, (const float*)x, stats, gamma, m, c, dgamma,
+        return bn_backward_t<float>((const float*)gy, (const float*)y_mask, relu_bits, (const float*)x, stats, gamma, m, c, dgamma,
                                     dbeta, (float*)dx, (float*)gmasked, (float*)workspace, workspace_bytes,
                                     as_stream(stream));
     }
     if (dtype == IIF_BF16) {
         if (c % 8) return IIF_EUNSUPPORTED;
-        return bn_backward_t<unsigned short>((const unsigned short*)gy, (const unsigned short*)y_mask,
+        return bn_backward_t<unsigned short>((const unsigned short*)gy, (const unsigned short*)y_mask, relu_bits,
                                              (const unsigned short*)x, stats, gamma, m, c, dgamma, dbeta,
                                              (unsigned short*)dx, (unsigned short*)gmasked, (float*)workspace,
                                              workspace_bytes, as_stream(stream));

@@ -101,18 +101,18 @@ def bn_forward_stats(x2d, gamma, beta, running_mean, running_var, stats, ws, eps
     return stats
 
 
-def bn_apply(x2d, stats, y2d, relu=True, residual=None, residual_stats=None):
+def bn_apply(x2d, stats, y2d, relu=True, residual=None, residual_stats=None, relu_bits=None):
     m, c = x2d.shape
     check(lib().iif_bn_apply(ptr(x2d), dtype_code(x2d), m, c, ptr(stats), ptr(residual), ptr(residual_stats),
-                             1 if relu else 0, ptr(y2d), stream_ptr()), "iif_bn_apply")
+                             1 if relu else 0, ptr(y2d), ptr(relu_bits), stream_ptr()), "iif_bn_apply")
     return y2d
 
 
-def bn_backward(gy, y_mask, x2d, stats, gamma, dgamma, dbeta, dx, ws, gmasked=None):
+def bn_backward(gy, y_mask, x2d, stats, gamma, dgamma, dbeta, dx, ws, gmasked=None, relu_bits=None):
     m, c = x2d.shape
-    check(lib().iif_bn_backward(ptr(gy), ptr(y_mask), ptr(x2d), dtype_code(x2d), m, c, ptr(stats), ptr(gamma),
-                                ptr(dgamma), ptr(dbeta), ptr(dx), ptr(gmasked), ptr(ws), ws.numel(), stream_ptr()),
-          "iif_bn_backward")
+    check(lib().iif_bn_backward(ptr(gy), ptr(y_mask), ptr(relu_bits), ptr(x2d), dtype_code(x2d), m, c, ptr(stats),
+                                ptr(gamma), ptr(dgamma), ptr(dbeta), ptr(dx), ptr(gmasked), ptr(ws), ws.numel(),
+                                stream_ptr()), "iif_bn_backward")
     return dx
 
 

@@ -489,7 +489,7 @@ class _NetFunction(torch.autograd.Function):
 class _ConvUnit(object):
     """Buffers of one conv+BN unit inside a plan."""
     __slots__ = ("conv", "bn", "src", "x", "stats", "y", "w", "wt", "n", "hi", "wi", "ho", "wo", "is_patch_gemm",
-                 "groups", "dwp")
+                 "groups", "dwp", "bits")
 
 
 class _Plan(object):
@@ -590,6 +590,8 @@ class _Plan(object):
         u.x = torch.empty((n, ho, wo, conv.cout), dtype=dt, device=dev)
         u.y = torch.empty((n, ho, wo, conv.cout), dtype=dt, device=dev) if need_y else None
         u.stats = torch.empty((4, conv.cout), dtype=torch.float32, device=dev)
+        vec = 8 if dt == torch.bfloat16 else 4                     # channels per 16-byte vector
+        u.bits = torch.empty(n * ho * wo * conv.cout // vec, dtype=torch.uint8, device=dev) if need_y else None
         u.groups, u.dwp = 1, None
         if conv.groups > 1:
             # grouped conv: dense inside chunks of conv.chunk channels, block-diagonal packed weights
@@ -656,25 +658,28 @@ class _Plan(object):
         ops.im2col_nchw(img, c1.k, c1.k, c1.stride, c1.pad, c1.ldw, self.dt, out=self.patches)
         u = self.stem
         x2 = self._conv_bn(u, training)
-        ops.bn_apply(x2, u.stats, u.y.view(x2.shape), relu=True)
+        ops.bn_apply(x2, u.stats, u.y.view(x2.shape), relu=True, relu_bits=u.bits)
         if net.style == "imagenet":
             self._maxpool_fwd(u.y)
         for b in self.blocks:
             units = b["units"]
             for uu in units[:-1]:
                 x2 = self._conv_bn(uu, training)
-                ops.bn_apply(x2, uu.stats, uu.y.view(x2.shape), relu=True)
+                ops.bn_apply(x2, uu.stats, uu.y.view(x2.shape), relu=True, relu_bits=uu.bits)
             last = units[-1]
             x2 = self._conv_bn(last, training)
             if "ds" in b:
                 du = b["ds"]
                 xd = self._conv_bn(du, training)
-                ops.bn_apply(x2, last.stats, last.y.view(x2.shape), relu=True, residual=xd, residual_stats=du.stats)
+                ops.bn_apply(x2, last.stats, last.y.view(x2.shape), relu=True, residual=xd, residual_stats=du.stats,
+                             relu_bits=last.bits)
             elif "sc" in b:
                 ops.shortcut_a_forward(b["inp"], b["blk"].out_planes, out=b["sc"])
-                ops.bn_apply(x2, last.stats, last.y.view(x2.shape), relu=True, residual=b["sc"].view(x2.shape))
+                ops.bn_apply(x2, last.stats, last.y.view(x2.shape), relu=True, residual=b["sc"].view(x2.shape),
+                             relu_bits=last.bits)
             else:
-                ops.bn_apply(x2, last.stats, last.y.view(x2.shape), relu=True, residual=b["inp"].view(x2.shape))
+                ops.bn_apply(x2, last.stats, last.y.view(x2.shape), relu=True, residual=b["inp"].view(x2.shape),
+                             relu_bits=last.bits)
         ops.avgpool_forward(self.final, out=self.pooled)
         head = net._head
         feat, bias = self.pooled, None
@@ -721,11 +726,12 @@ class _Plan(object):
         if gmasked is not None:
             dx = self._gbuf(("dx", m, cv.cout), (m, cv.cout))
             ops.bn_backward(g2, None if mask is None else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats, bn.weight,
-                            bn._dgamma, bn._dbeta, dx, self.bn_ws, gmasked=gmasked.view(m, cv.cout))
+                            bn._dgamma, bn._dbeta, dx, self.bn_ws, gmasked=gmasked.view(m, cv.cout),
+                            relu_bits=None if mask is None else u.bits)
         else:
             dx = g2
             ops.bn_backward(g2, None if mask is None else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats, bn.weight,
-                            bn._dgamma, bn._dbeta, dx, self.bn_ws)
+                            bn._dgamma, bn._dbeta, dx, self.bn_ws, relu_bits=None if mask is None else u.bits)
         dx4 = dx.view(u.n, u.ho, u.wo, cv.cout)
         if u.is_patch_gemm:
             ops.conv_wgrad(u.src, dx4, 1, 1, 1, 0, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws)

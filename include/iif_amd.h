@@ -180,6 +180,9 @@ int iif_conv_wgrad(const iif_conv_desc* d, const void* x, const void* dy, float*
  *   dx = gamma*invstd*(dy - mean(dy) - xhat*mean(dy*xhat)).
  *   gmasked (nullable, may alias gy) receives dy — the gradient that also flows
  *   into the residual branch.  dx may alias gy when gmasked is NULL.
+ * relu_bits (apply: nullable output, backward: nullable input that replaces y_mask): one byte per
+ *   16-byte channel vector (8 bf16 / 4 f32 channels), bit k = [pre-activation k > 0] — the backward
+ *   passes then read 1/16 of the mask bytes.  m*c/8 (bf16) or m*c/4 (f32) bytes.
  * workspace: iif_bn_workspace_bytes(m, c) bytes. */
 int64_t iif_bn_workspace_bytes(int64_t m, int c);
 int iif_bn_forward_stats(const void* x, int dtype, int64_t m, int c, const float* gamma,
@@ -187,7 +190,8 @@ int iif_bn_forward_stats(const void* x, int dtype, int64_t m, int c, const float
                          float* running_var, float* stats, void* workspace,
                          int64_t workspace_bytes, void* stream);
 int iif_bn_apply(const void* x, int dtype, int64_t m, int c, const float* stats,
-                 const void* residual, const float* residual_stats, int relu, void* y, void* stream);
+                 const void* residual, const float* residual_stats, int relu, void* y,
+                 uint8_t* relu_bits, void* stream);
 /* second half of iif_bn_forward_stats on externally produced partial sums
  * (partial[t][0][k] = sum, [t][1][k] = sum of squares; fixed-order fp64 reduction).
  * scratch (nullable, >= 128*c floats) lets > 512 partial rows be reduced in two
@@ -196,9 +200,10 @@ int iif_bn_finalize_stats(const float* partial, int n_partials, int64_t m, int c
                           const float* beta, float eps, float momentum, float* running_mean,
                           float* running_var, float* stats, float* scratch, int64_t scratch_floats,
                           void* stream);
-int iif_bn_backward(const void* gy, const void* y_mask, const void* x, int dtype, int64_t m, int c,
-                    const float* stats, const float* gamma, float* dgamma, float* dbeta, void* dx,
-                    void* gmasked, void* workspace, int64_t workspace_bytes, void* stream);
+int iif_bn_backward(const void* gy, const void* y_mask, const uint8_t* relu_bits, const void* x,
+                    int dtype, int64_t m, int c, const float* stats, const float* gamma, float* dgamma,
+                    float* dbeta, void* dx, void* gmasked, void* workspace, int64_t workspace_bytes,
+                    void* stream);
 
 /* Max pooling k x k / stride / pad on NHWC (resnet_pytorch.py:206 MaxPool2d(3,2,1)).
  * argmax: uint8 per output element = kh*k + kw of the first maximum in scan

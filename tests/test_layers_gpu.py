@@ -62,8 +62,10 @@ def test_batchnorm_forward_backward(shape, dt, mode):
     if mode == "res2":
         stats2 = torch.empty(4, c, device=DEV)
         ops.bn_forward_stats(resd, gamma2.to(DEV), beta2.to(DEV), None, None, stats2, ws)
+    vec = 8 if dt == torch.bfloat16 else 4
+    bits = torch.zeros(m * c // vec, dtype=torch.uint8, device=DEV)
     ops.bn_apply(xd, stats, yd, relu=(mode != "plain"), residual=resd if mode in ("res", "res2") else None,
-                 residual_stats=stats2)
+                 residual_stats=stats2, relu_bits=bits)
     tol = tol_for(dt)
     got_y = nchw(yd.view(n, h, w, c).float().cpu())
     assert (got_y - y.detach()).abs().max().item() <= tol * max(1.0, y.detach().abs().max().item())
@@ -75,6 +77,17 @@ def test_batchnorm_forward_backward(shape, dt, mode):
     dxd = torch.empty_like(xd)
     gm = torch.empty_like(xd) if mode in ("res", "res2") else None
     ops.bn_backward(gyd, yd if mode != "plain" else None, xd, stats, gd, dgam, dbet, dxd, ws, gmasked=gm)
+    if mode != "plain":
+        # the 1-bit mask path is the same computation with 1/16 of the mask bytes
+        packed = (yd.view(-1, vec) > 0).to(torch.int32) * (2 ** torch.arange(vec, device=DEV, dtype=torch.int32))
+        assert torch.equal(bits.to(torch.int32), packed.sum(1))
+        dg2, db2 = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+        dx2 = torch.empty_like(xd)
+        gm2 = torch.empty_like(xd) if gm is not None else None
+        ops.bn_backward(gyd, None, xd, stats, gd, dg2, db2, dx2, ws, gmasked=gm2, relu_bits=bits)
+        assert torch.equal(dx2, dxd) and torch.equal(dg2, dgam) and torch.equal(db2, dbet)
+        if gm is not None:
+            assert torch.equal(gm2, gm)
     gtol = 1e-4 if dt == torch.float32 else 3e-2        # bf16: mask flips on rounded outputs near 0
     ref_dx = xr.grad
     assert (nchw(dxd.view(n, h, w, c).float().cpu()) - ref_dx).abs().max().item() <= gtol * max(1e-3, ref_dx.abs().max().item())
