@@ -543,387 +543,6 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     conv_epilogue<T, BN, OUTF32>(a, acc, m0, n0, wm, wn, fr, fc, grp * a.Cd);
 }
 
-// ------------------------------------------------------------------------------------------
-// Large-tile variant for MFMA-bound bf16 layers: 256 pixels x 128 channels per workgroup of 8 waves,
-// K step = 64 channels = 128-byte rows, so every LDS-DMA piece covers 8 rows x one FULL 128-byte line
-// (the 64-byte rows of the 128x128 kernel touch 16 half lines per piece), 85 instead of 64 FLOP per
-// loaded byte, three 48-KB LDS stages (147 KB, one workgroup per CU).  Uniform-tap addressing only
-// (Cs % 64 == 0, not a stride-2 data gradient).  Swizzle for 128-byte rows: chunk ^= (row>>1)&7, which
-// makes every ds_read_b128 lane group hit 16 distinct 16-byte slots.
-__device__ __forceinline__ int swz128(int row) { return (row >> 1) & 7; }
-
-__global__ void __launch_bounds__(512) conv_igemm_big_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
-    using T = unsigned short;
-    constexpr int BM = 256, BN = 128, KE = 64, PE = 8, RB = 128;
-    constexpr int STAGE = (BM + BN) * RB;          // 49152
-    constexpr int LPS = 6;                         // DMA instructions per wave per stage (4 pixel + 2 weight pieces)
-    constexpr unsigned OOB = 0x80000000u;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;       // 4 pixel quarters x 2 channel halves, 64 x 64 per wave
-    const int b = blockIdx.x;
-    const int xcd = b & 7, j = b >> 3;
-    const int mt = (j / a.ntiles) * 8 + xcd, nt = j % a.ntiles;
-    if (mt >= a.mtiles) return;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int grp = blockIdx.y;
-    const unsigned gsrc = (unsigned)(grp * a.Cs) * 2u;
-    const unsigned char* wgt_g = a.wgt + (int64_t)grp * a.Cd * a.ldw * 2;
-
-    // lane role inside an 8-row piece: row l>>3, physical chunk l&7; logical chunk = physical ^ key(row),
-    // key = (4*(piece&1) + (l>>4)) & 7 for piece index (within the wave) parity
-    const int prow = lane >> 3, pchunk = lane & 7;
-    const int HW = a.Hd * a.Wd;
-    const int dsign = a.transposed ? -1 : 1;
-    const int dmin = a.transposed ? ((a.pad - a.R + 1) * a.Ws + (a.pad - a.S + 1)) : (-a.pad * a.Ws - a.pad);
-    const int shiftP = dmin < 0 ? -dmin * a.spitch * 2 : 0;
-    unsigned vbase[4], vmask[4], vwf[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int chunk = pchunk ^ ((4 * (i & 1) + (lane >> 4)) & 7);
-        const int m = m0 + 32 * wave + 8 * i + prow;
-        const bool valid = m < a.M;
-        const int mm = valid ? m : 0;
-        const int n = mm / HW, rem = mm - n * HW;
-        const int y = rem / a.Wd, x = rem - y * a.Wd;
-        const int y0 = a.transposed ? y : (y << a.sshift), x0 = a.transposed ? x : (x << a.sshift);
-        vbase[i] = ((unsigned)(n * a.Hs * a.Ws + y0 * a.Ws + x0) * (unsigned)a.spitch + (unsigned)(chunk * PE)) * 2u + gsrc;
-        unsigned mask = 0;
-        for (int rr = 0; rr < a.R; ++rr)
-            for (int ss = 0; ss < a.S; ++ss) {
-                const int ys = a.transposed ? y + a.pad - rr : y0 - a.pad + rr;
-                const int xs = a.transposed ? x + a.pad - ss : x0 - a.pad + ss;
-                const bool ok = valid && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
-                mask |= (ok ? 1u : 0u) << (rr * a.S + ss);
-            }
-        vmask[i] = mask;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int chunk = pchunk ^ ((4 * (i & 1) + (lane >> 4)) & 7);
-        const int n = n0 + 16 * wave + 8 * i + prow;
-        vwf[i] = n < a.Cd ? ((unsigned)n * (unsigned)a.ldw + (unsigned)(chunk * PE)) * 2u : OOB;
-    }
-    const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src) - shiftP, 0,
-                                                          src_bytes + (unsigned)shiftP + 16u, 0x00020000);
-    const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wgt_g), 0, wgt_bytes, 0x00020000);
-    int ur = 0, us = 0, uc = 0, ut = 0;
-    unsigned usoff = (unsigned)(dsign * (-a.pad * a.Ws - a.pad) * a.spitch * 2 + shiftP), uwoff = 0;
-
-    auto issue = [&](auto stage_c) {
-        constexpr int stage = decltype(stage_c)::value;
-        unsigned char* A = smem + stage * STAGE;
-        unsigned char* B = A + BM * RB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned off = ((vmask[i] >> ut) & 1u) ? vbase[i] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(A + (4 * wave + i) * 1024), 16, off, usoff, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)(B + (2 * wave + i) * 1024), 16, vwf[i], uwoff, 0, 0);
-    };
-    auto advance = [&]() {
-        uwoff += KE * 2u;
-        usoff += KE * 2u;
-        uc += KE;
-        if (uc >= a.Cs) {
-            uc = 0; ++ut;
-            if (++us == a.S) { us = 0; ++ur; }
-            usoff = (unsigned)(dsign * ((ur - a.pad) * a.Ws + (us - a.pad)) * a.spitch * 2 + shiftP);
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int pj = 0; pj < 4; ++pj) acc[ci][pj] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = a.K / KE;
-    const int fr = lane & 15, fc = lane >> 4;
-    // per-lane fragment offsets for the two K halves of a step
-    int wofs[2][4], xofs[2][4];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci) {
-            const int row = wn * 64 + ci * 16 + fr;
-            wofs[kk][ci] = BM * RB + row * RB + (((kk * 4 + fc) ^ swz128(row)) << 4);
-        }
-#pragma unroll
-        for (int pj = 0; pj < 4; ++pj) {
-            const int row = wm * 64 + pj * 16 + fr;
-            xofs[kk][pj] = row * RB + (((kk * 4 + fc) ^ swz128(row)) << 4);
-        }
-    }
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    using S2 = std::integral_constant<int, 2>;
-    auto step = [&](auto stage_c, auto refill_c, int k) {
-        constexpr int S = decltype(stage_c)::value;
-        if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (k + 2 < nk) { advance(); issue(refill_c); }
-        const unsigned char* base = smem + S * STAGE;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            u32x4 wf[4], xf[4];
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci) wf[ci] = *reinterpret_cast<const u32x4*>(base + wofs[kk][ci]);
-#pragma unroll
-            for (int pj = 0; pj < 4; ++pj) xf[pj] = *reinterpret_cast<const u32x4*>(base + xofs[kk][pj]);
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-                for (int pj = 0; pj < 4; ++pj)
-                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, wf[ci]), __builtin_bit_cast(bf16x8, xf[pj]), acc[ci][pj], 0, 0, 0);
-        }
-    };
-    issue(S0{});
-    if (nk > 1) { advance(); issue(S1{}); }
-    for (int k = 0; k < nk; k += 3) {
-        step(S0{}, S2{}, k);
-        if (k + 1 < nk) step(S1{}, S0{}, k + 1);
-        if (k + 2 < nk) step(S2{}, S1{}, k + 2);
-    }
-
-    // ---- LDS-staged epilogue (bf16): 256 rows x 272-byte pitch, 16-byte coalesced stores, optional residual
-    // and per-tile batch-norm partial sums (one partial row per 256-pixel tile)
-    constexpr int PITCH = BN * 2 + 16;
-    const int goff = grp * a.Cd;
-    __syncthreads();
-#pragma unroll
-    for (int pj = 0; pj < 4; ++pj)
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci) {
-            const int row = wm * 64 + pj * 16 + fr, ch = wn * 64 + ci * 16 + fc * 4;
-            u32x2 w;
-            w.x = pack_bf16x2(acc[ci][pj].x, acc[ci][pj].y);
-            w.y = pack_bf16x2(acc[ci][pj].z, acc[ci][pj].w);
-            *reinterpret_cast<u32x2*>(smem + row * PITCH + ch * 2) = w;
-        }
-    __syncthreads();
-    const int chunk = tid & 15, r0 = tid >> 4;       // 16 chunks per row, 32 rows per pass
-    const int n = n0 + chunk * 8;
-    if (n < a.Cd) {
-#pragma unroll 4
-        for (int row = r0; row < BM; row += 32) {
-            const int m = m0 + row;
-            if (m >= a.M) break;
-            u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PITCH + chunk * 16);
-            const int64_t o = ((int64_t)m * a.dpitch + goff + n) * 2;
-            if (a.res) {
-                const u32x4 rr = *reinterpret_cast<const u32x4*>(a.res + o);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float lo = bf16_bits_to_f32(v[q] & 0xffffu) + bf16_bits_to_f32(rr[q] & 0xffffu);
-                    const float hi = __uint_as_float(v[q] & 0xffff0000u) + __uint_as_float(rr[q] & 0xffff0000u);
-                    v[q] = pack_bf16x2(lo, hi);
-                }
-            }
-            *reinterpret_cast<u32x4*>(a.dst + o) = v;
-        }
-    }
-    if (a.bn_partial) {
-        float* scratch = reinterpret_cast<float*>(smem + BM * PITCH);
-        const int ch = tid & 127, g4 = tid >> 7;           // 4 row groups of 64 rows
-        float sm = 0.f, q = 0.f;
-#pragma unroll 8
-        for (int row = g4 * 64; row < g4 * 64 + 64; ++row) {
-            const float x = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(smem + row * PITCH + ch * 2));
-            sm += x; q = fmaf(x, x, q);
-        }
-        scratch[tid] = sm; scratch[512 + tid] = q;
-        __syncthreads();
-        if (tid < BN && n0 + tid < a.Cd) {
-            float s2 = 0.f, q2 = 0.f;
-#pragma unroll
-            for (int gi = 0; gi < 4; ++gi) { s2 += scratch[gi * 128 + tid]; q2 += scratch[512 + gi * 128 + tid]; }
-            float* p = a.bn_partial + (int64_t)mt * 2 * a.dpitch + goff + n0 + tid;
-            p[0] = s2; p[a.dpitch] = q2;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Register-staged uniform-tap variant.  Same tile, LDS image, fragment maps and epilogues as the LDS-DMA
-// body, but the pieces travel buffer_load_dwordx4 -> VGPR -> ds_write_b128: on this loop one LDS-DMA piece
-// holds the wave's issue slot for ~150 cycles (4 pieces x 12 waves per CU bound the step), a register
-// load + ds_write costs ~20.  Pipeline per K step k (3 LDS stages, one staging register set):
-//   write step k+1's registers (loaded during step k-1) to stage (k+1)%3  ->  s_barrier  ->
-//   issue the loads of step k+2  ->  multiply stage k%3.
-// Out-of-range lanes still read zeros through the buffer range check, so there are no predicated loads.
-template <typename T, int BN, bool OUTF32>
-__device__ __forceinline__ void conv_igemm_rs_body(const ConvArgs& a, unsigned src_bytes, unsigned wgt_bytes) {
-    constexpr int BM = 128;
-    constexpr int PE = ET<T>::PE, KE = ET<T>::KE;
-    constexpr int NBI = BN / 64;
-    constexpr int CI = BN / 32;
-    constexpr int STAGE = (BM + BN) * 64;
-    constexpr unsigned OOB = 0x80000000u;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.x;
-    const int xcd = b & 7, j = b >> 3;
-    const int mt = (j / a.ntiles) * 8 + xcd, nt = j % a.ntiles;
-    if (mt >= a.mtiles) return;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int grp = blockIdx.y;
-    const unsigned gsrc = (unsigned)(grp * a.Cs) * (unsigned)sizeof(T);
-    const unsigned char* wgt_g = a.wgt + (int64_t)grp * a.Cd * a.ldw * (int64_t)sizeof(T);
-
-    const int prow = lane >> 2;
-    const int chunk = (lane & 3) ^ swz(prow);
-    const int HW = a.Hd * a.Wd;
-    const int dsign = a.transposed ? -1 : 1;
-    const int dmin = a.transposed ? ((a.pad - a.R + 1) * a.Ws + (a.pad - a.S + 1)) : (-a.pad * a.Ws - a.pad);
-    const int shiftP = dmin < 0 ? -dmin * a.spitch * (int)sizeof(T) : 0;
-    unsigned vbase[2], vmask[2], vwf[NBI];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + 16 * (2 * wave + i) + prow;
-        const bool valid = m < a.M;
-        const int mm = valid ? m : 0;
-        const int n = mm / HW, rem = mm - n * HW;
-        const int y = rem / a.Wd, x = rem - y * a.Wd;
-        const int y0 = a.transposed ? y : (y << a.sshift), x0 = a.transposed ? x : (x << a.sshift);
-        vbase[i] = ((unsigned)(n * a.Hs * a.Ws + y0 * a.Ws + x0) * (unsigned)a.spitch + (unsigned)(chunk * PE)) * (unsigned)sizeof(T) + gsrc;
-        unsigned mask = 0;
-        for (int rr = 0; rr < a.R; ++rr)
-            for (int ss = 0; ss < a.S; ++ss) {
-                const int ys = a.transposed ? y + a.pad - rr : y0 - a.pad + rr;
-                const int xs = a.transposed ? x + a.pad - ss : x0 - a.pad + ss;
-                const bool ok = valid && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
-                mask |= (ok ? 1u : 0u) << (rr * a.S + ss);
-            }
-        vmask[i] = mask;
-    }
-#pragma unroll
-    for (int i = 0; i < NBI; ++i) {
-        const int n = n0 + 16 * (NBI * wave + i) + prow;
-        vwf[i] = n < a.Cd ? ((unsigned)n * (unsigned)a.ldw + (unsigned)(chunk * PE)) * (unsigned)sizeof(T) : OOB;
-    }
-    const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src) - shiftP, 0,
-                                                          src_bytes + (unsigned)shiftP + 16u, 0x00020000);
-    const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wgt_g), 0, wgt_bytes, 0x00020000);
-    int ur = 0, us = 0, uc = 0, ut = 0;
-    unsigned usoff = (unsigned)(dsign * (-a.pad * a.Ws - a.pad) * a.spitch * (int)sizeof(T) + shiftP), uwoff = 0;
-
-    u32x4 ra[2], rb[NBI];
-    auto load_regs = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const unsigned off = ((vmask[i] >> ut) & 1u) ? vbase[i] : OOB;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, usoff, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NBI; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, vwf[i], uwoff, 0);
-    };
-    // LDS byte offsets of this lane's pieces inside a stage (the image is the lane-linear one of the DMA body)
-    int aofs[2], bofs[NBI];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) aofs[i] = (2 * wave + i) * 1024 + lane * 16;
-#pragma unroll
-    for (int i = 0; i < NBI; ++i) bofs[i] = BM * 64 + (NBI * wave + i) * 1024 + lane * 16;
-    auto store_regs = [&](auto stage_c) {
-        constexpr int stage = decltype(stage_c)::value;
-        unsigned char* base = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(base + aofs[i]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NBI; ++i) *reinterpret_cast<u32x4*>(base + bofs[i]) = rb[i];
-    };
-    auto advance = [&]() {
-        uwoff += KE * (unsigned)sizeof(T);
-        usoff += KE * (unsigned)sizeof(T);
-        uc += KE;
-        if (uc >= a.Cs) {
-            uc = 0; ++ut;
-            if (++us == a.S) { us = 0; ++ur; }
-            usoff = (unsigned)(dsign * ((ur - a.pad) * a.Ws + (us - a.pad)) * a.spitch * (int)sizeof(T) + shiftP);
-        }
-    };
-
-    f32x4 acc[CI][4];
-#pragma unroll
-    for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-        for (int pj = 0; pj < 4; ++pj) acc[ci][pj] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (a.K + KE - 1) / KE;
-    const int fr = lane & 15, fc = lane >> 4;
-    int wofs[CI], xofs[4];
-#pragma unroll
-    for (int ci = 0; ci < CI; ++ci) {
-        const int row = wn * (BN / 2) + ci * 16 + fr;
-        wofs[ci] = BM * 64 + row * 64 + ((fc ^ swz(row)) << 4);
-    }
-#pragma unroll
-    for (int pj = 0; pj < 4; ++pj) {
-        const int row = wm * 64 + pj * 16 + fr;
-        xofs[pj] = row * 64 + ((fc ^ swz(row)) << 4);
-    }
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    using S2 = std::integral_constant<int, 2>;
-    auto step = [&](auto stage_c, auto next_c, int k) {
-        constexpr int S = decltype(stage_c)::value;
-        if (k + 1 < nk) store_regs(next_c);          // step k+1's data (loaded during step k-1) -> its stage
-        __syncthreads();
-        if (k + 2 < nk) { advance(); load_regs(); }  // in flight during this whole step
-        const unsigned char* base = smem + S * STAGE;
-        u32x4 wf[CI], xf[4];
-#pragma unroll
-        for (int ci = 0; ci < CI; ++ci) wf[ci] = *reinterpret_cast<const u32x4*>(base + wofs[ci]);
-#pragma unroll
-        for (int pj = 0; pj < 4; ++pj) xf[pj] = *reinterpret_cast<const u32x4*>(base + xofs[pj]);
-#pragma unroll
-        for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-            for (int pj = 0; pj < 4; ++pj) {
-                if constexpr (sizeof(T) == 2) {
-                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, wf[ci]), __builtin_bit_cast(bf16x8, xf[pj]), acc[ci][pj], 0, 0, 0);
-                } else {
-                    const f32x4 wv = __builtin_bit_cast(f32x4, wf[ci]), xv = __builtin_bit_cast(f32x4, xf[pj]);
-                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc[ci][pj], 0, 0, 0);
-                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc[ci][pj], 0, 0, 0);
-                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[ci][pj], 0, 0, 0);
-                    acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[ci][pj], 0, 0, 0);
-                }
-            }
-    };
-    // prologue: step 0 straight into stage 0, step 1 left in the registers
-    load_regs();
-    store_regs(S0{});
-    if (nk > 1) { advance(); load_regs(); }
-    for (int k = 0; k < nk; k += 3) {
-        step(S0{}, S1{}, k);
-        if (k + 1 < nk) step(S1{}, S2{}, k + 1);
-        if (k + 2 < nk) step(S2{}, S0{}, k + 2);
-    }
-    if constexpr (sizeof(T) == 2 && !OUTF32) {
-        if ((a.Cd & 7) == 0 && a.bias == nullptr) {
-            conv_epilogue_staged<BN>(a, acc, smem, m0, n0, mt, wm, wn, fr, fc, grp * a.Cd);
-            return;
-        }
-    }
-    conv_epilogue<T, BN, OUTF32>(a, acc, m0, n0, wm, wn, fr, fc, grp * a.Cd);
-}
-
-template <typename T, int BN, bool OUTF32>
-__global__ void __launch_bounds__(256) conv_igemm_rs_utap_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
-    conv_igemm_rs_body<T, BN, OUTF32>(a, src_bytes, wgt_bytes);
-}
-
 // two kernel names instead of a fourth template flag (hipcc/ROCm 7.2 fails to emit the host stub of a
 // __global__ template whose body differs only by such a flag)
 template <typename T, int BN, bool OUTF32>
@@ -935,29 +554,9 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_utap_kernel(ConvArgs a, un
     conv_igemm_dma_body<T, BN, OUTF32, true>(a, src_bytes, wgt_bytes);
 }
 
-// eligibility of the 256x128 large-tile kernel
-inline bool big_tile_ok(const ConvArgs& a, int esz, bool outf32, int64_t src_bytes, int64_t wgt_bytes) {
-    static const int mode = getenv("IIF_CONV_BIG") ? atoi(getenv("IIF_CONV_BIG")) : 0;   // 0 off (default: measured slower), 1 heuristic, 2 whenever legal
-    if (mode == 0 || esz != 2 || outf32 || a.bias) return false;
-    if ((a.Cs % 64) || a.R * a.S > 32 || (a.transposed && a.sshift) || (a.Cd % 8) || a.Cd < 128) return false;
-    if (src_bytes >= 0x7f000000LL || wgt_bytes >= 0x7f000000LL || getenv("IIF_CONV_REGSTAGE")) return false;
-    if (mode == 2) return true;
-    const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.Cd + 127) / 128) * a.groups;
-    return tiles >= 1024;            // >= 4 full rounds of one workgroup per CU, so the tail round is small
-}
-
 template <typename T, bool OUTF32>
 int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
     ConvArgs a = a0;
-    if (big_tile_ok(a, (int)sizeof(T), OUTF32, src_bytes, wgt_bytes)) {
-        a.mtiles = (a.M + 255) / 256;
-        a.ntiles = (a.Cd + 127) / 128;
-        const int64_t blocks = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
-        hipLaunchKernelGGL(conv_igemm_big_kernel, dim3((unsigned)blocks, (unsigned)a.groups), dim3(512), 0, st, a,
-                           (unsigned)src_bytes, (unsigned)wgt_bytes);
-        IIF_LAUNCH_CHECK();
-        return IIF_OK;
-    }
     a.mtiles = (a.M + 127) / 128;
     const bool narrow = a.Cd <= 64;
     const int bn = narrow ? 64 : 128;
@@ -973,11 +572,7 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
         const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
         static const bool no_fast = getenv("IIF_CONV_GENERAL_ADDR") != nullptr;
         const bool fast = !no_fast && (a.Cs % ET<T>::KE) == 0 && a.R * a.S <= 32 && !(a.transposed && a.sshift);
-        static const bool use_dma = getenv("IIF_CONV_LDSDMA") != nullptr;     // A/B switch: LDS-DMA staging instead
-        if (fast && !use_dma) {
-            if (narrow) hipLaunchKernelGGL((conv_igemm_rs_utap_kernel<T, 64, OUTF32>), grid, blk, 0, st, a, sb, wb);
-            else hipLaunchKernelGGL((conv_igemm_rs_utap_kernel<T, 128, OUTF32>), grid, blk, 0, st, a, sb, wb);
-        } else if (fast) {
+        if (fast) {
             if (narrow) hipLaunchKernelGGL((conv_igemm_dma_utap_kernel<T, 64, OUTF32>), grid, blk, 0, st, a, sb, wb);
             else hipLaunchKernelGGL((conv_igemm_dma_utap_kernel<T, 128, OUTF32>), grid, blk, 0, st, a, sb, wb);
         } else {
@@ -1036,17 +631,7 @@ extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, c
                         bn_partial_floats >= mt * groups * 2 * d->cd * (d->groups > 1 ? d->groups : 1);
         if (!ok) return IIF_EUNSUPPORTED;
         a.bn_partial = bn_partial;
-        int64_t npart = mt * groups;
-        {
-            ConvArgs probe{};
-            probe.M = (int)M; probe.Cs = d->cs; probe.Cd = d->cd; probe.R = d->r; probe.S = d->s;
-            probe.transposed = d->transposed ? 1 : 0; probe.sshift = d->stride - 1;
-            probe.groups = d->groups > 1 ? d->groups : 1;
-            if (big_tile_ok(probe, 2, false, (int64_t)d->n * d->hs * d->ws * d->cs * probe.groups * 2,
-                            (int64_t)d->cd * d->ldw * 2))
-                npart = (M + 255) / 256;
-        }
-        if (n_partials) *n_partials = (int32_t)npart;
+        if (n_partials) *n_partials = (int32_t)(mt * groups);
     }
     a.N = d->n; a.Hs = d->hs; a.Ws = d->ws; a.Cs = d->cs; a.Hd = d->hd; a.Wd = d->wd; a.Cd = d->cd;
     a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.transposed = d->transposed ? 1 : 0;
