@@ -43,6 +43,7 @@ class ArenaReducer(object):
         self._next = 0
         self._works = []
         self.force = False         # exercise the bucket/stream machinery even with a single rank (tests)
+        self.extra_streams = []    # other producer streams of gradients (the engine's wgrad stream)
 
     # ---- called by the engine -------------------------------------------------
     def begin(self):
@@ -88,6 +89,8 @@ class ArenaReducer(object):
         view = self.arena[lo:hi]
         if self.use_streams:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for s in self.extra_streams:
+                self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         else:

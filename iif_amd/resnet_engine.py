@@ -579,6 +579,9 @@ class _Plan(object):
         self.wg_ws = torch.empty(min(16 * wmax * 4, 512 << 20), dtype=torch.uint8, device=dev)
         self._grad_pool = {}
         self._bwd_ready = False
+        import os
+        self.wg_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and not os.environ.get("IIF_NO_WGRAD_STREAM")) else None
+        self._wg_events = {}
 
     def _unit(self, conv, bn, src, n, ho, wo, patch=False, need_y=True):
         dt, dev = self.dt, self.dev
@@ -716,7 +719,35 @@ class _Plan(object):
             self._grad_pool[key] = t
         return t
 
-    def _unit_backward(self, u, gy, mask, gmasked=None, dgrad_out=None, dgrad_res=None, need_dgrad=True):
+    # ---- weight gradients on a side stream ---------------------------------------------------------
+    # After bn_backward the weight gradient (reads x-operand + dx, writes only the gradient arena) and the
+    # data gradient are independent.  wgrad is issued on a second HIP stream so that it overlaps the
+    # bandwidth-bound BN-backward / dgrad kernels of the following units.  A pending wgrad of block b+1 still
+    # reads that block's dx buffers and its g (= the block-input gradient G[b+2]); so dx buffers rotate over
+    # 2 slots, block-input gradients over 3, and before block b starts the main stream waits for every wgrad
+    # of the blocks >= b+2 (the fence recorded when block b+1 started).
+    def _wgrad_async(self, fn):
+        if self.wg_stream is None:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.wg_stream):
+            self.wg_stream.wait_event(ev)
+            fn()
+
+    def _wgrad_fence(self, tag):
+        """Record where the side stream is after block ``tag``; wait for the fence of block tag+2."""
+        if self.wg_stream is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.wg_stream)
+        self._wg_events[tag] = ev
+        old = self._wg_events.pop(tag + 1, None)
+        if old is not None:
+            torch.cuda.current_stream().wait_event(old)
+
+    def _unit_backward(self, u, gy, mask, gmasked=None, dgrad_out=None, dgrad_res=None, need_dgrad=True, par=0):
         """gy: grad w.r.t. the unit's activated output (NHWC).  Computes in place
         dx (into gy's storage unless gmasked is requested), the weight / BN
         gradients, and (optionally) the data gradient w.r.t. the unit's source."""
@@ -724,7 +755,7 @@ class _Plan(object):
         m = u.n * u.ho * u.wo
         g2 = gy.view(m, cv.cout)
         if gmasked is not None:
-            dx = self._gbuf(("dx", m, cv.cout), (m, cv.cout))
+            dx = self._gbuf(("dx", m, cv.cout, par), (m, cv.cout))
             ops.bn_backward(g2, None if mask is None else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats, bn.weight,
                             bn._dgamma, bn._dbeta, dx, self.bn_ws, gmasked=gmasked.view(m, cv.cout),
                             relu_bits=None if mask is None else u.bits)
@@ -734,14 +765,17 @@ class _Plan(object):
                             bn._dgamma, bn._dbeta, dx, self.bn_ws, relu_bits=None if mask is None else u.bits)
         dx4 = dx.view(u.n, u.ho, u.wo, cv.cout)
         if u.is_patch_gemm:
-            ops.conv_wgrad(u.src, dx4, 1, 1, 1, 0, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws)
+            self._wgrad_async(lambda: ops.conv_wgrad(u.src, dx4, 1, 1, 1, 0, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws))
             return None
         if u.groups > 1:
-            ops.conv_wgrad(u.src, dx4, cv.k, cv.k, cv.stride, cv.pad, ldw=u.dwp.shape[1], out=u.dwp, workspace=self.wg_ws,
-                           groups=u.groups)
-            ops.group_unpack_grad(u.dwp, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, cv._g2d)
+            def grouped():
+                ops.conv_wgrad(u.src, dx4, cv.k, cv.k, cv.stride, cv.pad, ldw=u.dwp.shape[1], out=u.dwp,
+                               workspace=self.wg_ws, groups=u.groups)
+                ops.group_unpack_grad(u.dwp, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, cv._g2d)
+            self._wgrad_async(grouped)
         else:
-            ops.conv_wgrad(u.src, dx4, cv.k, cv.k, cv.stride, cv.pad, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws)
+            self._wgrad_async(lambda: ops.conv_wgrad(u.src, dx4, cv.k, cv.k, cv.stride, cv.pad, ldw=cv.ldw, out=cv._g2d,
+                                                     workspace=self.wg_ws))
         if not need_dgrad:
             return None
         return ops.conv_dgrad(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), out=dgrad_out, res=dgrad_res,
@@ -754,6 +788,7 @@ class _Plan(object):
         offs = net.block_offsets() if reducer is not None else None
         if reducer is not None:
             reducer.begin()
+            reducer.extra_streams = [self.wg_stream] if self.wg_stream is not None else []
         # ---- head: dlogits (fp32, pad columns are zero) -> head grads -> pooled grad -> final activation grad
         op, D = head.out_padded, head.in_features
         if self.dt == torch.float32:
@@ -805,22 +840,25 @@ class _Plan(object):
             inp = b["inp"]
             # g is the gradient w.r.t. the block output (pre-mask).  After this call g holds the masked
             # gradient (the residual-branch gradient) and dx of the last conv has been consumed.
-            gin = self._gbuf(("gin", tuple(inp.shape), bi & 1), inp.shape)
-            d = self._unit_backward(last, g, last.y, gmasked=g,
-                                    dgrad_out=self._gbuf(("d", tuple(last.src.shape), len(units) - 1), last.src.shape))
+            par = bi & 1
+            self._wgrad_fence(bi)
+            gin = self._gbuf(("gin", tuple(inp.shape), bi % 3), inp.shape)
+            d = self._unit_backward(last, g, last.y, gmasked=g, par=par,
+                                    dgrad_out=self._gbuf(("d", tuple(last.src.shape), len(units) - 1, par), last.src.shape))
             for ui in range(len(units) - 2, 0, -1):
                 uu = units[ui]
-                d = self._unit_backward(uu, d, uu.y, dgrad_out=self._gbuf(("d", tuple(uu.src.shape), ui), uu.src.shape))
+                d = self._unit_backward(uu, d, uu.y, par=par,
+                                        dgrad_out=self._gbuf(("d", tuple(uu.src.shape), ui, par), uu.src.shape))
             first = units[0]
             if "ds" in b:
-                self._unit_backward(first, d, first.y, dgrad_out=gin)
+                self._unit_backward(first, d, first.y, dgrad_out=gin, par=par)
                 du = b["ds"]
-                self._unit_backward(du, g, None, dgrad_out=gin, dgrad_res=gin)
+                self._unit_backward(du, g, None, dgrad_out=gin, dgrad_res=gin, par=par)
             elif "sc" in b:
-                self._unit_backward(first, d, first.y, dgrad_out=gin)
+                self._unit_backward(first, d, first.y, dgrad_out=gin, par=par)
                 ops.shortcut_a_backward_acc(g, gin)
             else:
-                self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=g)
+                self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=g, par=par)
             g = gin
             if reducer is not None:
                 reducer.gradients_ready_from(offs["blocks"][bi])
@@ -833,6 +871,9 @@ class _Plan(object):
                        "iif_maxpool_backward")
             g = dy0
         self._unit_backward(u, g, u.y, need_dgrad=False)
+        if self.wg_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wg_stream)
+            self._wg_events.clear()
         if reducer is not None:
             reducer.finish()
 
