@@ -41,7 +41,24 @@ struct ConvArgs {
     float* bn_partial;     // nullable: [mtiles][2][Cd] per-tile (sum, sum of squares) of the stored output
     int N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, sshift, pad, transposed, ldw, M, K, mtiles, ntiles;
     int spitch, dpitch, groups;   // channels per pixel of the source / destination TENSORS (= groups * Cs / Cd)
+    // uniform-tap path: explicit tap list (source displacement in pixels of the source grid, weight tap index);
+    // source pixel of output (y, x) and tap t is ((y << in_shift) + tap_dy[t], (x << in_shift) + tap_dx[t])
+    int ntaps, in_shift;
+    signed char tap_dy[16], tap_dx[16];
+    unsigned char tap_w[16];
+    // destination scatter: GEMM row (n, y, x) of the (Hd, Wd) grid is written to pixel
+    // (n, (y << ds_shift) + doy, (x << ds_shift) + dox) of a [N, Hfull, Wfull] tensor (stride-2 data gradients
+    // run as one dense sub-convolution per output parity class)
+    int scatter, ds_shift, doy, dox, Hfull, Wfull;
 };
+
+__device__ __forceinline__ int64_t dst_row(const ConvArgs& a, int m) {
+    if (!a.scatter) return m;
+    const int hw = a.Hd * a.Wd;
+    const int n = m / hw, rem = m - n * hw;
+    const int y = rem / a.Wd, x = rem - y * a.Wd;
+    return ((int64_t)n * a.Hfull + ((y << a.ds_shift) + a.doy)) * a.Wfull + ((x << a.ds_shift) + a.dox);
+}
 
 __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
@@ -56,12 +73,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BN
     for (int pj = 0; pj < 4; ++pj) {
         const int m = m0 + wm * 64 + pj * 16 + fr;
         if (m >= a.M) continue;
+        const int64_t drow = dst_row(a, m);
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) {
             const int n = n0 + wn * (BN / 2) + ci * 16 + fc * 4;
             if (n >= a.Cd) continue;
             float v[4] = {acc[ci][pj].x, acc[ci][pj].y, acc[ci][pj].z, acc[ci][pj].w};
-            const int64_t o = (int64_t)m * a.dpitch + goff + n;
+            const int64_t o = drow * a.dpitch + goff + n;
             const int cnt = a.Cd - n < 4 ? a.Cd - n : 4;
             if (a.bias)
                 for (int q = 0; q < cnt; ++q) v[q] += a.bias[n + q];
@@ -276,7 +294,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
             const int m = m0 + row;
             if (m >= a.M) break;
             u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PITCH + chunk * 16);
-            const int64_t o = ((int64_t)m * a.dpitch + goff + n) * 2;
+            const int64_t o = (dst_row(a, m) * a.dpitch + goff + n) * 2;
             if (a.res) {
                 const u32x4 rr = *reinterpret_cast<const u32x4*>(a.res + o);
 #pragma unroll
@@ -349,7 +367,6 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     const int HW = a.Hd * a.Wd;
     // fast-path state
     unsigned vbase[2], vmask[2], vwf[NBI];
-    int dsign = a.transposed ? -1 : 1;                        // tap displacement sign
     int shiftP = 0;                                           // bytes subtracted from the base so soffset >= 0
     // general-path state
     int by[2], bx[2], ib[2];
@@ -358,8 +375,12 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     int e = chunk * PE, c = 0, r = 0, s = 0;
     if constexpr (UTAP) {
         // most negative tap displacement, in pixels
-        const int dmin = a.transposed ? ((a.pad - a.R + 1) * a.Ws + (a.pad - a.S + 1)) : (-a.pad * a.Ws - a.pad);
-        shiftP = dmin < 0 ? -dmin * a.spitch * (int)sizeof(T) : 0;
+        int dmin = 0;
+        for (int t = 0; t < a.ntaps; ++t) {
+            const int dd = a.tap_dy[t] * a.Ws + a.tap_dx[t];
+            dmin = dd < dmin ? dd : dmin;
+        }
+        shiftP = -dmin * a.spitch * (int)sizeof(T);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + 16 * (2 * wave + i) + prow;
@@ -367,16 +388,14 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
             const int mm = valid ? m : 0;
             const int n = mm / HW, rem = mm - n * HW;
             const int y = rem / a.Wd, x = rem - y * a.Wd;
-            const int y0 = a.transposed ? y : (y << a.sshift), x0 = a.transposed ? x : (x << a.sshift);
+            const int y0 = y << a.in_shift, x0 = x << a.in_shift;
             vbase[i] = ((unsigned)(n * a.Hs * a.Ws + y0 * a.Ws + x0) * (unsigned)a.spitch + (unsigned)(chunk * PE)) * (unsigned)sizeof(T) + gsrc;
             unsigned mask = 0;
-            for (int rr = 0; rr < a.R; ++rr)
-                for (int ss = 0; ss < a.S; ++ss) {
-                    const int ys = a.transposed ? y + a.pad - rr : y0 - a.pad + rr;
-                    const int xs = a.transposed ? x + a.pad - ss : x0 - a.pad + ss;
-                    const bool ok = valid && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
-                    mask |= (ok ? 1u : 0u) << (rr * a.S + ss);
-                }
+            for (int t = 0; t < a.ntaps; ++t) {
+                const int ys = y0 + a.tap_dy[t], xs = x0 + a.tap_dx[t];
+                const bool ok = valid && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
+                mask |= (ok ? 1u : 0u) << t;
+            }
             vmask[i] = mask;
         }
 #pragma unroll
@@ -414,8 +433,12 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wgt_g), 0, wgt_bytes, 0x00020000);
     // wave-uniform K-step state of the uniform-tap path, kept incrementally: tap (ur, us), first channel uc,
     // tap bit index ut, source soffset usoff (bytes), weight soffset uwoff (bytes)
-    int ur = 0, us = 0, uc = 0, ut = 0;
-    unsigned usoff = (unsigned)(dsign * (-a.pad * a.Ws - a.pad) * a.spitch * (int)sizeof(T) + shiftP), uwoff = 0;
+    int uc = 0, ut = 0;
+    unsigned usoff = 0, uwoff = 0;
+    if constexpr (UTAP) {
+        usoff = (unsigned)((a.tap_dy[0] * a.Ws + a.tap_dx[0]) * a.spitch * (int)sizeof(T) + shiftP);
+        uwoff = (unsigned)(a.tap_w[0] * a.Cs) * (unsigned)sizeof(T);
+    }
 
     auto issue = [&](auto stage_c) {
         constexpr int stage = decltype(stage_c)::value;
@@ -463,8 +486,9 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
             uc += KE;
             if (uc >= a.Cs) {
                 uc = 0; ++ut;
-                if (++us == a.S) { us = 0; ++ur; }
-                usoff = (unsigned)(dsign * ((ur - a.pad) * a.Ws + (us - a.pad)) * a.spitch * (int)sizeof(T) + shiftP);
+                const int tt = ut < a.ntaps ? ut : 0;
+                usoff = (unsigned)((a.tap_dy[tt] * a.Ws + a.tap_dx[tt]) * a.spitch * (int)sizeof(T) + shiftP);
+                uwoff = (unsigned)(a.tap_w[tt] * a.Cs) * (unsigned)sizeof(T);
             }
         } else {
             e += KE;
@@ -479,7 +503,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
 #pragma unroll
         for (int pj = 0; pj < 4; ++pj) acc[ci][pj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (a.K + KE - 1) / KE;
+    const int nk = UTAP ? a.ntaps * (a.Cs / KE) : (a.K + KE - 1) / KE;
     const int fr = lane & 15, fc = lane >> 4;
     // per-lane fragment offsets inside a stage (stage bases are compile-time immediates below)
     int wofs[CI], xofs[4];
@@ -527,7 +551,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
                 }
             }
     };
-    issue(S0{});
+    if (nk > 0) issue(S0{});
     if (nk > 1) { advance(); issue(S1{}); }
     for (int k = 0; k < nk; k += 3) {
         step(S0{}, S2{}, k);
@@ -555,8 +579,7 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_utap_kernel(ConvArgs a, un
 }
 
 template <typename T, bool OUTF32>
-int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
-    ConvArgs a = a0;
+int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
     a.mtiles = (a.M + 127) / 128;
     const bool narrow = a.Cd <= 64;
     const int bn = narrow ? 64 : 128;
@@ -567,12 +590,11 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
     // LDS-DMA addressing is a 32-bit byte offset with a hardware range check: both operands must be < 2 GiB
     const bool dma = !force_v1 && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL;
     if (a.groups > 1 && !dma) return IIF_EUNSUPPORTED;     // grouped convolutions exist on the pipelined kernels only
+    if (a.scatter && !(dma && utap)) return IIF_EUNSUPPORTED;
     const dim3 grid((unsigned)blocks, (unsigned)a.groups), blk(256);
     if (dma) {
         const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
-        static const bool no_fast = getenv("IIF_CONV_GENERAL_ADDR") != nullptr;
-        const bool fast = !no_fast && (a.Cs % ET<T>::KE) == 0 && a.R * a.S <= 32 && !(a.transposed && a.sshift);
-        if (fast) {
+        if (utap) {
             if (narrow) hipLaunchKernelGGL((conv_igemm_dma_utap_kernel<T, 64, OUTF32>), grid, blk, 0, st, a, sb, wb);
             else hipLaunchKernelGGL((conv_igemm_dma_utap_kernel<T, 128, OUTF32>), grid, blk, 0, st, a, sb, wb);
         } else {
@@ -584,6 +606,58 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
         else hipLaunchKernelGGL((conv_igemm_kernel<T, 128, OUTF32>), grid, blk, 0, st, a);
     }
     IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+// Host-side planning: which addressing path, and the tap lists of the uniform-tap path.
+//   forward:              source (y*stride + r - pad, x*stride + s - pad)
+//   data gradient, s=1:   source (y + pad - r, x + pad - s)
+//   data gradient, s=2:   one dense stride-1 sub-convolution per output parity class (py, px): only the taps
+//                         with (py + pad - r) even reach that class (1, 2, 2 and 4 of the 9 taps of a 3x3),
+//                         source (yy + (py + pad - r)/2, ...), destination scattered to (2*yy + py, 2*xx + px).
+template <typename T, bool OUTF32>
+int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
+    ConvArgs a = a0;
+    static const bool no_fast = getenv("IIF_CONV_GENERAL_ADDR") != nullptr;
+    const bool dma_ok = getenv("IIF_CONV_REGSTAGE") == nullptr && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL;
+    const bool utap = !no_fast && dma_ok && (a.Cs % ET<T>::KE) == 0 && a.R * a.S <= 16 && a.R <= 16 && a.S <= 16;
+    a.scatter = 0; a.ds_shift = 0; a.doy = a.dox = 0; a.Hfull = a.Hd; a.Wfull = a.Wd; a.ntaps = 0; a.in_shift = 0;
+    if (!utap) return launch_one<T, OUTF32>(a, false, src_bytes, wgt_bytes, st);
+    if (!a.transposed || a.sshift == 0) {
+        for (int r = 0; r < a.R; ++r)
+            for (int s = 0; s < a.S; ++s) {
+                const int t = a.ntaps++;
+                a.tap_dy[t] = (signed char)(a.transposed ? a.pad - r : r - a.pad);
+                a.tap_dx[t] = (signed char)(a.transposed ? a.pad - s : s - a.pad);
+                a.tap_w[t] = (unsigned char)(r * a.S + s);
+            }
+        a.in_shift = a.transposed ? 0 : a.sshift;
+        return launch_one<T, OUTF32>(a, true, src_bytes, wgt_bytes, st);
+    }
+    // stride-2 data gradient: 4 parity classes of the destination grid
+    const int H = a.Hd, W = a.Wd;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            ConvArgs c = a;
+            c.Hd = (H - py + 1) / 2; c.Wd = (W - px + 1) / 2;
+            if (c.Hd <= 0 || c.Wd <= 0) continue;
+            c.M = a.N * c.Hd * c.Wd;
+            c.scatter = 1; c.ds_shift = 1; c.doy = py; c.dox = px; c.Hfull = H; c.Wfull = W;
+            c.ntaps = 0;
+            for (int r = 0; r < a.R; ++r) {
+                if ((py + a.pad - r) & 1) continue;
+                for (int s = 0; s < a.S; ++s) {
+                    if ((px + a.pad - s) & 1) continue;
+                    const int t = c.ntaps++;
+                    c.tap_dy[t] = (signed char)((py + a.pad - r) / 2);      // exact: the numerator is even
+                    c.tap_dx[t] = (signed char)((px + a.pad - s) / 2);
+                    c.tap_w[t] = (unsigned char)(r * a.S + s);
+                }
+            }
+            if (c.ntaps == 0 && c.res == c.dst) continue;      // this class receives no contribution: dst += 0
+            const int rc = launch_one<T, OUTF32>(c, true, src_bytes, wgt_bytes, st);
+            if (rc != IIF_OK) return rc;
+        }
     return IIF_OK;
 }
 
