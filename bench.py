@@ -59,11 +59,16 @@ class ConvTimer(object):
         timer = self
         orig = {k: getattr(ops, k) for k in ("conv_forward", "conv_dgrad", "conv_wgrad", "conv_forward_bnstats")}
 
-        def flops_fwd(x, w, r, s, stride, pad, groups=1, **kw):
+        def alg_k(r, s, stride, pad, cin):
+            # algorithmic K of one output: the space-to-depth stem (4x4/1 pad 2 on 32 channels) is charged
+            # for the 7*7*3 MACs of the convolution it implements, not for its zero padding
+            return 147.0 if (r, s, stride, pad, cin) == (4, 4, 1, 2, 32) else float(r * s * cin)
+
+        def flops_fwd(x, w, r, s, stride, pad, groups=1, out_hw=None, **kw):
             # algorithmic FLOPs: a chunked grouped conv is charged for its in-chunk MACs only
             n, h, wd, cin = x.shape
-            ho, wo = ops.conv_out_hw(h, wd, r, s, stride, pad)
-            return 2.0 * n * ho * wo * w.shape[0] * r * s * cin / groups
+            ho, wo = out_hw or ops.conv_out_hw(h, wd, r, s, stride, pad)
+            return 2.0 * n * ho * wo * w.shape[0] * alg_k(r, s, stride, pad, cin) / groups
 
         def conv_forward(x, w, r, s, stride, pad, **kw):
             return timer._timed("fwd", flops_fwd(x, w, r, s, stride, pad, **kw), orig["conv_forward"], x, w, r, s, stride, pad, **kw)
@@ -75,11 +80,12 @@ class ConvTimer(object):
 
         def conv_wgrad(x, dy, r, s, stride, pad, **kw):
             n, ho, wo, cout = dy.shape
-            fl = 2.0 * n * ho * wo * cout * r * s * x.shape[3] / kw.get("groups", 1)
+            fl = 2.0 * n * ho * wo * cout * alg_k(r, s, stride, pad, x.shape[3]) / kw.get("groups", 1)
             return timer._timed("wgrad", fl, orig["conv_wgrad"], x, dy, r, s, stride, pad, **kw)
 
         def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial, **kw):
-            return timer._timed("fwd", flops_fwd(x, w, r, s, stride, pad, **kw), orig["conv_forward_bnstats"], x, w, r, s, stride, pad, out, partial, **kw)
+            fl = flops_fwd(x, w, r, s, stride, pad, out_hw=(out.shape[1], out.shape[2]), **kw)
+            return timer._timed("fwd", fl, orig["conv_forward_bnstats"], x, w, r, s, stride, pad, out, partial, **kw)
 
         ops.conv_forward, ops.conv_dgrad, ops.conv_wgrad = conv_forward, conv_dgrad, conv_wgrad
         ops.conv_forward_bnstats = conv_forward_bnstats

@@ -500,3 +500,93 @@ extern "C" int iif_group_unpack_grad(const float* packed, int channels, int cg, 
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }
+
+// ---------------------------------------------------------------- stem as a space-to-depth convolution
+// The 7x7 / stride-2 / pad-3 stem on a 3-channel image (resnet_pytorch.py:203) equals a 4x4 / stride-1
+// convolution on the 2x2 space-to-depth image (12 channels, padded to `cpad` = 32 so that a K step is one
+// tap): input row i = 2I + di, original tap r = 2a + di - 1 for s2d tap a = 0..3 (r outside 0..6: zero
+// weight).  No patch matrix is materialised: the MFMA kernels gather the 16 taps themselves.
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256) s2d_kernel(const float* img, int N, int C, int H, int W, int cpad, T* out) {
+    const int H2 = H / 2, W2 = W / 2;
+    const int64_t total = (int64_t)N * H2 * W2 * cpad;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i % cpad);
+        int64_t pix = i / cpad;
+        const int x = (int)(pix % W2); pix /= W2;
+        const int y = (int)(pix % H2);
+        const int n = (int)(pix / H2);
+        float v = 0.f;
+        if (q < 4 * C) {
+            const int sub = q / C, c = q - sub * C;
+            v = img[(((int64_t)n * C + c) * H + 2 * y + (sub >> 1)) * W + 2 * x + (sub & 1)];
+        }
+        PT<T>::store1(out + i, v);
+    }
+}
+// master [K][ldm] rows of (r, s, c) over R x R taps -> packed [K][A*A*cpad] rows of (a, b, q), A = (R+1)/2
+template <typename T>
+__global__ void __launch_bounds__(256) stem_pack_kernel(const float* m, int K, int C, int R, int ldm, int cpad, T* out) {
+    const int A = (R + 1) / 2, ldp = A * A * cpad;
+    const int64_t total = (int64_t)K * ldp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int col = (int)(i % ldp), k = (int)(i / ldp);
+        const int q = col % cpad, ab = col / cpad, a = ab / A, b = ab - a * A;
+        float v = 0.f;
+        if (q < 4 * C) {
+            const int sub = q / C, c = q - sub * C;
+            const int r = 2 * a + (sub >> 1) - 1, s = 2 * b + (sub & 1) - 1;
+            if (r >= 0 && r < R && s >= 0 && s < R) v = m[(int64_t)k * ldm + (r * R + s) * C + c];
+        }
+        PT<T>::store1(out + i, v);
+    }
+}
+__global__ void __launch_bounds__(256) stem_unpack_kernel(const float* p, int K, int C, int R, int cpad, int ldm, float* m) {
+    const int A = (R + 1) / 2, ldp = A * A * cpad;
+    const int64_t total = (int64_t)K * R * R * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int s = (int)((i / C) % R);
+        const int r = (int)((i / ((int64_t)C * R)) % R);
+        const int k = (int)(i / ((int64_t)C * R * R));
+        const int a = (r + 1) / 2, di = (r + 1) & 1, b = (s + 1) / 2, dj = (s + 1) & 1;
+        m[(int64_t)k * ldm + (r * R + s) * C + c] = p[(int64_t)k * ldp + (a * A + b) * cpad + (di * 2 + dj) * C + c];
+    }
+}
+}  // namespace
+
+extern "C" int iif_space_to_depth_nchw(const float* img, int n, int c, int h, int w, int cpad, int out_dtype, void* out,
+                                       void* stream) {
+    if (!img || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || cpad < 4 * c) return IIF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = (int64_t)n * (h / 2) * (w / 2) * cpad;
+    IIF_BY_DTYPE(out_dtype,
+        hipLaunchKernelGGL(s2d_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, img, n, c, h, w, cpad, (float*)out),
+        hipLaunchKernelGGL(s2d_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, img, n, c, h, w, cpad, (unsigned short*)out))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+extern "C" int iif_stem_s2d_pack(const float* master, int k, int c, int r, int ldm, int cpad, int out_dtype, void* out,
+                                 void* stream) {
+    if (!master || !out || k <= 0 || c <= 0 || r <= 0 || !(r & 1) || ldm < r * r * c || cpad < 4 * c) return IIF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int a = (r + 1) / 2;
+    const int64_t tot = (int64_t)k * a * a * cpad;
+    IIF_BY_DTYPE(out_dtype,
+        hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, master, k, c, r, ldm, cpad, (float*)out),
+        hipLaunchKernelGGL(stem_pack_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, master, k, c, r, ldm, cpad, (unsigned short*)out))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+extern "C" int iif_stem_s2d_unpack_grad(const float* packed, int k, int c, int r, int cpad, int ldm, float* master,
+                                        void* stream) {
+    if (!packed || !master || k <= 0 || c <= 0 || r <= 0 || !(r & 1) || ldm < r * r * c || cpad < 4 * c) return IIF_EINVAL;
+    const int64_t tot = (int64_t)k * r * r * c;
+    hipLaunchKernelGGL(stem_unpack_kernel, dim3(sblocks(tot)), dim3(256), 0, as_stream(stream), packed, k, c, r, cpad, ldm,
+                       master);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}

@@ -17,13 +17,13 @@ def conv_out_hw(h, w, r, s, stride, pad):
     return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
 
 
-def conv_forward(x, w, r, s, stride, pad, out=None, out_dtype=None, bias=None, res=None, groups=1):
+def conv_forward(x, w, r, s, stride, pad, out=None, out_dtype=None, bias=None, res=None, groups=1, out_hw=None):
     """x: [N,H,W,Cin] NHWC; w: [Cout, ldw] (rows = r*s*Cin K-contiguous, KRSC).  groups > 1: the
     channels split into `groups` chunks, w holds the chunk matrices one after the other."""
     require_gpu(x, w, bias, res)
     n, h, wd_, cin = x.shape
     cout, ldw = w.shape
-    ho, wo = conv_out_hw(h, wd_, r, s, stride, pad)
+    ho, wo = out_hw or conv_out_hw(h, wd_, r, s, stride, pad)     # out_hw: explicit grid (asymmetric padding)
     odt = out_dtype or x.dtype
     if out is None:
         out = torch.empty((n, ho, wo, cout), dtype=odt, device=x.device)
@@ -37,7 +37,7 @@ def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial, groups=1):
     """conv_forward (bf16) that also writes per-tile BN partial sums; returns the tile count."""
     n, h, wd_, cin = x.shape
     cout, ldw = w.shape
-    ho, wo = conv_out_hw(h, wd_, r, s, stride, pad)
+    ho, wo = out.shape[1], out.shape[2]
     d = _desc(n, h, wd_, cin // groups, ho, wo, cout // groups, r, s, stride, pad, 0, ldw, dtype_code(x), dtype_code(out),
               groups)
     nt = ctypes.c_int32(0)
@@ -239,4 +239,27 @@ def group_pack(master, channels, cg, chunk, rs, out, transposed=False):
 def group_unpack_grad(packed, channels, cg, chunk, rs, master_grad):
     check(lib().iif_group_unpack_grad(ptr(packed), channels, cg, chunk, rs, packed.shape[1], master_grad.shape[1],
                                       ptr(master_grad), stream_ptr()), "iif_group_unpack_grad")
+    return master_grad
+
+
+# ------------------------------------------------------------ space-to-depth stem
+def space_to_depth_nchw(img, cpad, out):
+    require_gpu(img)
+    if img.dtype != torch.float32 or not img.is_contiguous():
+        img = img.float().contiguous()
+    n, c, h, w = img.shape
+    check(lib().iif_space_to_depth_nchw(ptr(img), n, c, h, w, cpad, dtype_code(out), ptr(out), stream_ptr()),
+          "iif_space_to_depth_nchw")
+    return out
+
+
+def stem_s2d_pack(master, k, c, r, cpad, out):
+    check(lib().iif_stem_s2d_pack(ptr(master), k, c, r, master.shape[1], cpad, dtype_code(out), ptr(out), stream_ptr()),
+          "iif_stem_s2d_pack")
+    return out
+
+
+def stem_s2d_unpack_grad(packed, k, c, r, cpad, master_grad):
+    check(lib().iif_stem_s2d_unpack_grad(ptr(packed), k, c, r, cpad, master_grad.shape[1], ptr(master_grad), stream_ptr()),
+          "iif_stem_s2d_unpack_grad")
     return master_grad

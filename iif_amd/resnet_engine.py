@@ -24,6 +24,7 @@ accumulate on v_mfma_f32_16x16x32_bf16) or ``torch.float32`` (parity mode: exact
 fp32 MFMA, used to match the CPU reference to 1e-4).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -32,6 +33,7 @@ from . import _lib, ops
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+S2D_CPAD = 32            # channels of the space-to-depth stem image (4 * 3 real, zero padded: one tap per K step)
 
 
 def _round_up(v, m):
@@ -489,7 +491,7 @@ class _NetFunction(torch.autograd.Function):
 class _ConvUnit(object):
     """Buffers of one conv+BN unit inside a plan."""
     __slots__ = ("conv", "bn", "src", "x", "stats", "y", "w", "wt", "n", "hi", "wi", "ho", "wo", "is_patch_gemm",
-                 "groups", "dwp", "bits")
+                 "groups", "dwp", "bits", "geom", "s2d")
 
 
 class _Plan(object):
@@ -505,8 +507,19 @@ class _Plan(object):
         # ---- stem
         c1 = net.conv1
         ho, wo = ops.conv_out_hw(h, w, c1.k, c1.k, c1.stride, c1.pad)
-        self.patches = E(n, ho, wo, c1.ldw)
+        # 7x7/2 stem on even images: 4x4/1 convolution over the 2x2 space-to-depth image (no patch matrix);
+        # anything else (CIFAR 3x3 stem, odd sizes): GEMM over gathered patches
+        self.stem_s2d = (c1.k == 7 and c1.stride == 2 and c1.pad == 3 and h % 2 == 0 and w % 2 == 0
+                         and not os.environ.get("IIF_STEM_PATCHES"))
+        if self.stem_s2d:
+            self.patches = E(n, h // 2, w // 2, S2D_CPAD)
+        else:
+            self.patches = E(n, ho, wo, c1.ldw)
         u = self._unit(c1, net.bn1, self.patches, n, ho, wo, patch=True)
+        if self.stem_s2d:
+            u.s2d, u.geom = True, (4, 1, 2)
+            u.w = torch.empty((c1.cout, 16 * S2D_CPAD), dtype=dt, device=dev)
+            u.dwp = torch.empty((c1.cout, 16 * S2D_CPAD), dtype=torch.float32, device=dev)
         self.stem = u
         if net.style == "imagenet":
             self.pool_hw = ((ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1)
@@ -579,7 +592,6 @@ class _Plan(object):
         self.wg_ws = torch.empty(min(16 * wmax * 4, 512 << 20), dtype=torch.uint8, device=dev)
         self._grad_pool = {}
         self._bwd_ready = False
-        import os
         self.wg_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and not os.environ.get("IIF_NO_WGRAD_STREAM")) else None
         self._wg_events = {}
 
@@ -590,6 +602,8 @@ class _Plan(object):
         u.n, u.ho, u.wo = n, ho, wo
         u.hi, u.wi = src.shape[1], src.shape[2]
         u.is_patch_gemm = patch
+        u.s2d = False
+        u.geom = (1, 1, 0) if patch else (conv.k, conv.stride, conv.pad)   # geometry the MFMA kernels see
         u.x = torch.empty((n, ho, wo, conv.cout), dtype=dt, device=dev)
         u.y = torch.empty((n, ho, wo, conv.cout), dtype=dt, device=dev) if need_y else None
         u.stats = torch.empty((4, conv.cout), dtype=torch.float32, device=dev)
@@ -614,6 +628,9 @@ class _Plan(object):
     def prepare_weights(self, need_transposed):
         for u in self.units:
             cv = u.conv
+            if u.s2d:
+                ops.stem_s2d_pack(cv._w2d, cv.cout, cv.cin, cv.k, S2D_CPAD, u.w)
+                continue
             if cv.groups > 1:
                 ops.group_pack(cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.w)
                 if need_transposed:
@@ -637,7 +654,7 @@ class _Plan(object):
     # ---------------------------------------------------------------- forward
     def _conv_bn(self, u, training):
         cv = u.conv
-        k, st, pd = (1, 1, 0) if u.is_patch_gemm else (cv.k, cv.stride, cv.pad)
+        k, st, pd = u.geom
         m = u.n * u.ho * u.wo
         x2 = u.x.view(m, cv.cout)
         if training and self.dt == torch.bfloat16 and cv.cout % 8 == 0:
@@ -646,7 +663,7 @@ class _Plan(object):
             ops.bn_finalize_stats(self.bn_partial, nt, m, cv.cout, u.bn.weight, u.bn.bias, u.bn.running_mean,
                                   u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM, scratch=self.bn_scratch)
             return x2
-        ops.conv_forward(u.src, u.w, k, k, st, pd, out=u.x, groups=u.groups)
+        ops.conv_forward(u.src, u.w, k, k, st, pd, out=u.x, groups=u.groups, out_hw=(u.ho, u.wo))
         if training:
             ops.bn_forward_stats(x2, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var, u.stats, self.bn_ws,
                                  BN_EPS, BN_MOMENTUM)
@@ -658,7 +675,10 @@ class _Plan(object):
         net = self.net
         self.prepare_weights(training)
         c1 = net.conv1
-        ops.im2col_nchw(img, c1.k, c1.k, c1.stride, c1.pad, c1.ldw, self.dt, out=self.patches)
+        if self.stem_s2d:
+            ops.space_to_depth_nchw(img, S2D_CPAD, self.patches)
+        else:
+            ops.im2col_nchw(img, c1.k, c1.k, c1.stride, c1.pad, c1.ldw, self.dt, out=self.patches)
         u = self.stem
         x2 = self._conv_bn(u, training)
         ops.bn_apply(x2, u.stats, u.y.view(x2.shape), relu=True, relu_bits=u.bits)
@@ -764,6 +784,12 @@ class _Plan(object):
             ops.bn_backward(g2, None if mask is None else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats, bn.weight,
                             bn._dgamma, bn._dbeta, dx, self.bn_ws, relu_bits=None if mask is None else u.bits)
         dx4 = dx.view(u.n, u.ho, u.wo, cv.cout)
+        if u.s2d:
+            def stem():
+                ops.conv_wgrad(u.src, dx4, 4, 4, 1, 2, ldw=u.dwp.shape[1], out=u.dwp, workspace=self.wg_ws)
+                ops.stem_s2d_unpack_grad(u.dwp, cv.cout, cv.cin, cv.k, S2D_CPAD, cv._g2d)
+            self._wgrad_async(stem)
+            return None
         if u.is_patch_gemm:
             self._wgrad_async(lambda: ops.conv_wgrad(u.src, dx4, 1, 1, 1, 0, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws))
             return None

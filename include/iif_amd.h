@@ -286,6 +286,19 @@ int iif_group_pack(const float* master, int channels, int cg, int chunk, int rs,
 int iif_group_unpack_grad(const float* packed, int channels, int cg, int chunk, int rs, int ldp,
                           int ldm, float* master, void* stream);
 
+/* Stem as a space-to-depth convolution: the RxR / stride-2 / pad-(R-1)/2 convolution on a c-channel
+ * NCHW fp32 image (resnet_pytorch.py:203: 7x7/2 on 3 channels) equals an AxA / stride-1 / pad-A/2
+ * convolution, A = (R+1)/2, on the 2x2 space-to-depth image [n, h/2, w/2, cpad] (channel (di*2+dj)*c + ch,
+ * zero padded to cpad), with output grid h/2 x w/2.  No patch matrix is written.
+ * iif_space_to_depth_nchw builds that image, iif_stem_s2d_pack the [k][A*A*cpad] weight rows from the
+ * master [k][ldm] (r, s, c) rows, iif_stem_s2d_unpack_grad maps the weight gradient back. */
+int iif_space_to_depth_nchw(const float* img, int n, int c, int h, int w, int cpad, int out_dtype,
+                            void* out, void* stream);
+int iif_stem_s2d_pack(const float* master, int k, int c, int r, int ldm, int cpad, int out_dtype,
+                      void* out, void* stream);
+int iif_stem_s2d_unpack_grad(const float* packed, int k, int c, int r, int cpad, int ldm, float* master,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

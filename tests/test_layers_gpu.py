@@ -208,3 +208,34 @@ def test_fused_sgd_matches_torch_optim():
             ops.sgd_step(pd, gr.to(DEV), bd, lr, 0.9, 1e-4, nesterov)
         assert (pd.cpu() - q.detach()).abs().max().item() <= 1e-6
         assert (pd.cpu() - ref_p[0]).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_stem_space_to_depth_equals_7x7_stride2_conv(dt):
+    """The s2d formulation of the ImageNet stem (4x4/1 conv on the 2x2 space-to-depth image) reproduces
+    conv2d(7x7, stride 2, pad 3) forward and its weight gradient."""
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(8)
+    n, hw, cout, cpad = 3, 32, 64, 32
+    img = torch.randn(n, 3, hw, hw, generator=g)
+    w = (torch.randn(cout, 3, 7, 7, generator=g) * 0.1).to(dt).float()
+    ref = F.conv2d(img.to(dt).float(), w, None, 2, 3)
+    master = torch.zeros(cout, 160)
+    master[:, :147] = w.permute(0, 2, 3, 1).reshape(cout, 147)
+    x2 = torch.empty(n, hw // 2, hw // 2, cpad, dtype=dt, device=DEV)
+    ops.space_to_depth_nchw(img.to(DEV), cpad, x2)
+    wp = torch.empty(cout, 16 * cpad, dtype=dt, device=DEV)
+    ops.stem_s2d_pack(master.to(DEV), cout, 3, 7, cpad, wp)
+    y = ops.conv_forward(x2, wp, 4, 4, 1, 2, out_hw=(hw // 2, hw // 2))
+    got = nchw(y.float().cpu())
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= tol_for(dt) * ref.abs().max().item()
+    dy = torch.randn(ref.shape, generator=g).to(dt).float()
+    refdw = torch.nn.grad.conv2d_weight(img.to(dt).float(), w.shape, dy, 2, 3).permute(0, 2, 3, 1).reshape(cout, 147)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    dwp = ops.conv_wgrad(x2, nhwc(dy).to(dt).to(DEV), 4, 4, 1, 2, ldw=16 * cpad, workspace=ws)
+    dwm = torch.zeros(cout, 160, device=DEV)
+    ops.stem_s2d_unpack_grad(dwp, cout, 3, 7, cpad, dwm)
+    wtol = 2e-5 if dt == torch.float32 else 1e-4
+    assert (dwm[:, :147].cpu() - refdw).abs().max().item() <= wtol * refdw.abs().max().item()
+    assert (dwm[:, 147:] == 0).all()
