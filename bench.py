@@ -168,17 +168,23 @@ def main():
     ap.add_argument("--per-shape", action="store_true", help="print the per-shape conv table to stderr")
     ap.add_argument("--trace-loss", action="store_true", help="record the loss of every step (one tiny copy per step)")
     ap.add_argument("--force-reducer", action="store_true", help="drive the bucketed all-reduce path even with one rank")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the measured path); gloo only to rehearse N ranks on one GPU")
+    ap.add_argument("--device-index", type=int, default=None, help="put every rank on this GPU (rehearsal only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) if args.device_index is None else args.device_index
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or (args.force_reducer and "RANK" in os.environ):
-        dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -254,7 +260,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "images/sec ResNet50+IIF ImageNet-LT bs=256/GPU",
+            "metric": ("images/sec ResNet50+IIF ImageNet-LT bs=256/GPU" if (args.model, B, C, args.image) == ("resnet50", 256, 1000, 224)
+                       else "images/sec %s+IIF C=%d %dx%d bs=%d/GPU" % (args.model, C, args.image, args.image, B)),
             "value": round(B * world * args.steps / dt, 2),
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
