@@ -52,7 +52,7 @@ class ConvTimer(object):
     launch goes to: the kernels are enqueued on torch's current stream)."""
 
     def __init__(self):
-        self.records = []      # (kind, flops, start_event, stop_event)
+        self.records = []      # (kind, flops, ideal_bytes, start_event, stop_event)
         self.shapes = []
 
     def wrap(self, ops):
@@ -70,22 +70,33 @@ class ConvTimer(object):
             ho, wo = out_hw or ops.conv_out_hw(h, wd, r, s, stride, pad)
             return 2.0 * n * ho * wo * w.shape[0] * alg_k(r, s, stride, pad, cin) / groups
 
+        def nbytes(*ts):
+            # ideal HBM bytes of a launch: every operand / result tensor moved exactly once
+            return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
+
         def conv_forward(x, w, r, s, stride, pad, **kw):
-            return timer._timed("fwd", flops_fwd(x, w, r, s, stride, pad, **kw), orig["conv_forward"], x, w, r, s, stride, pad, **kw)
+            n, h, wd, _ = x.shape
+            ho, wo = kw.get("out_hw") or ops.conv_out_hw(h, wd, r, s, stride, pad)
+            out_b = n * ho * wo * w.shape[0] * (kw["out"].element_size() if kw.get("out") is not None else x.element_size())
+            by = nbytes(x, w, kw.get("res")) + out_b
+            return timer._timed("fwd", flops_fwd(x, w, r, s, stride, pad, **{k: v for k, v in kw.items() if k in ("groups", "out_hw")}),
+                                by, orig["conv_forward"], x, w, r, s, stride, pad, **kw)
 
         def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, **kw):
             n, ho, wo, cout = dy.shape
             fl = 2.0 * n * ho * wo * cout * r * s * wt.shape[0] / kw.get("groups", 1)
-            return timer._timed("dgrad", fl, orig["conv_dgrad"], dy, wt, r, s, stride, pad, in_hw, **kw)
+            by = nbytes(dy, wt, kw.get("res")) + n * in_hw[0] * in_hw[1] * wt.shape[0] * dy.element_size()
+            return timer._timed("dgrad", fl, by, orig["conv_dgrad"], dy, wt, r, s, stride, pad, in_hw, **kw)
 
         def conv_wgrad(x, dy, r, s, stride, pad, **kw):
             n, ho, wo, cout = dy.shape
             fl = 2.0 * n * ho * wo * cout * alg_k(r, s, stride, pad, x.shape[3]) / kw.get("groups", 1)
-            return timer._timed("wgrad", fl, orig["conv_wgrad"], x, dy, r, s, stride, pad, **kw)
+            by = nbytes(x, dy) + 4.0 * cout * r * s * x.shape[3] / kw.get("groups", 1)
+            return timer._timed("wgrad", fl, by, orig["conv_wgrad"], x, dy, r, s, stride, pad, **kw)
 
         def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial, **kw):
             fl = flops_fwd(x, w, r, s, stride, pad, out_hw=(out.shape[1], out.shape[2]), **kw)
-            return timer._timed("fwd", fl, orig["conv_forward_bnstats"], x, w, r, s, stride, pad, out, partial, **kw)
+            return timer._timed("fwd", fl, nbytes(x, w, out), orig["conv_forward_bnstats"], x, w, r, s, stride, pad, out, partial, **kw)
 
         ops.conv_forward, ops.conv_dgrad, ops.conv_wgrad = conv_forward, conv_dgrad, conv_wgrad
         ops.conv_forward_bnstats = conv_forward_bnstats
@@ -95,31 +106,53 @@ class ConvTimer(object):
         for k, v in self._orig.items():
             setattr(self._ops, k, v)
 
-    def _timed(self, kind, flops, fn, *a, **kw):
+    def _timed(self, kind, flops, ideal_bytes, fn, *a, **kw):
         self.shapes.append("%s %s x %s k%s s%s" % (kind, tuple(a[0].shape), tuple(a[1].shape), a[2], a[4]))
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         out = fn(*a, **kw)
         e1.record()
-        self.records.append((kind, flops, e0, e1))
+        self.records.append((kind, flops, ideal_bytes, e0, e1))
         return out
 
     def per_shape(self):
         agg = {}
-        for (kind, fl, e0, e1), sh in zip(self.records, self.shapes):
+        for (kind, fl, _by, e0, e1), sh in zip(self.records, self.shapes):
             a = agg.setdefault(sh, [0, 0.0, 0.0])
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
         return agg
 
     def summary(self):
         tot_ms, tot_fl, by = 0.0, 0.0, {}
-        for kind, fl, e0, e1 in self.records:
+        self.sol_ms = 0.0      # sum over launches of max(MFMA time at peak, HBM time at peak)
+        for kind, fl, nb, e0, e1 in self.records:
             ms = e0.elapsed_time(e1)
             tot_ms += ms; tot_fl += fl
+            self.sol_ms += 1e3 * max(fl / (MFMA_BF16_PEAK_TFLOPS * 1e12), nb / (HBM_PEAK_GBS * 1e9))
             k = by.setdefault(kind, [0, 0.0, 0.0])
             k[0] += 1; k[1] += ms; k[2] += fl
         return tot_ms, tot_fl, by
+
+
+def profiled_traffic():
+    """HBM bytes per launch of the convolution family from the committed rocprofv3 PMC passes
+    (profiles/r1_*_pmc_hbm_traffic.csv: FETCH_SIZE x2 + WRITE_SIZE of the same bench command, collected in
+    separate --pmc runs; counters cannot be read from inside the timed run).  None if no summary is there."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")))
+    if not files:
+        return None
+    mb, launches = 0.0, 0.0
+    with open(files[-1]) as f:
+        for row in csv.reader(f):
+            if len(row) >= 5 and ("conv_igemm" in row[0] or "conv_wgrad" in row[0]):
+                mb += float(row[4]); launches += float(row[1])
+    if launches <= 0:
+        return None
+    return {"MB_per_launch": round(mb / launches, 1), "GB_per_step": round(mb / 1e3, 2),
+            "source": os.path.relpath(files[-1], ROOT)}
 
 
 def cpu_baseline(counts, sample_bs, steps):
@@ -280,9 +313,13 @@ def main():
             nl = len(timer.records)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_kernel + conv_wgrad_kernel (implicit-GEMM convolution family)",
+                "bound": "mfma", "kernel": "conv_igemm_dma*_kernel + conv_wgrad_dma_kernel (implicit-GEMM convolution family)",
                 "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                "traffic": profiled_traffic() if (args.model, B, C, args.image, args.dtype) == ("resnet50", 256, 1000, 224, "bf16") else None,
+                # shape-aware speed of light: per launch max(FLOPs / MFMA peak, ideal bytes / HBM peak)
+                "sol_ms_per_step": round(timer.sol_ms / max(args.steps, 1), 3),
+                "frac_of_shape_sol": round(timer.sol_ms / tot_ms, 4) if tot_ms > 0 else None,
                 "launches_per_step": nl // max(args.steps, 1),
                 "avg_launch_us": round(1000.0 * tot_ms / max(nl, 1), 2),
                 "algorithmic_gflop_per_step": round(tot_fl / max(args.steps, 1) / 1e9, 1),
