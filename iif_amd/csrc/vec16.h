@@ -1,0 +1,30 @@
+// 16-byte channel vectors of an NHWC row: 4 fp32 or 8 bf16 values, widened to fp32 in registers.
+#pragma once
+#include "common.h"
+
+namespace {
+template <typename T> struct VT;
+template <> struct VT<float> {
+    static constexpr int V = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+};
+template <> struct VT<unsigned short> {
+    static constexpr int V = 8;
+    static __device__ __forceinline__ void load(const unsigned short* p, float (&v)[8]) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_bits_to_f32(t[i] & 0xffffu); v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(unsigned short* p, const float (&v)[8]) {
+        u32x4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        *reinterpret_cast<u32x4*>(p) = t;
+    }
+};
+}  // namespace

@@ -263,3 +263,31 @@ def stem_s2d_unpack_grad(packed, k, c, r, cpad, master_grad):
     check(lib().iif_stem_s2d_unpack_grad(ptr(packed), k, c, r, cpad, master_grad.shape[1], ptr(master_grad), stream_ptr()),
           "iif_stem_s2d_unpack_grad")
     return master_grad
+
+
+# ------------------------------------------------------------ squeeze-and-excitation
+def se_squeeze(x, sums):
+    """x [N,H,W,C] raw conv output -> sums [N,C] fp32 over H*W."""
+    n, h, w, c = x.shape
+    check(lib().iif_se_squeeze(ptr(x), dtype_code(x), n, h * w, c, ptr(sums), stream_ptr()), "iif_se_squeeze")
+    return sums
+
+
+def se_apply(x, stats, excite, y, relu_bits, residual=None, residual_stats=None):
+    n, h, w, c = x.shape
+    check(lib().iif_se_apply(ptr(x), dtype_code(x), n, h * w, c, ptr(stats), ptr(excite), ptr(residual),
+                             ptr(residual_stats), ptr(y), ptr(relu_bits), stream_ptr()), "iif_se_apply")
+    return y
+
+
+def se_backward_sums(g, relu_bits, x, s1, s2):
+    n, h, w, c = x.shape
+    check(lib().iif_se_backward_sums(ptr(g), ptr(relu_bits), ptr(x), dtype_code(x), n, h * w, c, ptr(s1), ptr(s2),
+                                     stream_ptr()), "iif_se_backward_sums")
+
+
+def se_backward_form(g, excite, offset, out):
+    n, h, w, c = g.shape
+    check(lib().iif_se_backward_form(ptr(g), dtype_code(g), n, h * w, c, ptr(excite), ptr(offset), ptr(out), stream_ptr()),
+          "iif_se_backward_form")
+    return out

@@ -108,10 +108,30 @@ class NormedLinearParam(nn.Module):
         self.bias = nn.Parameter(torch.empty(out_features))
 
 
+class SELinearParam(nn.Module):
+    """Bias-free linear of an SE block (nn.Linear(c, c // r, bias=False), resnet_pytorch.py:306-310)."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+
+
+class SEParam(nn.Module):
+    """SE_Block (resnet_pytorch.py:301-317, r=16; resnet_cifar.py:89-106, r=4): parameters under the
+    reference's names ``se.excitation.0.weight`` / ``se.excitation.2.weight``."""
+
+    def __init__(self, c, r):
+        super().__init__()
+        self.c, self.hidden = c, c // r
+        self.excitation = nn.Sequential(SELinearParam(c, c // r), nn.Identity(), SELinearParam(c // r, c), nn.Identity())
+
+
 class BlockParam(nn.Module):
     """conv/bn pairs of one residual block, registered in the reference's order."""
 
-    def __init__(self, kind, inplanes, planes, stride, width, out_planes, downsample, shortcut_a=False, groups=1):
+    def __init__(self, kind, inplanes, planes, stride, width, out_planes, downsample, shortcut_a=False, groups=1,
+                 se_reduction=0):
         super().__init__()
         self.kind, self.stride, self.shortcut_a = kind, stride, shortcut_a
         self.inplanes, self.out_planes = inplanes, out_planes
@@ -126,6 +146,7 @@ class BlockParam(nn.Module):
             self.downsample = nn.Sequential(ConvParam(inplanes, out_planes, 1, stride, 0), BNParam(out_planes))
         else:
             self.downsample = None
+        self.se = SEParam(out_planes, se_reduction) if se_reduction else None
 
     def units(self):
         if self.kind == "bottleneck":
@@ -138,7 +159,7 @@ class NativeResNet(nn.Module):
     """ImageNet-style (``style='imagenet'``) or CIFAR-style (``style='cifar'``) ResNet."""
 
     def __init__(self, style, block, layers, num_classes, groups=1, width_per_group=64, device="cuda",
-                 compute_dtype=torch.bfloat16, zero_init_residual=False, use_norm=None):
+                 compute_dtype=torch.bfloat16, zero_init_residual=False, use_norm=None, se=False):
         super().__init__()
         assert compute_dtype in (torch.bfloat16, torch.float32)
         self.style, self.block_kind = style, block
@@ -159,7 +180,7 @@ class NativeResNet(nn.Module):
                     width = int(planes * (width_per_group / 64.0)) * groups
                     ds = b == 0 and (stride != 1 or inpl != planes * exp)
                     blocks.append(BlockParam(block, inpl, planes, stride, width, planes * exp, ds,
-                                             groups=groups if block == "bottleneck" else 1))
+                                             groups=groups if block == "bottleneck" else 1, se_reduction=16 if se else 0))
                     inpl = planes * exp
                 stages.append(nn.Sequential(*blocks))
             self.layer1, self.layer2, self.layer3, self.layer4 = stages
@@ -174,7 +195,8 @@ class NativeResNet(nn.Module):
                 for b in range(nb):
                     stride = 2 if (b == 0 and li > 0) else 1
                     sa = stride != 1 or inpl != planes
-                    blocks.append(BlockParam("basic", inpl, planes, stride, planes, planes, False, shortcut_a=sa))
+                    blocks.append(BlockParam("basic", inpl, planes, stride, planes, planes, False, shortcut_a=sa,
+                                             se_reduction=4 if se else 0))
                     inpl = planes
                 stages.append(nn.Sequential(*blocks))
             self.layer1, self.layer2, self.layer3 = stages
@@ -216,6 +238,11 @@ class NativeResNet(nn.Module):
                 with torch.no_grad():
                     m.weight.uniform_(-1, 1).renorm_(2, 1, 1e-5).mul_(1e5)
                     m.bias.normal_()
+            elif isinstance(m, SELinearParam):
+                if self.style == "imagenet":      # nn.Linear default (the init loop :221-226 skips Linear)
+                    nn.init.kaiming_uniform_(m.weight, a=math.sqrt(5))
+                else:                             # _weights_init, resnet_cifar.py:33-36
+                    nn.init.kaiming_normal_(m.weight)
             elif isinstance(m, LinearParam):
                 if self.style == "imagenet":      # nn.Linear default
                     nn.init.kaiming_uniform_(m.weight, a=math.sqrt(5))
@@ -237,6 +264,8 @@ class NativeResNet(nn.Module):
             elif isinstance(m, BNParam):
                 specs.append((m, "weight", 1, m.num_features))
                 specs.append((m, "bias", 1, m.num_features))
+            elif isinstance(m, SELinearParam):
+                specs.append((m, "weight", m.out_features, m.in_features))
             elif isinstance(m, LinearParam):
                 specs.append((m, "weight", m.out_padded, m.in_features))
                 specs.append((m, "bias", 1, m.out_padded))
@@ -265,6 +294,9 @@ class NativeResNet(nn.Module):
                 old = getattr(m, attr)
                 if isinstance(m, ConvParam):
                     view = flat[:, :m.kdim].view(m.cout, m.k, m.k, m.cg).permute(0, 3, 1, 2)
+                    m._w2d = flat
+                elif isinstance(m, SELinearParam):
+                    view = flat
                     m._w2d = flat
                 elif isinstance(m, LinearParam):
                     if attr == "weight":
@@ -319,6 +351,9 @@ class NativeResNet(nn.Module):
             gflat = self._grad_arena[o2:o2 + rows * pitch].view(rows, pitch)
             if isinstance(m, ConvParam):
                 gv = gflat[:, :m.kdim].view(m.cout, m.k, m.k, m.cg).permute(0, 3, 1, 2)
+                m._g2d = gflat
+            elif isinstance(m, SELinearParam):
+                gv = gflat
                 m._g2d = gflat
             elif isinstance(m, LinearParam):
                 if attr == "weight":
@@ -549,6 +584,11 @@ class _Plan(object):
                     b["ds"] = du
                 elif blk.shortcut_a:
                     b["sc"] = E(n, last.ho, last.wo, blk.out_planes)
+                if blk.se is not None:
+                    Z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)   # noqa: E731
+                    c, hid = blk.se.c, blk.se.hidden
+                    b["se"] = {"sums": Z(n, c), "q": Z(n, c), "h": Z(n, hid), "e": Z(n, c), "s1": Z(n, c), "s2": Z(n, c),
+                               "o": Z(n, c)}
                 self.blocks.append(b)
                 cur = last.y
         self.final = cur
@@ -691,6 +731,9 @@ class _Plan(object):
                 ops.bn_apply(x2, uu.stats, uu.y.view(x2.shape), relu=True, relu_bits=uu.bits)
             last = units[-1]
             x2 = self._conv_bn(last, training)
+            if "se" in b:
+                self._se_forward(b, last, training)
+                continue
             if "ds" in b:
                 du = b["ds"]
                 xd = self._conv_bn(du, training)
@@ -724,6 +767,48 @@ class _Plan(object):
                          out=self.logits.view(self.n, 1, 1, head.out_padded), bias=bias)
         if training:
             net._nbt += 1
+
+    def _se_forward(self, b, last, training):
+        """y = relu(bn(x) * e + identity), e = sigmoid(W2 relu(W1 mean_hw(bn(x)))) — SEBottleneck.forward
+        (resnet_pytorch.py:358-381) / Se_Block.forward (resnet_cifar.py:163-169).  The squeeze and the
+        rescale are native streaming kernels; the [N, C]-sized excitation is two rocBLAS GEMMs in fp32."""
+        se, P = b["blk"].se, b["se"]
+        w1, w2 = se.excitation[0]._w2d, se.excitation[2]._w2d
+        ops.se_squeeze(last.x, P["sums"])
+        # mean_hw(a*x + b) = a * mean_hw(x) + b
+        torch.addcmul(last.stats[3], P["sums"], last.stats[2], value=1.0 / (last.ho * last.wo), out=P["q"])
+        torch.mm(P["q"], w1.t(), out=P["h"])
+        P["h"].relu_()
+        torch.mm(P["h"], w2.t(), out=P["e"])
+        P["e"].sigmoid_()
+        res, rstats = b["inp"], None
+        if "ds" in b:
+            du = b["ds"]
+            self._conv_bn(du, training)
+            res, rstats = du.x, du.stats
+        elif "sc" in b:
+            ops.shortcut_a_forward(b["inp"], b["blk"].out_planes, out=b["sc"])
+            res = b["sc"]
+        ops.se_apply(last.x, last.stats, P["e"], last.y, last.bits, residual=res, residual_stats=rstats)
+
+    def _se_backward(self, b, last, g, par):
+        """g: gradient w.r.t. the block output.  Masks g in place (it then is the identity-path gradient)
+        and returns G = d(loss)/d(bn output) = g*e + d(squeeze)/HW, to be fed to the BN backward."""
+        se, P = b["blk"].se, b["se"]
+        l1, l2 = se.excitation[0], se.excitation[2]
+        hw = last.ho * last.wo
+        ops.se_backward_sums(g, last.bits, last.x, P["s1"], P["s2"])
+        # d e[n,c] = sum_hw g * (a*x + b) = a*S2 + b*S1;  back through sigmoid / linear / relu / linear
+        de = torch.addcmul(P["s1"] * last.stats[3], P["s2"], last.stats[2])
+        dz2 = de * P["e"] * (1.0 - P["e"])
+        torch.mm(dz2.t(), P["h"], out=l2._g2d)
+        dz1 = torch.mm(dz2, l2._w2d) * (P["h"] > 0)
+        torch.mm(dz1.t(), P["q"], out=l1._g2d)
+        torch.mm(dz1, l1._w2d, out=P["o"])
+        P["o"].mul_(1.0 / hw)
+        m = last.n * hw
+        G = self._gbuf(("dx", m, last.conv.cout, par), (m, last.conv.cout)).view(last.n, last.ho, last.wo, last.conv.cout)
+        return ops.se_backward_form(g, P["e"], P["o"], G)
 
     def _maxpool_fwd(self, y):
         n, h, w, c = y.shape
@@ -869,8 +954,13 @@ class _Plan(object):
             par = bi & 1
             self._wgrad_fence(bi)
             gin = self._gbuf(("gin", tuple(inp.shape), bi % 3), inp.shape)
-            d = self._unit_backward(last, g, last.y, gmasked=g, par=par,
-                                    dgrad_out=self._gbuf(("d", tuple(last.src.shape), len(units) - 1, par), last.src.shape))
+            if "se" in b:
+                G = self._se_backward(b, last, g, par)
+                d = self._unit_backward(last, G, None, par=par,
+                                        dgrad_out=self._gbuf(("d", tuple(last.src.shape), len(units) - 1, par), last.src.shape))
+            else:
+                d = self._unit_backward(last, g, last.y, gmasked=g, par=par,
+                                        dgrad_out=self._gbuf(("d", tuple(last.src.shape), len(units) - 1, par), last.src.shape))
             for ui in range(len(units) - 2, 0, -1):
                 uu = units[ui]
                 d = self._unit_backward(uu, d, uu.y, par=par,

@@ -14,7 +14,8 @@ import torch
 from .resnet_engine import NativeResNet
 
 __all__ = ["ResNet", "resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "wide_resnet50_2",
-           "wide_resnet101_2", "resnext50_32x4d", "resnext101_32x4d", "resnext101_32x8d"]
+           "wide_resnet101_2", "resnext50_32x4d", "resnext101_32x4d", "resnext101_32x8d", "se_resnet50", "se_resnet152",
+           "se_resnext50_32x4d"]
 
 
 def _absent(v):
@@ -23,11 +24,15 @@ def _absent(v):
 
 def ResNet(block, layers, use_norm=None, num_classes=1000, zero_init_residual=False, groups=1, width_per_group=64,
            device="cuda", compute_dtype=torch.bfloat16):
+    """``block``: "basic", "bottleneck" or "se_bottleneck" (SEBottleneck, resnet_pytorch.py:320-381)."""
+    se = block == "se_bottleneck"
+    block = "bottleneck" if se else block
     un = None if _absent(use_norm) else use_norm
     if un not in (None, "cosine", "lr_cosine", "norm"):
         un = None                       # the reference falls through to nn.Linear for any other string
     return NativeResNet("imagenet", block, list(layers), num_classes, groups=groups, width_per_group=width_per_group,
-                        device=device, compute_dtype=compute_dtype, zero_init_residual=zero_init_residual, use_norm=un)
+                        device=device, compute_dtype=compute_dtype, zero_init_residual=zero_init_residual, use_norm=un,
+                        se=se)
 
 
 def _resnet(block, layers, pretrained, use_norm, **kwargs):
@@ -94,3 +99,20 @@ def resnext101_32x4d(pretrained=None, progress=True, use_norm=None, **kw):
 def resnext101_32x8d(pretrained=None, progress=True, use_norm=None, **kw):
     kw["groups"], kw["width_per_group"] = 32, 8
     return _resnet("bottleneck", [3, 4, 23, 3], pretrained, use_norm, **kw)
+
+
+def se_resnet50(pretrained=None, progress=True, use_norm=None, **kw):
+    """resnet_pytorch.py:537-539."""
+    return _resnet("se_bottleneck", [3, 4, 6, 3], pretrained, use_norm, **kw)
+
+
+def se_resnet152(pretrained=None, progress=True, use_norm=None, **kw):
+    """resnet_pytorch.py:472-480."""
+    return _resnet("se_bottleneck", [3, 8, 36, 3], pretrained, use_norm, **kw)
+
+
+def se_resnext50_32x4d(pretrained=None, progress=True, use_norm=None, **kw):
+    """resnet_pytorch.py:542-551."""
+    kw["groups"] = 32
+    kw["width_per_group"] = 4
+    return _resnet("se_bottleneck", [3, 4, 6, 3], pretrained, use_norm, **kw)

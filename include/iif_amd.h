@@ -299,6 +299,25 @@ int iif_stem_s2d_pack(const float* master, int k, int c, int r, int ldm, int cpa
 int iif_stem_s2d_unpack_grad(const float* packed, int k, int c, int r, int cpad, int ldm, float* master,
                              void* stream);
 
+/* Squeeze-and-excitation around the last BN of a residual block (SE_Block.forward,
+ * classification/resnet_pytorch.py:313-317 / resnet_cifar.py:102-106, inside SEBottleneck.forward :358-381
+ * and Se_Block.forward resnet_cifar.py:163-169).  x is the raw convolution output [n, hw, c] (NHWC), stats
+ * the BN stats block (scale at [2c], shift at [3c]), excite / offset fp32 [n, c].
+ *   iif_se_squeeze        sums[n,c] = sum_hw x
+ *   iif_se_apply          y = relu((a*x + b) * excite[n,c] + identity), identity = residual or
+ *                         a2*residual + b2 (residual_stats), relu_bits = 1 bit per element
+ *   iif_se_backward_sums  g <- g * [y > 0] in place; s1[n,c] = sum_hw g; s2[n,c] = sum_hw g*x
+ *   iif_se_backward_form  out = g * excite[n,c] + offset[n,c]  (gradient w.r.t. the BN output)
+ * The [n, c]-sized excitation (two bias-free linears, ReLU, sigmoid) is host-side plumbing. */
+int iif_se_squeeze(const void* x, int dtype, int n, int hw, int c, float* sums, void* stream);
+int iif_se_apply(const void* x, int dtype, int n, int hw, int c, const float* stats, const float* excite,
+                 const void* residual, const float* residual_stats, void* y, unsigned char* relu_bits,
+                 void* stream);
+int iif_se_backward_sums(void* g, const unsigned char* relu_bits, const void* x, int dtype, int n, int hw,
+                         int c, float* s1, float* s2, void* stream);
+int iif_se_backward_form(const void* g, int dtype, int n, int hw, int c, const float* excite,
+                         const float* offset, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

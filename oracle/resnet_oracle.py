@@ -32,9 +32,20 @@ IMAGENET_ARCHS = {
     "resnext101_32x4d": ("bottleneck", (3, 4, 23, 3), 32, 4),
     "resnext101_32x8d": ("bottleneck", (3, 4, 23, 3), 32, 8),
     "wide_resnet50_2": ("bottleneck", (3, 4, 6, 3), 1, 128),
+    # squeeze-and-excitation variants (SEBottleneck, resnet_pytorch.py:320-381; ctors :472-551)
+    "se_resnet50": ("bottleneck", (3, 4, 6, 3), 1, 64),
+    "se_resnet152": ("bottleneck", (3, 8, 36, 3), 1, 64),
+    "se_resnext50_32x4d": ("bottleneck", (3, 4, 6, 3), 32, 4),
 }
 CIFAR_ARCHS = {"resnet20": (3, 3, 3), "resnet32": (5, 5, 5), "resnet44": (7, 7, 7),
-               "resnet56": (9, 9, 9), "resnet110": (18, 18, 18)}
+               "resnet56": (9, 9, 9), "resnet110": (18, 18, 18),
+               "se_resnet32": (5, 5, 5)}          # Se_Block, resnet_cifar.py:140-171, ctor :221-222
+SE_REDUCTION = 16                                 # SE_Block(c, r=16), resnet_pytorch.py:303
+SE_REDUCTION_CIFAR = 4                            # SE_Block(c, r=4), resnet_cifar.py:91
+
+
+def is_se(arch):
+    return arch.startswith("se_")
 
 
 # ------------------------------------------------------------------ parameters
@@ -86,6 +97,11 @@ def init_imagenet(arch, num_classes, seed=0):
             if b == 0 and (stride != 1 or inpl != planes * exp):
                 _conv_entry(sd, p + ".downsample.0.weight", planes * exp, inpl, 1, g, "fan_out")
                 _bn_entries(sd, p + ".downsample.1", planes * exp)
+            if is_se(arch):
+                # nn.Linear default init (bias=False); the init loop at :221-226 touches conv and BN only
+                c, h = planes * exp, planes * exp // SE_REDUCTION
+                sd[p + ".se.excitation.0.weight"] = torch.empty(h, c).uniform_(-1 / math.sqrt(c), 1 / math.sqrt(c), generator=g)
+                sd[p + ".se.excitation.2.weight"] = torch.empty(c, h).uniform_(-1 / math.sqrt(h), 1 / math.sqrt(h), generator=g)
             inpl = planes * exp
     bound = 1.0 / math.sqrt(inpl)
     sd["fc.weight"] = torch.empty(num_classes, inpl).uniform_(-bound, bound, generator=g)
@@ -109,6 +125,10 @@ def init_cifar(arch, num_classes, seed=0):
             _bn_entries(sd, p + ".bn1", planes)
             _conv_entry(sd, p + ".conv2.weight", planes, planes, 3, g, "fan_in")
             _bn_entries(sd, p + ".bn2", planes)
+            if is_se(arch):     # _weights_init (:33-36) re-initialises every nn.Linear: kaiming-normal, fan_in
+                h = planes // SE_REDUCTION_CIFAR
+                sd[p + ".se.excitation.0.weight"] = torch.empty(h, planes).normal_(0, math.sqrt(2.0 / planes), generator=g)
+                sd[p + ".se.excitation.2.weight"] = torch.empty(planes, h).normal_(0, math.sqrt(2.0 / h), generator=g)
             inpl = planes
     sd["linear.weight"] = torch.empty(num_classes, 64).normal_(0, math.sqrt(2.0 / 64), generator=g)
     bound = 1.0 / math.sqrt(64)
@@ -193,6 +213,15 @@ def head_forward(sd, prefix, x, head="linear", q=_id):
     raise ValueError(head)
 
 
+def _se(sd, p, o):
+    """SE_Block.forward, resnet_pytorch.py:313-317: squeeze (global mean), two bias-free linears with
+    ReLU / sigmoid, channel-wise rescale."""
+    y = o.mean(dim=(2, 3))
+    y = F.relu(F.linear(y, sd[p + ".se.excitation.0.weight"]))
+    y = torch.sigmoid(F.linear(y, sd[p + ".se.excitation.2.weight"]))
+    return o * y[:, :, None, None]
+
+
 def forward_imagenet(sd, x, arch, training=True, q=_id, head="linear"):
     """resnet_pytorch.py:279-295 (stem, 4 stages, GAP, fc); blocks :95-111 and
     :149-169 (stride on the 3x3 = v1.5).  ``q`` (identity by default) is applied
@@ -220,6 +249,8 @@ def forward_imagenet(sd, x, arch, training=True, q=_id, head="linear"):
                 o = q(_relu(_bn(sd, p + ".bn1", o, training))); _count_bn(sd, p + ".bn1", training)
                 o = q(F.conv2d(o, q(sd[p + ".conv2.weight"]), None, 1, 1))
                 o = _bn(sd, p + ".bn2", o, training); _count_bn(sd, p + ".bn2", training)
+            if is_se(arch):
+                o = _se(sd, p, o)
             if (p + ".downsample.0.weight") in sd:
                 idt = q(F.conv2d(x, q(sd[p + ".downsample.0.weight"]), None, stride))
                 idt = _bn(sd, p + ".downsample.1", idt, training)
@@ -245,6 +276,8 @@ def forward_cifar(sd, x, arch="resnet32", training=True, q=_id, head="linear"):
             o = q(_relu(_bn(sd, p + ".bn1", o, training))); _count_bn(sd, p + ".bn1", training)
             o = q(F.conv2d(o, q(sd[p + ".conv2.weight"]), None, 1, 1))
             o = _bn(sd, p + ".bn2", o, training); _count_bn(sd, p + ".bn2", training)
+            if is_se(arch):
+                o = _se(sd, p, o)
             sc = x
             if stride != 1 or inpl != planes:
                 sc = F.pad(x[:, :, ::2, ::2], (0, 0, 0, 0, planes // 4, planes // 4))

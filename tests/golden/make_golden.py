@@ -301,6 +301,19 @@ def g7_nets():
     return out
 
 
+# -------------------------------------------------------------------------- G10
+def g10_se():
+    """Squeeze-and-excitation variants (SEBottleneck / Se_Block) run from the reference's constructors."""
+    out = {}
+    c100 = O.img_num_per_cls(100, 50000, "exp", 0.01)
+    for k, v in _net_case("se_resnet32", 100, c100, 8, 32, 3, 0.1).items():
+        out["se_resnet32_" + k] = v
+    c1000 = COUNT_SETS["imagenet1000"]
+    for k, v in _net_case("se_resnet50", 1000, c1000, 2, 64, 2, 0.1).items():
+        out["se_resnet50_" + k] = v
+    return out
+
+
 # --------------------------------------------------------------------------- G9
 def g9_heads():
     """Classifier heads run from the reference's own forward code.  CosNorm_Classifier.__init__
@@ -358,7 +371,7 @@ def g8_warmup():
 
 def main():
     sets = {"g1_class_counts": g1_class_counts, "g2_class_map": g2_class_map, "g3_tables": g3_tables,
-            "g4_loss": g4_loss, "g7_nets": g7_nets, "g8_warmup": g8_warmup, "g9_heads": g9_heads}
+            "g4_loss": g4_loss, "g7_nets": g7_nets, "g8_warmup": g8_warmup, "g9_heads": g9_heads, "g10_se": g10_se}
     only = sys.argv[1:]
     if only:
         sets = {k: v for k, v in sets.items() if k in only}

@@ -239,3 +239,48 @@ def test_stem_space_to_depth_equals_7x7_stride2_conv(dt):
     wtol = 2e-5 if dt == torch.float32 else 1e-4
     assert (dwm[:, :147].cpu() - refdw).abs().max().item() <= wtol * refdw.abs().max().item()
     assert (dwm[:, 147:] == 0).all()
+
+
+@pytest.mark.parametrize("dt,n,hw,c,res", [(torch.float32, 3, 49, 64, 1), (torch.bfloat16, 2, 196, 256, 2), (torch.float32, 4, 64, 16, 0)])
+def test_se_kernels_against_torch(dt, n, hw, c, res):
+    """iif_se_squeeze / iif_se_apply / iif_se_backward_sums / iif_se_backward_form against their
+    definitions (SE_Block.forward, resnet_pytorch.py:313-317, around the block's last BN)."""
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(21)
+    h = int(hw ** 0.5)
+    x = torch.randn(n, h, h, c, generator=g).to(dt)
+    r = torch.randn(n, h, h, c, generator=g).to(dt)
+    stats = torch.randn(4, c, generator=g)
+    stats2 = torch.randn(4, c, generator=g)
+    e = torch.rand(n, c, generator=g)
+    xd, rd = x.to(DEV), r.to(DEV)
+    sums = torch.empty(n, c, device=DEV)
+    ops.se_squeeze(xd, sums)
+    ref_sums = x.float().sum(dim=(1, 2))
+    assert (sums.cpu() - ref_sums).abs().max().item() <= 1e-5 * max(1.0, ref_sums.abs().max().item())
+    y = torch.empty_like(xd)
+    bits = torch.empty(n * hw * c // (8 if dt == torch.bfloat16 else 4), dtype=torch.uint8, device=DEV)
+    ops.se_apply(xd, stats.to(DEV), e.to(DEV), y, bits, residual=rd if res else None,
+                 residual_stats=stats2.to(DEV) if res == 2 else None)
+    t = (x.float() * stats[2] + stats[3]) * e[:, None, None, :]
+    if res == 1:
+        t = t + r.float()
+    if res == 2:
+        t = t + r.float() * stats2[2] + stats2[3]
+    ref_y = t.clamp_min(0)
+    assert (y.float().cpu() - ref_y).abs().max().item() <= tol_for(dt) * max(1.0, ref_y.abs().max().item())
+    gy = torch.randn(n, h, h, c, generator=g).to(dt)
+    gd = gy.to(DEV).clone()
+    s1 = torch.empty(n, c, device=DEV)
+    s2 = torch.empty(n, c, device=DEV)
+    ops.se_backward_sums(gd, bits, xd, s1, s2)
+    mask = (y.float().cpu() > 0)
+    gm = gy.float() * mask
+    assert torch.equal(gd.float().cpu(), gm.to(dt).float())
+    assert (s1.cpu() - gm.sum(dim=(1, 2))).abs().max().item() <= 1e-4 * hw ** 0.5
+    assert (s2.cpu() - (gm * x.float()).sum(dim=(1, 2))).abs().max().item() <= 2e-4 * hw ** 0.5
+    off = torch.randn(n, c, generator=g)
+    out = torch.empty_like(gd)
+    ops.se_backward_form(gd, e.to(DEV), off.to(DEV), out)
+    ref_o = gm.to(dt).float() * e[:, None, None, :] + off[:, None, None, :]
+    assert (out.float().cpu() - ref_o).abs().max().item() <= tol_for(dt) * max(1.0, ref_o.abs().max().item())

@@ -89,15 +89,18 @@ def _checksum(sd):
     return np.array([float(v.double().sum()) for v in sd.values() if v.is_floating_point()])
 
 
-@pytest.mark.parametrize("prefix,arch,C,cname,B,hw", [
-    ("resnet32", "resnet32", 100, "cifar100_exp100", 8, 32),
-    ("resnet50", "resnet50", 1000, "imagenet1000", 2, 64),
-    ("resnext50", "resnext50_32x4d", 365, "places365", 2, 64),
+@pytest.mark.parametrize("fixture,prefix,arch,C,cname,B,hw", [
+    ("g7_nets", "resnet32", "resnet32", 100, "cifar100_exp100", 8, 32),
+    ("g7_nets", "resnet50", "resnet50", 1000, "imagenet1000", 2, 64),
+    ("g7_nets", "resnext50", "resnext50_32x4d", 365, "places365", 2, 64),
+    ("g10_se", "se_resnet32", "se_resnet32", 100, "cifar100_exp100", 8, 32),
+    ("g10_se", "se_resnet50", "se_resnet50", 1000, "imagenet1000", 2, 64),
 ])
-def test_g7_train_steps(golden, prefix, arch, C, cname, B, hw):
+def test_g7_train_steps(golden, fixture, prefix, arch, C, cname, B, hw):
     """Forward, IIF loss, backward and SGD(+warm-up) of the oracle reproduce the
-    reference model's logits, gradient norms, loss sequence and final weights."""
-    g, t = golden("g7_nets"), golden("g3_tables")
+    reference model's logits, gradient norms, loss sequence and final weights
+    (g10: the squeeze-and-excitation variants)."""
+    g, t = golden(fixture), golden("g3_tables")
     counts = t[cname + "_counts"].tolist()
     sd = (R.init_cifar if arch in R.CIFAR_ARCHS else R.init_imagenet)(arch, C, seed=7)
     if not np.allclose(_checksum(sd), g[prefix + "_init_checksum"], rtol=0, atol=1e-9):

@@ -68,7 +68,7 @@ def damp_residual_branches(sd, arch, factor=0.25):
 
 
 CASES = [("resnet32", 100, 8, 32), ("resnet20", 10, 5, 32), ("resnet50", 1000, 8, 64), ("resnet18", 365, 4, 96),
-         ("resnext50_32x4d", 365, 8, 64)]
+         ("resnext50_32x4d", 365, 8, 64), ("se_resnet32", 100, 8, 32), ("se_resnet50", 1000, 8, 64)]
 
 
 @pytest.mark.parametrize("arch,C,B,hw", CASES)
@@ -114,7 +114,8 @@ def test_fp32_forward_backward_parity(arch, C, B, hw):
     assert relerr(ev, ref_ev) <= 1e-4
 
 
-@pytest.mark.parametrize("arch,C,B,hw", [("resnet32", 100, 8, 32), ("resnet50", 1000, 8, 64), ("resnext50_32x4d", 365, 8, 64)])
+@pytest.mark.parametrize("arch,C,B,hw", [("resnet32", 100, 8, 32), ("resnet50", 1000, 8, 64), ("resnext50_32x4d", 365, 8, 64),
+                                         ("se_resnet32", 100, 8, 32), ("se_resnext50_32x4d", 365, 8, 64)])
 def test_fp32_loss_curve_fused_step(arch, C, B, hw):
     """forward -> fused IIF loss -> backward -> ONE fused SGD launch, 4 steps with
     the first-epoch warm-up (train.py:52-56): the loss sequence matches the CPU
@@ -144,7 +145,8 @@ def test_fp32_loss_curve_fused_step(arch, C, B, hw):
             assert relerr(v, ref_sd[k]) <= 2e-4, (k, relerr(v, ref_sd[k]))
 
 
-@pytest.mark.parametrize("arch,C,B,hw", [("resnet50", 1000, 8, 64), ("resnet32", 100, 16, 32), ("resnext50_32x4d", 365, 8, 64)])
+@pytest.mark.parametrize("arch,C,B,hw", [("resnet50", 1000, 8, 64), ("resnet32", 100, 16, 32), ("resnext50_32x4d", 365, 8, 64),
+                                         ("se_resnet50", 1000, 8, 64)])
 def test_bf16_mode_against_bf16_storage_oracle(arch, C, B, hw):
     """Performance mode (bf16 storage, fp32 accumulate).  The oracle run with
     ``q=bf16_storage`` rounds the same tensors at the same places, so what is left
