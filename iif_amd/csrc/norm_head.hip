@@ -64,6 +64,49 @@ __global__ void __launch_bounds__(256) rowmap_bwd_kernel(const TI* x, const floa
     for (int c = lane; c < cols; c += 64) HIO<TO>::st(o + c, HIO<TG>::ld(gr + c) * a - HIO<TI>::ld(xr + c) * b);
 }
 
+
+// mmdet normed predictors (instance_segmentation/mmdet/models/utils/normed_predictor.py:34-40, 67-73, 104-112):
+//   v = r[row] * x[row]  (r = per-row IIF weight, or 1);  n = |v|;  out = v * scale / (n^power + eps)
+// backward, g = dL/d(out):  dv = g*a - v*b,  a = scale/den,  b = scale*power*n^(power-2)*<g,v>/den^2;  dx = r*dv
+__global__ void __launch_bounds__(256) rownorm_fwd_kernel(const float* x, const float* rscale, int rows, int cols, int64_t ldx,
+                                                          float power, float scale, float eps, float* out, int64_t ldo,
+                                                          float* norms) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * ldx;
+    const float r = rscale ? rscale[row] : 1.0f;
+    float ss = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float v = xr[c] * r; ss = fmaf(v, v, ss); }
+    const float n = sqrtf(wave_sum(ss));
+    const float den = (power == 1.0f ? n : powf(n, power)) + eps;
+    const float coef = scale / den;
+    float* o = out + (int64_t)row * ldo;
+    for (int c = lane; c < cols; c += 64) o[c] = xr[c] * r * coef;
+    if (lane == 0) norms[row] = n;
+}
+
+__global__ void __launch_bounds__(256) rownorm_bwd_kernel(const float* x, const float* rscale, const float* norms, const float* g,
+                                                          int rows, int cols, int64_t ldx, int64_t ldg, float power, float scale,
+                                                          float eps, float* dx, int64_t lddx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * ldx;
+    const float* gr = g + (int64_t)row * ldg;
+    const float r = rscale ? rscale[row] : 1.0f;
+    float dot = 0.f;
+    for (int c = lane; c < cols; c += 64) dot = fmaf(gr[c], xr[c] * r, dot);
+    dot = wave_sum(dot);
+    const float n = norms[row];
+    const float den = (power == 1.0f ? n : powf(n, power)) + eps;
+    const float a = scale / den;
+    // d(n^p)/dv = p * n^(p-2) * v
+    const float b = n > 0.f ? scale * power * (power == 1.0f ? 1.0f / n : powf(n, power - 2.0f)) * dot / (den * den) : 0.f;
+    float* o = dx + (int64_t)row * lddx;
+    for (int c = lane; c < cols; c += 64) o[c] = r * (gr[c] * a - xr[c] * r * b);
+}
+
 __global__ void __launch_bounds__(256) transpose_f32_kernel(const float* in, int rows, int cols, int64_t ldi, float* out,
                                                             int64_t ldo) {
     __shared__ float tile[32][33];
@@ -132,6 +175,28 @@ int iif_rowmap_backward(const void* x, int x_dtype, const float* norms, const vo
     else if (x_dtype == IIF_F32 && g_dtype == IIF_BF16 && dx_dtype == IIF_F32) IIF_RB(float, unsigned short, float);
     else return IIF_EINVAL;
 #undef IIF_RB
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_rownorm_forward(const float* x, const float* row_scale, int rows, int cols, int64_t ldx, float power, float scale,
+                        float eps, float* out, int64_t ldo, float* norms, void* stream) {
+    if (rows < 0 || cols <= 0 || !(power > 0.f)) return IIF_EINVAL;
+    if (rows == 0) return IIF_OK;
+    if (!x || !out || !norms || ldx < cols || ldo < cols) return IIF_EINVAL;
+    hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, row_scale, rows, cols, ldx,
+                       power, scale, eps, out, ldo, norms);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_rownorm_backward(const float* x, const float* row_scale, const float* norms, const float* g, int rows, int cols,
+                         int64_t ldx, int64_t ldg, float power, float scale, float eps, float* dx, int64_t lddx, void* stream) {
+    if (rows < 0 || cols <= 0 || !(power > 0.f)) return IIF_EINVAL;
+    if (rows == 0) return IIF_OK;
+    if (!x || !norms || !g || !dx || ldx < cols || ldg < cols || lddx < cols) return IIF_EINVAL;
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, row_scale, norms, g, rows,
+                       cols, ldx, ldg, power, scale, eps, dx, lddx);
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }

@@ -291,3 +291,19 @@ def se_backward_form(g, excite, offset, out):
     check(lib().iif_se_backward_form(ptr(g), dtype_code(g), n, h * w, c, ptr(excite), ptr(offset), ptr(out), stream_ptr()),
           "iif_se_backward_form")
     return out
+
+
+# ------------------------------------------------------------ mmdet normed predictors
+def rownorm_forward(x, power, scale, eps, out, norms, row_scale=None):
+    rows, cols = x.shape
+    check(lib().iif_rownorm_forward(ptr(x), ptr(row_scale), rows, cols, x.stride(0), float(power), float(scale), float(eps),
+                                    ptr(out), out.stride(0), ptr(norms), stream_ptr()), "iif_rownorm_forward")
+    return out
+
+
+def rownorm_backward(x, norms, g, power, scale, eps, dx, row_scale=None):
+    rows, cols = x.shape
+    check(lib().iif_rownorm_backward(ptr(x), ptr(row_scale), ptr(norms), ptr(g), rows, cols, x.stride(0), g.stride(0),
+                                     float(power), float(scale), float(eps), ptr(dx), dx.stride(0), stream_ptr()),
+          "iif_rownorm_backward")
+    return dx

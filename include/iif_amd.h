@@ -318,6 +318,16 @@ int iif_se_backward_sums(void* g, const unsigned char* relu_bits, const void* x,
 int iif_se_backward_form(const void* g, int dtype, int n, int hw, int c, const float* excite,
                          const float* offset, void* out, void* stream);
 
+/* mmdet normed predictors (instance_segmentation/mmdet/models/utils/normed_predictor.py: NormedLinear :34-40,
+ * IIFNormedLinear :67-73, NormedConv2d with a 1x1 kernel :104-112), fp32:
+ *   v = row_scale[row] * x[row] (row_scale nullable = 1);  out = v * scale / (|v|^power + eps);  norms[row] = |v|
+ * backward: dx = d(out)/dx^T g.  The products run on iif_conv_igemm / iif_conv_wgrad. */
+int iif_rownorm_forward(const float* x, const float* row_scale, int rows, int cols, int64_t ldx, float power,
+                        float scale, float eps, float* out, int64_t ldo, float* norms, void* stream);
+int iif_rownorm_backward(const float* x, const float* row_scale, const float* norms, const float* g, int rows,
+                         int cols, int64_t ldx, int64_t ldg, float power, float scale, float eps, float* dx,
+                         int64_t lddx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,3 +71,22 @@ def accuracy_top1(pred, target):
     _, lbl = pred.topk(1, dim=1)
     correct = lbl.t().eq(target.view(1, -1))
     return correct[:1].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / pred.size(0))
+
+
+def normed_linear(x, weight, bias=None, temperature=20.0, power=1.0, eps=1e-6, iif_rows=None):
+    """mmdet/models/utils/normed_predictor.py: NormedLinear.forward :34-40; with ``iif_rows`` ([C] or [C,1])
+    IIFNormedLinear.forward :67-73 (rows of W scaled by the class's IIF weight before normalising)."""
+    w = weight if iif_rows is None else iif_rows.reshape(-1, 1) * weight
+    weight_ = w / (w.norm(dim=1, keepdim=True).pow(power) + eps)
+    x_ = x / (x.norm(dim=1, keepdim=True).pow(power) + eps)
+    x_ = x_ * temperature
+    return F.linear(x_, weight_, bias)
+
+
+def normed_conv2d_1x1(x, weight, bias=None, temperature=20.0, power=1.0, eps=1e-6):
+    """normed_predictor.py: NormedConv2d.forward :104-124 (norm over the channel dimension of every pixel
+    and of every filter), for the 1x1 predictor the mask head builds."""
+    weight_ = weight / (weight.norm(dim=1, keepdim=True).pow(power) + eps)
+    x_ = x / (x.norm(dim=1, keepdim=True).pow(power) + eps)
+    x_ = x_ * temperature
+    return F.conv2d(x_, weight_, bias)
