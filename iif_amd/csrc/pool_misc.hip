@@ -210,6 +210,35 @@ __global__ void __launch_bounds__(256) weight_transpose_kernel(const float* w, i
     }
 }
 
+// every dense convolution's transposed copy in ONE launch: a device table of per-tensor descriptors, each
+// block finds its tensor by binary search over the table's block prefix and writes 1024 output elements
+template <typename T>
+__global__ void __launch_bounds__(256) weight_transpose_batched_kernel(const float* arena, const iif_wt_desc* tab, int n, T* out) {
+    int lo = 0, hi = n - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].block_start <= b) lo = mid; else hi = mid - 1;
+    }
+    const iif_wt_desc d = tab[lo];
+    const float* w = arena + d.src_off;
+    T* wt = out + d.dst_off;
+    const int64_t total = (int64_t)d.cin * d.ldwt;
+    const int64_t base = (int64_t)(b - d.block_start) * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int col = (int)(i % d.ldwt), c = (int)(i / d.ldwt);
+        float v = 0.f;
+        if (col < d.rs * d.cout) {
+            const int tap = col / d.cout, k = col - tap * d.cout;
+            v = w[(int64_t)k * d.ldw + tap * d.cin + c];
+        }
+        PT<T>::store1(wt + i, v);
+    }
+}
+
 // ---------------------------------------------------------------- option-A shortcut (resnet_cifar.py:125-126)
 template <typename T>
 __global__ void __launch_bounds__(256) shortcut_a_fwd_kernel(const T* x, int N, int H, int W, int Cin, int Ho, int Wo,
@@ -389,6 +418,17 @@ int iif_weight_transpose(const float* w, int cout, int cin, int rs, int ldw, int
     IIF_BY_DTYPE(out_dtype,
         hipLaunchKernelGGL(weight_transpose_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, w, cout, cin, rs, ldw, ldwt, (float*)wt),
         hipLaunchKernelGGL(weight_transpose_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, w, cout, cin, rs, ldw, ldwt, (unsigned short*)wt))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_weight_transpose_batched(const float* arena, const iif_wt_desc* table, int n_desc, int total_blocks, int out_dtype,
+                                 void* out, void* stream) {
+    if (!arena || !table || !out || n_desc <= 0 || total_blocks <= 0) return IIF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    IIF_BY_DTYPE(out_dtype,
+        hipLaunchKernelGGL(weight_transpose_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, st, arena, table, n_desc, (float*)out),
+        hipLaunchKernelGGL(weight_transpose_batched_kernel<unsigned short>, dim3(total_blocks), dim3(256), 0, st, arena, table, n_desc, (unsigned short*)out))
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }

@@ -307,3 +307,22 @@ def rownorm_backward(x, norms, g, power, scale, eps, dx, row_scale=None):
                                      float(power), float(scale), float(eps), ptr(dx), dx.stride(0), stream_ptr()),
           "iif_rownorm_backward")
     return dx
+
+
+# ------------------------------------------------------------ batched weight preparation
+def wt_table(entries, device):
+    """entries: [(src_off, dst_off, cout, cin, rs, ldw, ldwt)] -> (device int32 table, total blocks).  Layout =
+    struct iif_wt_desc {int64 src_off, dst_off; int32 cout, cin, rs, ldw, ldwt, block_start;} (40 bytes)."""
+    import struct
+    blob, start = b"", 0
+    for (so, do, cout, cin, rs, ldw, ldwt) in entries:
+        blob += struct.pack("<qqiiiiii", so, do, cout, cin, rs, ldw, ldwt, start)
+        start += (cin * ldwt + 1023) // 1024
+    t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    return t, start
+
+
+def weight_transpose_batched(arena, table, n_desc, total_blocks, out):
+    check(lib().iif_weight_transpose_batched(ptr(arena), ptr(table), n_desc, total_blocks, dtype_code(out), ptr(out),
+                                             stream_ptr()), "iif_weight_transpose_batched")
+    return out

@@ -539,6 +539,9 @@ class _Plan(object):
         E = lambda *s: torch.empty(s, dtype=dt, device=dev)   # noqa: E731
         self.units = []
         self.steps = []          # structural description used by forward/backward
+        # low-precision copy of the whole parameter arena: ONE cast launch per step; a dense convolution's
+        # bf16 weights are a view of it (same offsets, same [cout][ldw] rows)
+        self.lp_arena = torch.empty_like(net._arena, dtype=dt) if dt != torch.float32 else None
         # ---- stem
         c1 = net.conv1
         ho, wo = ops.conv_out_hw(h, w, c1.k, c1.k, c1.stride, c1.pad)
@@ -618,8 +621,13 @@ class _Plan(object):
                 self.head_dwT = F32(op, D)
             if self.head_kind == "cosine" and head.lr_scale:
                 self.head_s2 = F32(1)
-        self.head_w = self.head_wsrc if dt == torch.float32 else torch.empty((op, D), dtype=dt, device=dev)
-        self.head_wt = torch.zeros((D, _round_up(op, 16)), dtype=dt, device=dev)
+        if self.head_kind == "linear" and dt != torch.float32:
+            ho_, hr_, hp_ = net._offsets[(id(head), "weight")]
+            self.head_w = self.lp_arena[ho_:ho_ + hr_ * hp_].view(hr_, hp_)
+        else:
+            self.head_w = self.head_wsrc if dt == torch.float32 else torch.empty((op, D), dtype=dt, device=dev)
+        self.head_wt = None if self.head_kind == "linear" else torch.zeros((D, _round_up(op, 16)), dtype=dt, device=dev)
+        self._finish_weight_plan()
         # ---- scratch
         cmax = max(u.conv.cout for u in self.units)
         mmax = max(u.n * u.ho * u.wo for u in self.units)
@@ -634,6 +642,34 @@ class _Plan(object):
         self._bwd_ready = False
         self.wg_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and not os.environ.get("IIF_NO_WGRAD_STREAM")) else None
         self._wg_events = {}
+
+    def _finish_weight_plan(self):
+        """One arena for every dense transposed weight copy ([cin][k*k*cout], the data-gradient operand) and
+        the device table that lets ONE launch fill it from the fp32 parameter arena."""
+        net, entries, views, off = self.net, [], [], 0
+        for u in self.units:
+            cv = u.conv
+            if cv.groups > 1 or u.is_patch_gemm:
+                continue
+            ldwt = _round_up(cv.k * cv.k * cv.cout, 16)
+            entries.append((net._offsets[(id(cv), "weight")][0], off, cv.cout, cv.cin, cv.k * cv.k, cv.ldw, ldwt))
+            views.append((u, off, cv.cin, ldwt))
+            off += _round_up(cv.cin * ldwt, 64)
+        head = net._head
+        head_view = None
+        if self.head_kind == "linear":
+            ldwt = _round_up(head.out_padded, 16)
+            entries.append((net._offsets[(id(head), "weight")][0], off, head.out_padded, head.in_features, 1, head.in_features, ldwt))
+            head_view = (off, head.in_features, ldwt)
+            off += _round_up(head.in_features * ldwt, 64)
+        self.wt_arena = torch.zeros(max(off, 1), dtype=self.dt, device=self.dev)
+        for (u, o, rows, ld) in views:
+            u.wt = self.wt_arena[o:o + rows * ld].view(rows, ld)
+        if head_view is not None:
+            o, rows, ld = head_view
+            self.head_wt = self.wt_arena[o:o + rows * ld].view(rows, ld)
+        self.wt_n = len(entries)
+        self.wt_table, self.wt_blocks = ops.wt_table(entries, self.dev) if entries else (None, 0)
 
     def _unit(self, conv, bn, src, n, ho, wo, patch=False, need_y=True):
         dt, dev = self.dt, self.dev
@@ -658,32 +694,33 @@ class _Plan(object):
             u.wt = torch.empty((conv.cin, ldp), dtype=dt, device=dev)
             u.dwp = torch.empty((conv.cout, ldp), dtype=torch.float32, device=dev)
         else:
-            u.w = conv._w2d if dt == torch.float32 else torch.empty((conv.cout, conv.ldw), dtype=dt, device=dev)
-            u.wt = None if patch else torch.zeros((conv.cin, _round_up(conv.k * conv.k * conv.cout, 16)), dtype=dt,
-                                                  device=dev)
+            o, rows, pitch = self.net._offsets[(id(conv), "weight")]
+            u.w = conv._w2d if dt == torch.float32 else self.lp_arena[o:o + rows * pitch].view(rows, pitch)
+            u.wt = None        # dense transposed copies live in one arena, filled by one launch (_finish_weight_plan)
         self.units.append(u)
         return u
 
     # ---------------------------------------------------------------- weights
     def prepare_weights(self, need_transposed):
+        net = self.net
+        if self.lp_arena is not None:
+            ops.cast(net._arena, self.lp_arena)
+        if need_transposed and self.wt_n:
+            ops.weight_transpose_batched(net._arena, self.wt_table, self.wt_n, self.wt_blocks, self.wt_arena)
         for u in self.units:
             cv = u.conv
             if u.s2d:
                 ops.stem_s2d_pack(cv._w2d, cv.cout, cv.cin, cv.k, S2D_CPAD, u.w)
-                continue
-            if cv.groups > 1:
+            elif cv.groups > 1:
                 ops.group_pack(cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.w)
                 if need_transposed:
                     ops.group_pack(cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.wt, transposed=True)
-                continue
-            if self.dt != torch.float32:
-                ops.cast(cv._w2d, u.w)
-            if need_transposed and u.wt is not None:
-                ops.weight_transpose(cv._w2d, cv.cout, cv.cin, cv.k * cv.k, u.wt)
-        head = self.net._head
+        head = net._head
+        if self.head_kind == "linear":
+            return
         if self.head_kind == "cosine":           # ew = W / |W_row|   (resnet_cifar.py:73)
             ops.rowmap_forward(head._w2d, 1, 1.0, self.head_wsrc, self.head_wnorm, eps=0.0)
-        elif self.head_kind == "norm":           # ew = W / |W_col|, W is [in, out]   (resnet_cifar.py:47)
+        else:                                    # ew = W / |W_col|, W is [in, out]   (resnet_cifar.py:47)
             ops.transpose_f32(head._w2d, self.head_wT)
             ops.rowmap_forward(self.head_wT, 1, 1.0, self.head_wsrc, self.head_wnorm)
         if self.dt != torch.float32:

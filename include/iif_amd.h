@@ -328,6 +328,17 @@ int iif_rownorm_backward(const float* x, const float* row_scale, const float* no
                          int cols, int64_t ldx, int64_t ldg, float power, float scale, float eps, float* dx,
                          int64_t lddx, void* stream);
 
+/* All dense convolutions' transposed copies ([cin][rs*cout], for the data gradient) in ONE launch.  `table` is a
+ * DEVICE array of n_desc descriptors sorted by block_start; descriptor i owns the blocks
+ * [block_start_i, block_start_{i+1}) and each block writes 1024 elements of its [cin, ldwt] output.
+ * src_off / dst_off are element offsets into the fp32 parameter arena / the output arena. */
+typedef struct iif_wt_desc {
+    int64_t src_off, dst_off;
+    int32_t cout, cin, rs, ldw, ldwt, block_start;
+} iif_wt_desc;
+int iif_weight_transpose_batched(const float* arena, const iif_wt_desc* table, int n_desc, int total_blocks,
+                                 int out_dtype, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
