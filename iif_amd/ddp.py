@@ -20,9 +20,11 @@ import torch.distributed as dist
 
 
 class ArenaReducer(object):
-    def __init__(self, grad_arena, boundaries, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, grad_arena, boundaries, bucket_bytes=32 << 20, process_group=None, tail_bytes=2 << 20):
         """grad_arena: flat fp32 tensor; boundaries: sorted arena offsets where a bucket
-        may start (tensor starts, in elements)."""
+        may start (tensor starts, in elements).  The LAST bucket (the arena's head: stem and
+        first blocks) can only start when backward has finished, so its reduction is exposed:
+        it is kept below ``tail_bytes`` by one extra cut."""
         self.arena = grad_arena
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -37,6 +39,11 @@ class ArenaReducer(object):
                 self.buckets.append((c, hi))
                 hi = c
         if hi > 0:
+            tail = max(tail_bytes // 4, 1)
+            small = [c for c in cuts if c < hi and c <= tail]
+            if hi > tail and small:
+                self.buckets.append((small[-1], hi))
+                hi = small[-1]
             self.buckets.append((0, hi))
         self.use_streams = grad_arena.is_cuda
         self.comm_stream = torch.cuda.Stream(device=grad_arena.device) if self.use_streams else None
