@@ -38,6 +38,7 @@ template <> struct ET<float> { static constexpr int PE = 4, KE = 16; };
 struct ConvArgs {
     const unsigned char* src; const unsigned char* wgt; unsigned char* dst; const unsigned char* res;
     const float* bias;
+    const unsigned char* res_bits;   // nullable: 1 bit per residual element (ReLU decisions); the residual is masked by it
     float* bn_partial;     // nullable: [mtiles][2][Cd] per-tile (sum, sum of squares) of the stored output
     int N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, sshift, pad, transposed, ldw, M, K, mtiles, ntiles;
     int spitch, dpitch, groups;   // channels per pixel of the source / destination TENSORS (= groups * Cs / Cd)
@@ -86,14 +87,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BN
             OT* dp = reinterpret_cast<OT*>(a.dst) + o;
             const OT* rp = reinterpret_cast<const OT*>(a.res) + o;
             if (vec_ok) {
+                // ReLU-decision bits of the residual's 16-byte vector (4 fp32 / 8 bf16 elements per byte)
+                constexpr int RV = sizeof(OT) == 4 ? 4 : 8;
+                const unsigned rb = a.res_bits ? (unsigned)a.res_bits[o / RV] >> (o % RV) : 0xffu;
                 if constexpr (sizeof(OT) == 4) {
-                    if (a.res) { const f32x4 t = *reinterpret_cast<const f32x4*>(rp); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                    if (a.res) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(rp);
+                        v[0] += (rb & 1u) ? t.x : 0.f; v[1] += (rb & 2u) ? t.y : 0.f;
+                        v[2] += (rb & 4u) ? t.z : 0.f; v[3] += (rb & 8u) ? t.w : 0.f;
+                    }
                     *reinterpret_cast<f32x4*>(dp) = f32x4{v[0], v[1], v[2], v[3]};
                 } else {
                     if (a.res) {
                         const u32x2 t = *reinterpret_cast<const u32x2*>(rp);
-                        v[0] += bf16_bits_to_f32(t.x & 0xffffu); v[1] += __uint_as_float(t.x & 0xffff0000u);
-                        v[2] += bf16_bits_to_f32(t.y & 0xffffu); v[3] += __uint_as_float(t.y & 0xffff0000u);
+                        v[0] += (rb & 1u) ? bf16_bits_to_f32(t.x & 0xffffu) : 0.f; v[1] += (rb & 2u) ? __uint_as_float(t.x & 0xffff0000u) : 0.f;
+                        v[2] += (rb & 4u) ? bf16_bits_to_f32(t.y & 0xffffu) : 0.f; v[3] += (rb & 8u) ? __uint_as_float(t.y & 0xffff0000u) : 0.f;
                     }
                     u32x2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
                     *reinterpret_cast<u32x2*>(dp) = w;
@@ -297,10 +305,11 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
             const int64_t o = (dst_row(a, m) * a.dpitch + goff + n) * 2;
             if (a.res) {
                 const u32x4 rr = *reinterpret_cast<const u32x4*>(a.res + o);
+                const unsigned rb = a.res_bits ? a.res_bits[o >> 4] : 0xffu;       // one byte per 16-byte vector
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float lo = bf16_bits_to_f32(v[q] & 0xffffu) + bf16_bits_to_f32(rr[q] & 0xffffu);
-                    const float hi = __uint_as_float(v[q] & 0xffff0000u) + __uint_as_float(rr[q] & 0xffff0000u);
+                    const float lo = bf16_bits_to_f32(v[q] & 0xffffu) + ((rb >> (2 * q)) & 1u ? bf16_bits_to_f32(rr[q] & 0xffffu) : 0.f);
+                    const float hi = __uint_as_float(v[q] & 0xffff0000u) + ((rb >> (2 * q + 1)) & 1u ? __uint_as_float(rr[q] & 0xffff0000u) : 0.f);
                     v[q] = pack_bf16x2(lo, hi);
                 }
             }
@@ -663,18 +672,36 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
 
 }  // namespace
 
+namespace {
+int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+               const unsigned char* res_bits, const float* bias, float* bn_partial, int64_t bn_partial_floats,
+               int32_t* n_partials, void* stream);
+}
+
 extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
                                       const void* res, const float* bias, float* bn_partial, int64_t bn_partial_floats,
-                                      int32_t* n_partials, void* stream);
+                                      int32_t* n_partials, void* stream) {
+    return conv_entry(d, src, wgt, dst, res, nullptr, bias, bn_partial, bn_partial_floats, n_partials, stream);
+}
+
+extern "C" int iif_conv_igemm_masked_res(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
+                                         const void* res, const unsigned char* res_bits, void* stream) {
+    if (!res || !res_bits) return IIF_EINVAL;
+    // the bit bytes follow the residual's 16-byte vectors: rows must be whole vectors, stores vectorised
+    const int v = d && d->dst_dtype == IIF_F32 ? 4 : 8;
+    if (!d || d->transposed == 0 || d->stride != 1 || (d->cd * (d->groups > 1 ? d->groups : 1)) % v) return IIF_EUNSUPPORTED;
+    return conv_entry(d, src, wgt, dst, res, res_bits, nullptr, nullptr, 0, nullptr, stream);
+}
 
 extern "C" int iif_conv_igemm(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                               const float* bias, void* stream) {
     return iif_conv_igemm_bnstats(d, src, wgt, dst, res, bias, nullptr, 0, nullptr, stream);
 }
 
-extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
-                                      const void* res, const float* bias, float* bn_partial, int64_t bn_partial_floats,
-                                      int32_t* n_partials, void* stream) {
+namespace {
+int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+               const unsigned char* res_bits, const float* bias, float* bn_partial, int64_t bn_partial_floats,
+               int32_t* n_partials, void* stream) {
     if (!d || !src || !wgt || !dst) return IIF_EINVAL;
     if (d->n <= 0 || d->hs <= 0 || d->ws <= 0 || d->cs <= 0 || d->hd <= 0 || d->wd <= 0 || d->cd <= 0 ||
         d->r <= 0 || d->s <= 0 || d->pad < 0)
@@ -692,6 +719,7 @@ extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, c
     ConvArgs a{};
     a.src = (const unsigned char*)src; a.wgt = (const unsigned char*)wgt; a.dst = (unsigned char*)dst;
     a.res = (const unsigned char*)res; a.bias = bias;
+    a.res_bits = res_bits;
     a.bn_partial = nullptr;
     if (n_partials) *n_partials = 0;
     if (bn_partial) {
@@ -723,3 +751,4 @@ extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, c
     }
     return launch_conv<float, true>(a, src_bytes, wgt_bytes, st);
 }
+}  // namespace

@@ -55,9 +55,9 @@ def bn_finalize_stats(partial, n_partials, m, c, gamma, beta, running_mean, runn
     return stats
 
 
-def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, out=None, res=None, groups=1):
+def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, out=None, res=None, groups=1, res_bits=None):
     """dy: [N,Ho,Wo,Cout]; wt: [Cin, ldw] rows of r*s*Cout (the CRSK transpose);
-    returns dx [N,H,W,Cin] (+ res)."""
+    returns dx [N,H,W,Cin] (+ res, gated element-wise by the ReLU bits ``res_bits`` if given)."""
     require_gpu(dy, wt, res)
     n, ho, wo, cout = dy.shape
     cin, ldw = wt.shape
@@ -66,6 +66,10 @@ def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, out=None, res=None, groups=1):
         out = torch.empty((n, h, w_, cin), dtype=dy.dtype, device=dy.device)
     d = _desc(n, ho, wo, cout // groups, h, w_, cin // groups, r, s, stride, pad, 1, ldw, dtype_code(dy), dtype_code(out),
               groups)
+    if res_bits is not None:
+        check(lib().iif_conv_igemm_masked_res(ctypes.byref(d), ptr(dy), ptr(wt), ptr(out), ptr(res), ptr(res_bits),
+                                              stream_ptr()), "iif_conv_igemm_masked_res")
+        return out
     check(lib().iif_conv_igemm(ctypes.byref(d), ptr(dy), ptr(wt), ptr(out), ptr(res), 0, stream_ptr()), "iif_conv_igemm(dgrad)")
     return out
 

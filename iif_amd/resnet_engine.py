@@ -889,22 +889,25 @@ class _Plan(object):
         if old is not None:
             torch.cuda.current_stream().wait_event(old)
 
-    def _unit_backward(self, u, gy, mask, gmasked=None, dgrad_out=None, dgrad_res=None, need_dgrad=True, par=0):
+    def _unit_backward(self, u, gy, mask, gmasked=None, dgrad_out=None, dgrad_res=None, need_dgrad=True, par=0,
+                       keep_gy=False, mask_bits=None, dgrad_res_bits=None):
         """gy: grad w.r.t. the unit's activated output (NHWC).  Computes in place
         dx (into gy's storage unless gmasked is requested), the weight / BN
         gradients, and (optionally) the data gradient w.r.t. the unit's source."""
         cv, bn = u.conv, u.bn
         m = u.n * u.ho * u.wo
         g2 = gy.view(m, cv.cout)
-        if gmasked is not None:
+        bits = mask_bits if mask_bits is not None else (None if mask is None else u.bits)
+        if gmasked is not None or keep_gy:
+            # dx goes to its own buffer; gy is either overwritten by its masked copy (gmasked) or left as is
             dx = self._gbuf(("dx", m, cv.cout, par), (m, cv.cout))
             ops.bn_backward(g2, None if mask is None else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats, bn.weight,
-                            bn._dgamma, bn._dbeta, dx, self.bn_ws, gmasked=gmasked.view(m, cv.cout),
-                            relu_bits=None if mask is None else u.bits)
+                            bn._dgamma, bn._dbeta, dx, self.bn_ws,
+                            gmasked=None if gmasked is None else gmasked.view(m, cv.cout), relu_bits=bits)
         else:
             dx = g2
             ops.bn_backward(g2, None if mask is None else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats, bn.weight,
-                            bn._dgamma, bn._dbeta, dx, self.bn_ws, relu_bits=None if mask is None else u.bits)
+                            bn._dgamma, bn._dbeta, dx, self.bn_ws, relu_bits=bits)
         dx4 = dx.view(u.n, u.ho, u.wo, cv.cout)
         if u.s2d:
             def stem():
@@ -927,7 +930,7 @@ class _Plan(object):
         if not need_dgrad:
             return None
         return ops.conv_dgrad(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), out=dgrad_out, res=dgrad_res,
-                              groups=u.groups)
+                              groups=u.groups, res_bits=dgrad_res_bits)
 
     def backward(self, reducer=None):
         net = self.net
@@ -991,13 +994,17 @@ class _Plan(object):
             par = bi & 1
             self._wgrad_fence(bi)
             gin = self._gbuf(("gin", tuple(inp.shape), bi % 3), inp.shape)
+            dkey = ("d", tuple(last.src.shape), len(units) - 1, par)
+            # The block's ReLU gates g on both paths.  With a convolutional shortcut or a plain identity no masked
+            # copy of g is written: the shortcut's BN backward and the identity add read g through the ReLU bits.
+            lazy_mask = "se" not in b and "sc" not in b
             if "se" in b:
                 G = self._se_backward(b, last, g, par)
-                d = self._unit_backward(last, G, None, par=par,
-                                        dgrad_out=self._gbuf(("d", tuple(last.src.shape), len(units) - 1, par), last.src.shape))
+                d = self._unit_backward(last, G, None, par=par, dgrad_out=self._gbuf(dkey, last.src.shape))
+            elif lazy_mask:
+                d = self._unit_backward(last, g, last.y, keep_gy=True, par=par, dgrad_out=self._gbuf(dkey, last.src.shape))
             else:
-                d = self._unit_backward(last, g, last.y, gmasked=g, par=par,
-                                        dgrad_out=self._gbuf(("d", tuple(last.src.shape), len(units) - 1, par), last.src.shape))
+                d = self._unit_backward(last, g, last.y, gmasked=g, par=par, dgrad_out=self._gbuf(dkey, last.src.shape))
             for ui in range(len(units) - 2, 0, -1):
                 uu = units[ui]
                 d = self._unit_backward(uu, d, uu.y, par=par,
@@ -1006,10 +1013,15 @@ class _Plan(object):
             if "ds" in b:
                 self._unit_backward(first, d, first.y, dgrad_out=gin, par=par)
                 du = b["ds"]
-                self._unit_backward(du, g, None, dgrad_out=gin, dgrad_res=gin, par=par)
+                if lazy_mask:       # in place: g is not needed after the shortcut's BN backward
+                    self._unit_backward(du, g, last.y, mask_bits=last.bits, dgrad_out=gin, dgrad_res=gin, par=par)
+                else:
+                    self._unit_backward(du, g, None, dgrad_out=gin, dgrad_res=gin, par=par)
             elif "sc" in b:
                 self._unit_backward(first, d, first.y, dgrad_out=gin, par=par)
                 ops.shortcut_a_backward_acc(g, gin)
+            elif lazy_mask:
+                self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=g, dgrad_res_bits=last.bits, par=par)
             else:
                 self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=g, par=par)
             g = gin

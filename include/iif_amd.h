@@ -339,6 +339,14 @@ typedef struct iif_wt_desc {
 int iif_weight_transpose_batched(const float* arena, const iif_wt_desc* table, int n_desc, int total_blocks,
                                  int out_dtype, void* out, void* stream);
 
+/* Data gradient with a MASKED residual: dst = dgrad(src, wgt) + res * [bit], where res_bits holds one ReLU
+ * decision bit per element of res (the relu_bits of iif_bn_apply: one byte per 16-byte vector).  This is the
+ * identity path of a residual block in backward (resnet_pytorch.py:163-167: out += identity; relu): the
+ * gradient of the block output is gated by the block's ReLU while it is added, so no masked copy is ever
+ * written.  transposed=1, stride 1 only. */
+int iif_conv_igemm_masked_res(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
+                              const void* res, const unsigned char* res_bits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

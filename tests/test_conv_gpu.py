@@ -225,3 +225,28 @@ def test_grouped_conv3x3(case, dt):
     ops.group_unpack_grad(dwp, width, cg, ch, 9, dwm)
     wtol = 2e-5 if dt == torch.float32 else 1e-4
     assert (dwm[:, :9 * cg].cpu() - refdw).abs().max().item() <= wtol * refdw.abs().max().item()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_dgrad_with_relu_masked_residual(dt):
+    """iif_conv_igemm_masked_res: dx = dgrad(dy, w) + res * [bit] with the 1-bit ReLU decisions bn_apply wrote."""
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(31)
+    n, h, cin, cout = 3, 14, 64, 32
+    dy = torch.randn(n, h, h, cout, generator=g).to(dt)
+    w = (torch.randn(cout, cin, generator=g) * 0.1).to(dt)
+    res = torch.randn(n, h, h, cin, generator=g).to(dt)
+    pre = torch.randn(n * h * h, cin, generator=g).to(dt)
+    # bits through the product path: bn_apply with identity statistics
+    stats = torch.zeros(4, cin)
+    stats[2] = 1.0
+    y = torch.empty(n * h * h, cin, dtype=dt, device=DEV)
+    vec = 8 if dt == torch.bfloat16 else 4
+    bits = torch.empty(n * h * h * cin // vec, dtype=torch.uint8, device=DEV)
+    ops.bn_apply(pre.to(DEV), stats.to(DEV), y, relu=True, relu_bits=bits)
+    wt = torch.zeros(cin, 32, dtype=dt, device=DEV)
+    ops.weight_transpose(w.float().to(DEV), cout, cin, 1, wt)
+    out = ops.conv_dgrad(dy.to(DEV), wt, 1, 1, 1, 0, (h, h), res=res.to(DEV), res_bits=bits)
+    ref = dy.float().reshape(-1, cout) @ w.float() + res.float().reshape(-1, cin) * (pre.float() > 0)
+    tol = 2e-5 if dt == torch.float32 else 2.0 ** -7
+    assert (out.float().cpu().reshape(-1, cin) - ref).abs().max().item() <= tol * ref.abs().max().item()
