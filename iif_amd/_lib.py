@@ -61,6 +61,8 @@ SIGNATURES = {
     "iif_rownorm_backward": [_P, _P, _P, _P, _I, _I, _L, _L, _F, _F, _F, _P, _L, _P],
     "iif_weight_transpose_batched": [_P, _P, _I, _I, _I, _P, _P],
     "iif_conv_igemm_masked_res": [_P, _P, _P, _P, _P, _P, _P],
+    "iif_mask_gather": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
+    "iif_mask_bce_fwd_bwd": [_P, _I, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "iif_rowmap_forward": [_P, _I, _I, _I, _L, _I, _F, _F, _P, _I, _L, _P, _P],
     "iif_rowmap_backward": [_P, _I, _P, _P, _I, _I, _I, _L, _L, _I, _F, _F, _P, _I, _L, _P],
     "iif_transpose_f32": [_P, _I, _I, _L, _P, _L, _P],

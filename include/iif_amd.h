@@ -347,6 +347,21 @@ int iif_weight_transpose_batched(const float* arena, const iif_wt_desc* table, i
 int iif_conv_igemm_masked_res(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
                               const void* res, const unsigned char* res_bits, void* stream);
 
+/* Mask-side class-channel selection.  pred is [n, c, hw] (NCHW mask logits / probabilities,
+ * fp32 or bf16), labels int64 [n] the IIF-derived class of every RoI.
+ *   iif_mask_gather       out[n, hw] = pred[i, labels[i], :]        (FCNMaskHead.get_seg_masks,
+ *                         mmdet/models/roi_heads/mask_heads/fcn_mask_head.py:289-290)
+ *   iif_mask_bce_fwd_bwd  loss = mean_i,p BCEWithLogits(pred[i, labels[i], p], target[i, p])   (mask_cross_entropy,
+ *                         mmdet/models/losses/cross_entropy_loss.py:158-162); dpred (nullable, fp32 [n, c, hw],
+ *                         ZERO-FILLED by the caller) receives grad_scale * d loss / d pred in the selected
+ *                         channels only.  row_loss: [n] scratch.  An out-of-range label sets bit 0 of *status
+ *                         (device int, caller-zeroed) and contributes nothing. */
+int iif_mask_gather(const void* pred, int dtype, const int64_t* labels, int n, int c, int hw, float* out,
+                    int* status, void* stream);
+int iif_mask_bce_fwd_bwd(const void* pred, int dtype, const float* target, const int64_t* labels, int n, int c,
+                         int hw, float grad_scale, float* row_loss, float* loss, float* dpred, int* status,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

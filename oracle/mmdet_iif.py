@@ -90,3 +90,16 @@ def normed_conv2d_1x1(x, weight, bias=None, temperature=20.0, power=1.0, eps=1e-
     x_ = x / (x.norm(dim=1, keepdim=True).pow(power) + eps)
     x_ = x_ * temperature
     return F.conv2d(x_, weight_, bias)
+
+
+def mask_cross_entropy(pred, target, label):
+    """mmdet/models/losses/cross_entropy_loss.py:158-162 (reduction 'mean', no avg_factor, no class_weight)."""
+    num_rois = pred.size()[0]
+    inds = torch.arange(0, num_rois, dtype=torch.long, device=pred.device)
+    pred_slice = pred[inds, label].squeeze(1)
+    return F.binary_cross_entropy_with_logits(pred_slice, target, reduction="mean")[None]
+
+
+def gather_class_masks(mask_pred, labels):
+    """mmdet/models/roi_heads/mask_heads/fcn_mask_head.py:289-290."""
+    return mask_pred[range(mask_pred.shape[0]), labels]
