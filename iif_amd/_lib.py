@@ -63,6 +63,9 @@ SIGNATURES = {
     "iif_conv_igemm_masked_res": [_P, _P, _P, _P, _P, _P, _P],
     "iif_mask_gather": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
     "iif_mask_bce_fwd_bwd": [_P, _I, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P],
+    "iif_class_accumulate": [_P, _P, _I, _I, _P, _P, _P],
+    "iif_fasa_update": [_P, _P, _I, _I, _L, _I, _F, _P, _P, _P, _P],
+    "iif_fasa_generate": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "iif_rowmap_forward": [_P, _I, _I, _I, _L, _I, _F, _F, _P, _I, _L, _P, _P],
     "iif_rowmap_backward": [_P, _I, _P, _P, _I, _I, _I, _L, _L, _I, _F, _F, _P, _I, _L, _P],
     "iif_transpose_f32": [_P, _I, _I, _L, _P, _L, _P],

@@ -362,6 +362,25 @@ int iif_mask_bce_fwd_bwd(const void* pred, int dtype, const float* target, const
                          int hw, float grad_scale, float* row_loss, float* loss, float* dpred, int* status,
                          void* stream);
 
+/* FASA side outputs of the IIF classifier loss (instance_segmentation/mmdet).
+ *   iif_class_accumulate  FasaIIFLoss.forward with use_cums (losses/fasa_iif_loss.py:154-160): for every class
+ *                         c in [0, C): cum_labels[c] += #{labels == c}, cum_losses[c] += sum of rows over them
+ *                         (row order; labels outside [0, C) are skipped).
+ *   iif_fasa_update       fa_update / fa_update_push (roi_heads/bbox_heads/fasa_bbox_head.py:118-147): per-class mean
+ *                         and unbiased variance of embedding [n, d] rows, first sight -> copy, afterwards
+ *                         exponential moving average with `decay`; feature_used[c] becomes 1.
+ *   iif_fasa_generate     fa_generate (:149-172) with the random numbers supplied by the caller: classes with
+ *                         rnd[c] < prob[c] and feature_used[c] > 0, ascending, get out[k] = mean + sqrt(var) *
+ *                         normal[c], out_labels[k] = c; *count (device) = number of rows written (<= c).
+ *                         slot_class: int32 [c] scratch. */
+int iif_class_accumulate(const float* rows, const int64_t* labels, int n, int c, float* cum_losses,
+                         float* cum_labels, void* stream);
+int iif_fasa_update(const float* embedding, const int64_t* labels, int n, int d, int64_t ld, int c, float decay,
+                    float* feature_mean, float* feature_var, float* feature_used, void* stream);
+int iif_fasa_generate(const float* rnd, const float* prob, const float* feature_used, const float* feature_mean,
+                      const float* feature_var, const float* normal, int c, int d, int* slot_class, int* count,
+                      float* out, int64_t* out_labels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,3 +103,45 @@ def mask_cross_entropy(pred, target, label):
 def gather_class_masks(mask_pred, labels):
     """mmdet/models/roi_heads/mask_heads/fcn_mask_head.py:289-290."""
     return mask_pred[range(mask_pred.shape[0]), labels]
+
+
+def fasa_accumulate(loss_rows, label, cum_losses, cum_labels):
+    """mmdet/models/losses/fasa_iif_loss.py:154-160 (in place on the two accumulators); returns the mean."""
+    for u_l in label.unique():
+        inds_ = torch.where(label == u_l)[0]
+        cum_labels[int(u_l)] += len(inds_)
+        cum_losses[int(u_l)] += loss_rows[inds_].sum()
+    return loss_rows.mean()
+
+
+def fasa_update(embedding, labels, feature_mean, feature_var, feature_used, decay_ratio):
+    """fasa_bbox_head.py:118-147 (fa_update + fa_update_push), in place."""
+    for c in torch.unique(labels):
+        c = int(c)
+        e = embedding[torch.nonzero(labels == c, as_tuple=False).squeeze(1)]
+        mean = e.mean(dim=0)
+        var = e.var(dim=0, unbiased=False)
+        n = e.numel() / e.size(1)
+        if n > 1:
+            var = var * n / (n - 1)
+        if feature_used[c] > 0:
+            feature_mean[c] = decay_ratio * mean + (1 - decay_ratio) * feature_mean[c]
+            feature_var[c] = decay_ratio * var + (1 - decay_ratio) * feature_var[c]
+        else:
+            feature_mean[c] = mean
+            feature_var[c] = var
+            feature_used[c] += 1
+
+
+def fasa_generate(rand, prob_list, feature_used, feature_mean, feature_var, normal):
+    """fasa_bbox_head.py:149-172 with the random draws passed in (``normal[c]`` is the draw of class c)."""
+    emb, lab = [], []
+    for c in torch.where(rand < prob_list)[0]:
+        c = int(c)
+        if feature_used[c] == 0:
+            continue
+        emb.append((feature_mean[c] + torch.sqrt(feature_var[c]) * normal[c]).unsqueeze(0))
+        lab.append(c)
+    if emb:
+        return torch.cat(emb, 0), torch.tensor(lab)
+    return [], []
