@@ -1,8 +1,9 @@
 """Class-count / class-map arithmetic of the reference's long-tailed datasets
 (the part of classification/imbalanced_dataset.py that feeds ``IIFLoss``) plus
-synthetic long-tailed datasets of the same shapes.  Image IO, augmentation and
-samplers of the reference are out of scope; there is no network in
-this environment, so every dataset here is generated from a seed.
+synthetic long-tailed datasets of the same shapes, and the list-file datasets
+``LT_Dataset`` / ``LT_Dataset_Eval``.  Augmentation is out of scope and
+image decoding needs PIL (absent here; pluggable ``loader``); there is no network in
+this environment, so the datasets the training entry point builds are generated from a seed.
 """
 import numpy as np
 import torch
@@ -88,3 +89,80 @@ def synthetic_lt(name, seed=0, train=True, scale=1.0):
     counts = lt_profile(C, top) if train else [2] * C
     counts = [max(int(c * scale), 1) for c in counts]
     return SyntheticLT(counts, 224, seed if train else seed + 1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Real long-tailed list files (ImageNet-LT / Places-LT / iNaturalist: "relative/path label" per line).
+# Parsing, class counting and the descending-frequency class map are the reference's host arithmetic
+# (classification/imbalanced_dataset.py:100-174); decoding an image needs PIL, which the build image lacks:
+# pass ``loader`` (path -> image) or install PIL.
+def _default_loader(path):
+    try:
+        from PIL import Image
+    except Exception as e:                       # pragma: no cover - depends on the deployment image
+        raise RuntimeError("decoding %s needs PIL (not in this image); pass loader= to LT_Dataset" % path) from e
+    with open(path, "rb") as f:
+        return Image.open(f).convert("RGB")
+
+
+def _read_list(root, txt):
+    import os
+    paths, targets = [], []
+    with open(txt) as f:
+        for line in f:
+            parts = line.split()
+            if not parts:
+                continue
+            paths.append(os.path.join(root, parts[0]))
+            targets.append(int(parts[1]))
+    return paths, targets
+
+
+class LT_Dataset(Dataset):
+    """imbalanced_dataset.py:100-144: classes are renumbered by descending training frequency."""
+
+    def __init__(self, root, txt, num_classes, transform=None, loader=None):
+        import numpy as np
+        self.num_classes = num_classes
+        self.transform = transform
+        self.loader = loader or _default_loader
+        self.img_path, raw = _read_list(root, txt)
+        self.class_map, self.targets, self.cls_num_list = lt_class_map(raw, num_classes)
+        self.classes = np.unique(np.array(self.targets))
+        self.class_data = [[] for _ in range(num_classes)]
+        for i, j in enumerate(self.targets):
+            self.class_data[j].append(i)
+
+    def __len__(self):
+        return len(self.targets)
+
+    def __getitem__(self, index):
+        sample = self.loader(self.img_path[index])
+        if self.transform is not None:
+            sample = self.transform(sample)
+        return sample, self.targets[index]
+
+    def get_cls_num_list(self):
+        return self.cls_num_list
+
+
+class LT_Dataset_Eval(Dataset):
+    """imbalanced_dataset.py:148-174: evaluation list remapped with the TRAINING set's class map."""
+
+    def __init__(self, root, txt, class_map, num_classes, transform=None, loader=None):
+        import numpy as np
+        self.num_classes = num_classes
+        self.transform = transform
+        self.loader = loader or _default_loader
+        self.class_map = class_map
+        self.img_path, raw = _read_list(root, txt)
+        self.targets = np.array(self.class_map)[raw].tolist() if raw else []
+
+    def __len__(self):
+        return len(self.targets)
+
+    def __getitem__(self, index):
+        sample = self.loader(self.img_path[index])
+        if self.transform is not None:
+            sample = self.transform(sample)
+        return sample, self.targets[index]

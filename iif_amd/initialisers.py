@@ -53,7 +53,14 @@ def get_data(args):
         ds = imbalanced_dataset.synthetic_lt(key, args.rand_number, True, getattr(args, "synthetic_scale", 1.0))
         ds_test = imbalanced_dataset.synthetic_lt(key, args.rand_number, False)
     sampler = test_sampler = None
-    if getattr(args, "distributed", False):
+    mode = getattr(args, "sampler", "random")
+    if mode != "random":                     # initialisers.py:154-171: class-balanced index stream
+        from .samplers import BalanceClassSampler, DistributedSamplerWrapper
+        sampler = BalanceClassSampler(ds.targets, mode=mode)
+        if getattr(args, "distributed", False):
+            sampler = DistributedSamplerWrapper(sampler)
+            test_sampler = torch.utils.data.distributed.DistributedSampler(ds_test, shuffle=False)
+    elif getattr(args, "distributed", False):
         sampler = torch.utils.data.distributed.DistributedSampler(ds)
         test_sampler = torch.utils.data.distributed.DistributedSampler(ds_test, shuffle=False)
     loader = torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,

@@ -442,6 +442,50 @@ class NativeResNet(nn.Module):
         ops.sgd_step(self._arena[lo:], self._grad_arena[lo:], self._mom_arena[lo:], lr, momentum, weight_decay, nesterov,
                      grad_scale)
 
+    # ------------------------------------------------ optimizer-state interop
+    def optimizer_state_dict(self, lr, momentum=0.9, weight_decay=1e-4, nesterov=False, initial_lr=None):
+        """The ``torch.optim.SGD.state_dict()`` the reference would have saved (classification/train.py:266-271):
+        one param group over ``model.parameters()`` order, ``momentum_buffer`` per parameter taken from the momentum
+        arena (as OIHW / reference-shaped tensors), so a reference run can resume from a native checkpoint."""
+        views = self._arena_views(self._mom_arena)
+        state = {i: {"momentum_buffer": v.detach().clone().contiguous().cpu()} for i, v in enumerate(views)}
+        group = {"lr": lr, "momentum": momentum, "dampening": 0, "weight_decay": weight_decay, "nesterov": nesterov,
+                 "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                 "params": list(range(len(views)))}
+        if initial_lr is not None:
+            group["initial_lr"] = initial_lr
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        """Momentum buffers of a reference checkpoint's ``optimizer`` entry -> momentum arena.  Parameters without
+        state (never stepped) keep a zero buffer, which is what SGD's lazy initialisation amounts to after step 1
+        only; so a state-less parameter is reported by name."""
+        views = self._arena_views(self._mom_arena)
+        missing = []
+        with torch.no_grad():
+            for i, v in enumerate(views):
+                st = sd["state"].get(i, sd["state"].get(str(i)))
+                if st is None or st.get("momentum_buffer") is None:
+                    v.zero_(); missing.append(i)
+                else:
+                    v.copy_(st["momentum_buffer"].to(v.device))
+        return missing
+
+    def _arena_views(self, arena):
+        """Reference-shaped views of ``arena`` (same layout as the parameter arena), in parameters() order."""
+        out = []
+        for (m, attr, rows, pitch) in self._param_specs():
+            o = self._offsets[(id(m), attr)][0]
+            flat = arena[o:o + rows * pitch].view(rows, pitch)
+            p = getattr(m, attr)
+            if isinstance(m, ConvParam):
+                out.append(flat[:, :m.kdim].view(m.cout, m.k, m.k, m.cg).permute(0, 3, 1, 2))
+            elif p.dim() == 2:
+                out.append(flat[:p.shape[0], :p.shape[1]])
+            else:
+                out.append(flat.view(-1)[:p.numel()])
+        return out
+
     def select_training_param(self):
         """Decoupled classifier stage (classification/train.py:123-145): freeze everything, re-initialise
         the classifier (xavier-uniform weight, bias 0.01) and train only it.  BN layers keep running in

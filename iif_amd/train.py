@@ -40,6 +40,19 @@ def lr_at(args, epoch, it, iters_per_epoch):
     return base
 
 
+def scheduler_state_dict(args, last_epoch):
+    """State of the reference's per-epoch scheduler (train.py:223-228) after ``last_epoch`` steps."""
+    lr = lr_at(args, last_epoch, 10 ** 9, 10 ** 9)
+    sd = {"last_epoch": last_epoch, "_step_count": last_epoch + 1, "base_lrs": [args.lr], "_last_lr": [lr],
+          "_get_lr_called_within_step": False, "verbose": False}
+    if args.cosine_scheduler:
+        sd.update({"T_max": args.epochs, "eta_min": 0})
+    else:
+        from collections import Counter
+        sd.update({"milestones": Counter(args.milestones), "gamma": args.lr_gamma})
+    return sd
+
+
 def train_one_epoch(model, criterion, data_loader, device, epoch, args, reducer=None):
     model.train()
     logger = utils.MetricLogger(delimiter="  ")
@@ -127,10 +140,11 @@ def main(args):
         broadcast_parameters(model)
         reducer = model.make_reducer()
     if args.resume:
+        # the reference's checkpoint dict (train.py:265-271): model / optimizer / lr_scheduler / epoch / args
         ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
         model.load_state_dict(ckpt["model"])
-        if "momentum_arena" in ckpt:
-            model._mom_arena.copy_(ckpt["momentum_arena"])
+        if "optimizer" in ckpt:
+            model.load_optimizer_state_dict(ckpt["optimizer"])
         args.start_epoch = ckpt["epoch"] + 1
     if args.load_from:
         model.load_state_dict(torch.load(args.load_from, map_location="cpu", weights_only=False)["model"])
@@ -147,8 +161,12 @@ def main(args):
         acc = evaluate(model, criterion, data_loader_test, device=device)
         best_acc = max(best_acc, acc)
         if args.output_dir:
-            ckpt = {"model": model.state_dict(), "momentum_arena": model._mom_arena.cpu(), "epoch": epoch,
-                    "args": args}
+            nxt = lr_at(args, epoch + 1, 10 ** 9, 10 ** 9)
+            ckpt = {"model": model.state_dict(),
+                    "optimizer": model.optimizer_state_dict(nxt, args.momentum, args.weight_decay,
+                                                            args.opt.lower() == "nesterov", initial_lr=args.lr),
+                    "lr_scheduler": scheduler_state_dict(args, epoch + 1),
+                    "epoch": epoch, "args": args}
             utils.save_on_master(ckpt, os.path.join(args.output_dir, "model_{}.pth".format(epoch)))
             utils.save_on_master(ckpt, os.path.join(args.output_dir, "checkpoint.pth"))
     print("Training time {}".format(datetime.timedelta(seconds=int(time.time() - start_time))))

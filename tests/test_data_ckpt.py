@@ -1,0 +1,120 @@
+"""Host-side rows of SURVEY §8f rank 4: list-file datasets, class-balanced sampling, shot accuracy and
+checkpoint interoperability with the reference's dict (classification/train.py:265-271).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import iif_oracle as O
+
+
+def test_lt_dataset_list_parsing_and_eval_remap(tmp_path):
+    from iif_amd.imbalanced_dataset import LT_Dataset, LT_Dataset_Eval
+    rng = np.random.RandomState(0)
+    C = 7
+    labels = rng.choice(C, size=300, p=np.array([1, 2, 4, 8, 16, 32, 64]) / 127.0)
+    train = tmp_path / "train.txt"
+    train.write_text("".join("img/%05d.jpg %d\n" % (i, l) for i, l in enumerate(labels)))
+    ds = LT_Dataset("/data", str(train), C, loader=lambda p: p)
+    cmap, remapped, counts = O.lt_class_map(labels.tolist(), C, kind="stable")
+    assert ds.class_map == cmap and ds.targets == remapped and ds.get_cls_num_list() == counts
+    assert counts == sorted(counts, reverse=True)                       # descending-frequency renumbering
+    assert len(ds) == 300 and ds[3] == ("/data/img/00003.jpg", remapped[3])
+    assert [len(c) for c in ds.class_data] == counts
+    val = tmp_path / "val.txt"
+    val.write_text("v/0.jpg 6\nv/1.jpg 0\n\n")
+    ev = LT_Dataset_Eval("/data", str(val), ds.class_map, C, loader=lambda p: p)
+    assert ev.targets == [cmap[6], cmap[0]] and len(ev) == 2
+
+
+def test_lt_dataset_without_pil_fails_loudly(tmp_path):
+    from iif_amd.imbalanced_dataset import LT_Dataset
+    f = tmp_path / "t.txt"
+    f.write_text("a.jpg 0\n")
+    ds = LT_Dataset(str(tmp_path), str(f), 2)
+    with pytest.raises((RuntimeError, FileNotFoundError)):
+        ds[0]
+
+
+def test_shot_acc_known_answer():
+    from iif_amd.per_shot_acc import shot_acc
+    train = [0] * 150 + [1] * 50 + [2] * 5
+    labels = np.array([0, 0, 0, 0, 1, 1, 2, 2])
+    preds = np.array([0, 0, 0, 1, 1, 0, 2, 2])
+    many, med, low, per = shot_acc(preds, labels, train, acc_per_cls=True)
+    assert (many, med, low) == (0.75, 0.5, 1.0) and per == [0.75, 0.5, 1.0]
+    m2 = shot_acc(torch.tensor(preds), torch.tensor(labels), np.array(train))
+    assert m2 == (0.75, 0.5, 1.0)
+    with pytest.raises(TypeError):
+        shot_acc(list(preds), labels, train)
+
+
+@pytest.mark.parametrize("mode,per", [("downsampling", 5), ("upsampling", 60), (17, 17)])
+def test_balance_class_sampler(mode, per):
+    from iif_amd.samplers import BalanceClassSampler
+    labels = [0] * 60 + [1] * 20 + [2] * 5
+    s = BalanceClassSampler(labels, mode=mode)
+    np.random.seed(0)
+    idx = list(s)
+    assert len(s) == len(idx) == 3 * per
+    got = np.bincount(np.array(labels)[idx], minlength=3)
+    assert got.tolist() == [per, per, per]
+    for c, n in ((0, 60), (1, 20), (2, 5)):                 # without replacement whenever the class is large enough
+        mine = [i for i in idx if labels[i] == c]
+        if per <= n:
+            assert len(set(mine)) == len(mine)
+
+
+def test_distributed_sampler_wrapper_shards():
+    from iif_amd.samplers import BalanceClassSampler, DistributedSamplerWrapper
+    labels = [0] * 30 + [1] * 10
+    shards = []
+    for r in range(2):
+        np.random.seed(1)
+        w = DistributedSamplerWrapper(BalanceClassSampler(labels, "upsampling"), num_replicas=2, rank=r, shuffle=False)
+        w.set_epoch(0)
+        shards.append(list(w))
+    assert len(shards[0]) == len(shards[1]) == 30
+    np.random.seed(1)
+    full = list(BalanceClassSampler(labels, "upsampling"))
+    assert shards[0] == full[0::2] and shards[1] == full[1::2]
+
+
+def test_optimizer_state_interoperates_with_torch_sgd():
+    from iif_amd import resnet_cifar
+    net = resnet_cifar.resnet20(num_classes=10, device="cpu", compute_dtype=torch.float32)
+    g = torch.Generator().manual_seed(0)
+    net._mom_arena.copy_(torch.randn(net._mom_arena.shape, generator=g))
+    sd = net.optimizer_state_dict(0.05, 0.9, 1e-4, False, initial_lr=0.1)
+    # a reference-side optimizer over same-shaped parameters accepts it as is
+    params = [torch.nn.Parameter(torch.zeros_like(p)) for p in net.parameters()]
+    opt = torch.optim.SGD(params, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    opt.load_state_dict(sd)
+    assert opt.param_groups[0]["lr"] == 0.05
+    for i, (p, v) in enumerate(zip(params, net._arena_views(net._mom_arena))):
+        assert torch.equal(opt.state[p]["momentum_buffer"], v), i
+    # and a torch optimizer's state comes back into the arena
+    for p in params:
+        opt.state[p]["momentum_buffer"].mul_(2.0)
+    net2 = resnet_cifar.resnet20(num_classes=10, device="cpu", compute_dtype=torch.float32)
+    assert net2.load_optimizer_state_dict(opt.state_dict()) == []
+    for v1, v2 in zip(net._arena_views(net._mom_arena), net2._arena_views(net2._mom_arena)):
+        assert torch.equal(v1 * 2.0, v2)
+
+
+def test_scheduler_state_matches_torch():
+    import argparse
+    from iif_amd.train import scheduler_state_dict
+    for cosine in (False, True):
+        args = argparse.Namespace(lr=0.1, cosine_scheduler=cosine, epochs=20, lr_gamma=0.1, milestones=[8, 14])
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=0.1, momentum=0.9)
+        sch = (torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=20) if cosine
+               else torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[8, 14], gamma=0.1))
+        for e in range(10):
+            opt.step(); sch.step()
+        mine, ref = scheduler_state_dict(args, 10), sch.state_dict()
+        assert mine["last_epoch"] == ref["last_epoch"] and abs(mine["_last_lr"][0] - ref["_last_lr"][0]) < 1e-12
+        sch2 = (torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=20) if cosine
+                else torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[8, 14], gamma=0.1))
+        sch2.load_state_dict(mine)                                       # the reference's resume path (train.py:241)
+        assert sch2.last_epoch == 10
