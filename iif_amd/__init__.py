@@ -6,4 +6,10 @@ calling hand-written gfx950 HIP kernels through the C ABI of
 ``classification/`` scripts (custom, resnet_pytorch, resnet_cifar, utils,
 initialisers, imbalanced_dataset, train) so callers switch by import path.
 """
+import os as _os
+
+# Three concurrent HIP streams per rank (main, weight gradients, RCCL): give the runtime enough hardware
+# queues that they never share one (effective only if HIP has not started yet; see DESIGN.md §5).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 __version__ = "0.1.0"

@@ -684,7 +684,10 @@ class _Plan(object):
         self.wg_ws = torch.empty(min(16 * wmax * 4, 512 << 20), dtype=torch.uint8, device=dev)
         self._grad_pool = {}
         self._bwd_ready = False
-        self.wg_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and not os.environ.get("IIF_NO_WGRAD_STREAM")) else None
+        self.wg_stream = None
+        if dev.type == "cuda" and not os.environ.get("IIF_NO_WGRAD_STREAM"):
+            pr = os.environ.get("IIF_WGRAD_STREAM_PRIORITY")
+            self.wg_stream = torch.cuda.Stream(device=dev) if pr is None else torch.cuda.Stream(device=dev, priority=int(pr))
         self._wg_events = {}
 
     def _finish_weight_plan(self):

@@ -21,7 +21,9 @@ import math
 import os
 import time
 
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # distinct hardware queues for the main / wgrad / RCCL streams
+
+import torch   # noqa: E402
 
 from . import custom, initialisers, resnet_cifar, resnet_pytorch, utils
 from .ddp import broadcast_parameters
