@@ -74,66 +74,92 @@ __device__ __forceinline__ RowCoef row_coef(const CeArgs& a, int row) {
 
 // ------------------------------------------------ register-resident row (C%4==0)
 // MODE 0: CE loss + gradient, MODE 1: softmax output (fp32)
+// A wave walks rows wave_id, wave_id + n_waves, ...: the IIF table chunk of the lane stays in registers for
+// all of them, and the next row's logits are already in flight while the current row is reduced.
 template <typename T, int NCH, int MODE>
 __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, int64_t ld_sm) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wpb = blockDim.x >> 6;
+    const int nwaves = gridDim.x * wpb;
+    int row = blockIdx.x * wpb + (threadIdx.x >> 6);
     if (row >= a.B) return;                       // wave-uniform
-    const T* x = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
-    f32x4 z[NCH], t[NCH];
-    float m = -INFINITY;
+    f32x4 t[NCH], xn[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c0 = (j * 64 + lane) * 4;
-        if (c0 < a.C) {
-            t[j] = *reinterpret_cast<const f32x4*>(a.tab + c0);
-            z[j] = Io<T>::load4(x + c0) * t[j];
-            m = fmaxf(m, fmaxf(fmaxf(z[j].x, z[j].y), fmaxf(z[j].z, z[j].w)));
-        } else {
-            t[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            z[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        }
+        t[j] = c0 < a.C ? *reinterpret_cast<const f32x4*>(a.tab + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    m = wave_max(m);
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        z[j].x = expf(z[j].x - m); z[j].y = expf(z[j].y - m);
-        z[j].z = expf(z[j].z - m); z[j].w = expf(z[j].w - m);
-        s += (z[j].x + z[j].y) + (z[j].z + z[j].w);
-    }
-    s = wave_sum(s);
-    const float inv_s = 1.0f / s;
-    if (MODE == 1) {
-        float* o = sm_out + (int64_t)row * ld_sm;
+    {
+        const T* x0 = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c0 = (j * 64 + lane) * 4;
-            if (c0 < a.C) *reinterpret_cast<f32x4*>(o + c0) = z[j] * inv_s;
+            if (c0 < a.C) xn[j] = Io<T>::load4(x0 + c0);
         }
-        return;
     }
-    const float lse = m + logf(s);
-    const RowCoef rc = row_coef(a, row);
-    float r = 0.f;
-    if (rc.ta >= 0) r += rc.wa * (lse - Io<T>::load1(x + rc.ta) * a.tab[rc.ta]);
-    if (rc.tb >= 0) r += rc.wb * (lse - Io<T>::load1(x + rc.tb) * a.tab[rc.tb]);
-    if (lane == 0) a.loss_row[row] = rc.rw * r;
-    if (a.dx == nullptr) return;
-    T* dx = static_cast<T*>(a.dx) + (int64_t)row * a.lddx;
-    const float g = a.scale * rc.rw;
-    const float gs = g * (rc.wa + rc.wb) * inv_s, ga = g * rc.wa, gb = g * rc.wb;
-    const int ia = (int)rc.ta, ib = (int)rc.tb;
+    for (; row < a.B; row += nwaves) {
+        const T* x = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
+        f32x4 z[NCH];
+        float m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int c0 = (j * 64 + lane) * 4;
-        if (c0 < a.C) {
-            f32x4 p = z[j] * gs;
-            p.x -= (ia == c0 ? ga : 0.f) + (ib == c0 ? gb : 0.f);
-            p.y -= (ia == c0 + 1 ? ga : 0.f) + (ib == c0 + 1 ? gb : 0.f);
-            p.z -= (ia == c0 + 2 ? ga : 0.f) + (ib == c0 + 2 ? gb : 0.f);
-            p.w -= (ia == c0 + 3 ? ga : 0.f) + (ib == c0 + 3 ? gb : 0.f);
-            Io<T>::store4(dx + c0, p * t[j]);
+        for (int j = 0; j < NCH; ++j) {
+            const int c0 = (j * 64 + lane) * 4;
+            if (c0 < a.C) {
+                z[j] = xn[j] * t[j];
+                m = fmaxf(m, fmaxf(fmaxf(z[j].x, z[j].y), fmaxf(z[j].z, z[j].w)));
+            } else {
+                z[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+        }
+        if (row + nwaves < a.B) {                 // wave-uniform: next row's loads go out before the reductions
+            const T* x1 = static_cast<const T*>(a.x) + (int64_t)(row + nwaves) * a.ldx;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c0 = (j * 64 + lane) * 4;
+                if (c0 < a.C) xn[j] = Io<T>::load4(x1 + c0);
+            }
+        }
+        m = wave_max(m);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            z[j].x = expf(z[j].x - m); z[j].y = expf(z[j].y - m);
+            z[j].z = expf(z[j].z - m); z[j].w = expf(z[j].w - m);
+            s += (z[j].x + z[j].y) + (z[j].z + z[j].w);
+        }
+        s = wave_sum(s);
+        const float inv_s = 1.0f / s;
+        if (MODE == 1) {
+            float* o = sm_out + (int64_t)row * ld_sm;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c0 = (j * 64 + lane) * 4;
+                if (c0 < a.C) *reinterpret_cast<f32x4*>(o + c0) = z[j] * inv_s;
+            }
+            continue;
+        }
+        const float lse = m + logf(s);
+        const RowCoef rc = row_coef(a, row);
+        float r = 0.f;
+        if (rc.ta >= 0) r += rc.wa * (lse - Io<T>::load1(x + rc.ta) * a.tab[rc.ta]);
+        if (rc.tb >= 0) r += rc.wb * (lse - Io<T>::load1(x + rc.tb) * a.tab[rc.tb]);
+        if (lane == 0) a.loss_row[row] = rc.rw * r;
+        if (a.dx == nullptr) continue;
+        T* dx = static_cast<T*>(a.dx) + (int64_t)row * a.lddx;
+        const float g = a.scale * rc.rw;
+        const float gs = g * (rc.wa + rc.wb) * inv_s, ga = g * rc.wa, gb = g * rc.wb;
+        const int ia = (int)rc.ta, ib = (int)rc.tb;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c0 = (j * 64 + lane) * 4;
+            if (c0 < a.C) {
+                f32x4 p = z[j] * gs;
+                p.x -= (ia == c0 ? ga : 0.f) + (ib == c0 ? gb : 0.f);
+                p.y -= (ia == c0 + 1 ? ga : 0.f) + (ib == c0 + 1 ? gb : 0.f);
+                p.z -= (ia == c0 + 2 ? ga : 0.f) + (ib == c0 + 2 ? gb : 0.f);
+                p.w -= (ia == c0 + 3 ? ga : 0.f) + (ib == c0 + 3 ? gb : 0.f);
+                Io<T>::store4(dx + c0, p * t[j]);
+            }
         }
     }
 }
@@ -238,16 +264,18 @@ template <typename T, int MODE>
 int launch_rows(const CeArgs& a, float* sm_out, int64_t ld_sm, hipStream_t st) {
     const int wpb = a.B <= 4096 ? 1 : 4;
     const dim3 grid((a.B + wpb - 1) / wpb), block(64 * wpb);
+    // register-row kernel: at most 256 CUs x 8 blocks; beyond that a wave walks several rows
+    const dim3 pgrid(grid.x < 2048u ? grid.x : 2048u);
     bool vec = (a.C % 4 == 0) && (a.C <= 2048) && (a.ldx % 4 == 0) && aligned(a.x, Io<T>::kAlign) &&
                aligned(a.tab, 16);
     if (MODE == 0 && a.dx) vec = vec && (a.lddx % 4 == 0) && aligned(a.dx, Io<T>::kAlign);
     if (MODE == 1) vec = vec && (ld_sm % 4 == 0) && aligned(sm_out, 16);
     if (vec) {
         const int nch = (a.C + 255) / 256;
-        if (nch <= 1) hipLaunchKernelGGL((row_reg_kernel<T, 1, MODE>), grid, block, 0, st, a, sm_out, ld_sm);
-        else if (nch <= 2) hipLaunchKernelGGL((row_reg_kernel<T, 2, MODE>), grid, block, 0, st, a, sm_out, ld_sm);
-        else if (nch <= 4) hipLaunchKernelGGL((row_reg_kernel<T, 4, MODE>), grid, block, 0, st, a, sm_out, ld_sm);
-        else hipLaunchKernelGGL((row_reg_kernel<T, 8, MODE>), grid, block, 0, st, a, sm_out, ld_sm);
+        if (nch <= 1) hipLaunchKernelGGL((row_reg_kernel<T, 1, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
+        else if (nch <= 2) hipLaunchKernelGGL((row_reg_kernel<T, 2, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
+        else if (nch <= 4) hipLaunchKernelGGL((row_reg_kernel<T, 4, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
+        else hipLaunchKernelGGL((row_reg_kernel<T, 8, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
     } else {
         hipLaunchKernelGGL((row_stream_kernel<T, MODE>), grid, block, 0, st, a, sm_out, ld_sm);
     }
