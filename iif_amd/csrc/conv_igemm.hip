@@ -63,6 +63,18 @@ __device__ __forceinline__ int64_t dst_row(const ConvArgs& a, int m) {
 
 __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
+#ifdef IIF_CONV_STAMPS
+// Diagnostic build only (make stamps): per-wave cycle sums of the K-step phases of the LDS-DMA kernel, written to
+// a buffer of their own (cdna_hip_programming.md §7, in-kernel stamps).  Read the SHARES, not the run time.
+__device__ unsigned long long* g_stamps = nullptr;
+#define IIF_STAMP(var)                                                                             \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#endif
+
 // epilogue: lane holds channels n0 + wn*BN/2 + ci*16 + fc*4 + {0..3} of pixel m0 + wm*64 + pj*16 + fr
 template <typename T, int BN, bool OUTF32>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BN / 32][4], int m0, int n0, int wm, int wn,
@@ -274,13 +286,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
 // written back with 16 B per lane, i.e. whole 128-B lines (the direct form writes 8 B per lane in 32-B
 // runs).  The residual is read the same way.  With bn_partial the per-channel (sum, sum of squares) of the
 // bf16-rounded tile are emitted too, so batch-norm statistics need no extra pass over the activation.
-template <int BN>
+template <int BN, int BM = 128>
 __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&acc)[BN / 32][4], unsigned char* smem,
                                                      int m0, int n0, int mt, int wm, int wn, int fr, int fc, int goff) {
     constexpr int CI = BN / 32;
+    constexpr int NT = BM * 2;                  // threads of the block (4 or 8 waves)
     constexpr int PITCH = BN * 2 + 16;
     constexpr int CPR = BN / 8;                 // 16-byte chunks per row
-    constexpr int RPP = 256 / CPR;              // rows per pass
+    constexpr int RPP = NT / CPR;               // rows per pass
     const int tid = threadIdx.x;
     __syncthreads();                            // every wave is done reading the last stage
 #pragma unroll
@@ -298,7 +311,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
     const int n = n0 + chunk * 8;
     if (n < a.Cd) {
 #pragma unroll 4
-        for (int row = r0; row < 128; row += RPP) {
+        for (int row = r0; row < BM; row += RPP) {
             const int m = m0 + row;
             if (m >= a.M) break;
             u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PITCH + chunk * 16);
@@ -319,8 +332,8 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
     if (a.bn_partial) {
         // all 256 threads: channel tid % BN, row group tid / BN; groups are combined in fixed order through
         // LDS scratch behind the tile, so each pixel tile contributes ONE partial row
-        constexpr int GROUPS = 256 / BN, RPG = 128 / GROUPS;
-        float* scratch = reinterpret_cast<float*>(smem + 128 * PITCH);
+        constexpr int GROUPS = NT / BN, RPG = BM / GROUPS;
+        float* scratch = reinterpret_cast<float*>(smem + BM * PITCH);
         const int ch = tid % BN, grp = tid / BN;
         float sm = 0.f, q = 0.f;
 #pragma unroll 8
@@ -328,12 +341,12 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
             const float x = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(smem + row * PITCH + ch * 2));
             sm += x; q = fmaf(x, x, q);
         }
-        scratch[tid] = sm; scratch[256 + tid] = q;
+        scratch[tid] = sm; scratch[NT + tid] = q;
         __syncthreads();
         if (tid < BN && n0 + tid < a.Cd) {
             float s2 = 0.f, q2 = 0.f;
 #pragma unroll
-            for (int gi = 0; gi < GROUPS; ++gi) { s2 += scratch[gi * BN + tid]; q2 += scratch[256 + gi * BN + tid]; }
+            for (int gi = 0; gi < GROUPS; ++gi) { s2 += scratch[gi * BN + tid]; q2 += scratch[NT + gi * BN + tid]; }
             float* p = a.bn_partial + (int64_t)mt * 2 * a.dpitch + goff + n0 + tid;
             p[0] = s2; p[a.dpitch] = q2;
         }
@@ -346,11 +359,15 @@ typedef __attribute__((address_space(3))) void lds_void;
 // so the tap / channel-chunk displacement is a wave-uniform SCALAR (the buffer instruction's soffset) and
 // the per-lane voffset (pixel base + this lane's chunk) never changes: address generation costs ~3 VALU
 // instructions per row per step (a tap-validity bit test), instead of the general per-piece arithmetic.
-template <typename T, int BN, bool OUTF32, bool UTAP>
+template <typename T, int BN, bool OUTF32, bool UTAP, int NW = 4>
 __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned src_bytes, unsigned wgt_bytes) {
-    constexpr int BM = 128;
+    // NW waves, each 64 pixels x BN/2 channels: 128 x BN (4 waves) or 256 x 128 (8 waves).  The larger tile moves
+    // 12 instead of 16 KB through the vector L1 per MFLOP: the stamps (scripts/conv_stamps.py) show the 4-wave
+    // kernel spending half of every K step issuing its LDS-DMA, i.e. bound by the 64 B/clk L1 path, not by MFMA.
+    constexpr int BM = 32 * NW;
     constexpr int PE = ET<T>::PE, KE = ET<T>::KE;
-    constexpr int NBI = BN / 64;        // weight DMA pieces per wave per stage
+    constexpr int NBI = BN / (16 * NW);  // weight DMA pieces per wave per stage
+    static_assert(NBI >= 1, "8 waves need the 128-channel tile");
     constexpr int CI = BN / 32;
     constexpr int STAGE = (BM + BN) * 64;
     constexpr int LPS = 2 + NBI;        // DMA instructions per wave per stage
@@ -531,19 +548,39 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     using S2 = std::integral_constant<int, 2>;
     // one K step on LDS stage S: retire this wave's DMA of step k (leave step k+1's in flight), meet the
     // other waves, refill the stage that was read in step k-1 with step k+2, multiply stage S
+#ifdef IIF_CONV_STAMPS
+    unsigned long long st_wait = 0, st_lds = 0, st_dma = 0, st_mfma = 0, st_prev = 0, st_begin = 0;
+    IIF_STAMP(st_begin);
+    st_prev = st_begin;
+#endif
     auto step = [&](auto stage_c, auto refill_c, int k) {
         constexpr int S = decltype(stage_c)::value;
+#ifdef IIF_CONV_STAMPS
+        unsigned long long t0, t1, t2, t3;
+        IIF_STAMP(t0);
+        st_mfma += t0 - st_prev;               // previous step's MFMA issue (first step: prologue)
+#endif
         if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef IIF_CONV_STAMPS
+        IIF_STAMP(t1);
+#endif
         const unsigned char* base = smem + S * STAGE;
         u32x4 wf[CI], xf[4];
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) wf[ci] = *reinterpret_cast<const u32x4*>(base + wofs[ci]);
 #pragma unroll
         for (int pj = 0; pj < 4; ++pj) xf[pj] = *reinterpret_cast<const u32x4*>(base + xofs[pj]);
+#ifdef IIF_CONV_STAMPS
+        IIF_STAMP(t2);
+#endif
         // the refill DMA is issued behind the fragment reads, so its issue time covers their LDS latency
         if (k + 2 < nk) { advance(); issue(refill_c); }
+#ifdef IIF_CONV_STAMPS
+        IIF_STAMP(t3);
+        st_wait += t1 - t0; st_lds += t2 - t1; st_dma += t3 - t2; st_prev = t3;
+#endif
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
@@ -567,9 +604,22 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
         if (k + 1 < nk) step(S1{}, S0{}, k + 1);
         if (k + 2 < nk) step(S2{}, S1{}, k + 2);
     }
+#ifdef IIF_CONV_STAMPS
+    unsigned long long st_loop_end, st_end;
+    IIF_STAMP(st_loop_end);
+    st_mfma += st_loop_end - st_prev;
+#endif
     if constexpr (sizeof(T) == 2 && !OUTF32) {
         if ((a.Cd & 7) == 0 && a.bias == nullptr) {     // wave-uniform
-            conv_epilogue_staged<BN>(a, acc, smem, m0, n0, mt, wm, wn, fr, fc, grp * a.Cd);
+            conv_epilogue_staged<BN, BM>(a, acc, smem, m0, n0, mt, wm, wn, fr, fc, grp * a.Cd);
+#ifdef IIF_CONV_STAMPS
+            IIF_STAMP(st_end);
+            if (g_stamps && b < 512 && lane == 0) {
+                unsigned long long* o = g_stamps + ((int64_t)b * 4 + wave) * 8;
+                o[0] = st_wait; o[1] = st_lds; o[2] = st_dma; o[3] = st_mfma; o[4] = st_end - st_loop_end;
+                o[5] = st_end - st_begin; o[6] = (unsigned long long)nk; o[7] = st_begin;
+            }
+#endif
             return;
         }
     }
@@ -588,7 +638,35 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_utap_kernel(ConvArgs a, un
 }
 
 template <typename T, bool OUTF32>
+__global__ void __launch_bounds__(512) conv_igemm_dma_utap256_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+    conv_igemm_dma_body<T, 128, OUTF32, true, 8>(a, src_bytes, wgt_bytes);
+}
+
+// 256-pixel tiles: bf16 uniform-tap launches wide enough for the 128-channel tile whose 256-row grid still fills
+// the chip (2 blocks per CU resident).  IIF_CONV_BM=128|256 forces a choice (experiments).
+inline bool use_bm256(const ConvArgs& a, bool utap, int esz) {
+    static const char* force = getenv("IIF_CONV_BM");
+    if (!utap || esz != 2 || a.Cd <= 64 || a.groups > 1) return false;
+    if (force) return atoi(force) == 256;
+    // measured (scripts/bm_ab.sh): +13..39 % on K >= 1024 (3x3 at 128/256 channels, 1x1 from 1024 channels) when the
+    // 256-row grid still offers >= 1.5 blocks per CU; short K loops and small grids are better off with 128 rows
+    const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.Cd + 127) / 128);
+    return tiles >= 384 && a.ntaps * a.Cs >= 1024;
+}
+
+template <typename T, bool OUTF32>
 int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
+    static const bool force_v1_ = getenv("IIF_CONV_REGSTAGE") != nullptr;
+    if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_bm256(a, utap, (int)sizeof(T))) {
+        a.mtiles = (a.M + 255) / 256;
+        a.ntiles = (a.Cd + 127) / 128;
+        const int64_t blocks256 = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
+        if (blocks256 > 0x7fffffff) return IIF_EUNSUPPORTED;
+        hipLaunchKernelGGL((conv_igemm_dma_utap256_kernel<T, OUTF32>), dim3((unsigned)blocks256, (unsigned)a.groups), dim3(512), 0,
+                           st, a, (unsigned)src_bytes, (unsigned)wgt_bytes);
+        IIF_LAUNCH_CHECK();
+        return IIF_OK;
+    }
     a.mtiles = (a.M + 127) / 128;
     const bool narrow = a.Cd <= 64;
     const int bn = narrow ? 64 : 128;
@@ -724,9 +802,13 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
     if (n_partials) *n_partials = 0;
     if (bn_partial) {
         // fused statistics need the LDS-staged bf16 epilogue of the pipelined kernel
-        const int64_t mt = (M + 127) / 128;
+        // one partial row per pixel tile; the tile height is the one launch_one will pick for this shape
+        ConvArgs p{};
+        p.M = (int)M; p.Cd = d->cd; p.Cs = d->cs; p.ntaps = d->r * d->s; p.groups = d->groups > 1 ? d->groups : 1;
+        const bool utap_p = getenv("IIF_CONV_GENERAL_ADDR") == nullptr && (d->cs % 32) == 0 && d->r * d->s <= 16;
+        const int64_t mt = use_bm256(p, utap_p && d->dtype == IIF_BF16, 2) ? (M + 255) / 256 : (M + 127) / 128;
         const int64_t esz0 = 2;
-        const int64_t groups = 1;                         // one partial row per 128-pixel tile
+        const int64_t groups = 1;
         const bool ok = d->dtype == IIF_BF16 && d->dst_dtype == IIF_BF16 && (d->cd % 8) == 0 && !bias && !res &&
                         getenv("IIF_CONV_REGSTAGE") == nullptr &&
                         (int64_t)d->n * d->hs * d->ws * d->cs * (d->groups > 1 ? d->groups : 1) * esz0 < 0x7f000000LL &&
@@ -752,3 +834,9 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
     return launch_conv<float, true>(a, src_bytes, wgt_bytes, st);
 }
 }  // namespace
+
+#ifdef IIF_CONV_STAMPS
+extern "C" int iif_debug_set_stamps(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? IIF_OK : IIF_ELAUNCH;
+}
+#endif

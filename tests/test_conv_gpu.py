@@ -152,7 +152,7 @@ def test_conv_fused_bn_statistics(case):
     out = torch.empty(n, ho, wo, cout, dtype=dt, device=DEV)
     partial = torch.full((((m + 127) // 128) * 2 * cout,), float("nan"), device=DEV)
     nt = ops.conv_forward_bnstats(xd, wd, r, r, stride, pad, out, partial)
-    assert nt == (m + 127) // 128
+    assert nt in ((m + 127) // 128, (m + 255) // 256)        # one partial per pixel tile (128 or 256 rows)
     ref = F.conv2d(x.float(), wt.float(), None, stride, pad)
     got = out.float().cpu().permute(0, 3, 1, 2)
     assert (got - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
