@@ -309,6 +309,11 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
     __syncthreads();
     const int chunk = tid % CPR, r0 = tid / CPR;
     const int n = n0 + chunk * 8;
+    // batch-norm partial sums of the STORED (bf16-rounded) values ride along with the store loop: every thread
+    // already holds 8 channels of each row it writes
+    float bs[8], bq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bs[q] = 0.f; bq[q] = 0.f; }
     if (n < a.Cd) {
 #pragma unroll 4
         for (int row = r0; row < BM; row += RPP) {
@@ -327,26 +332,40 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
                 }
             }
             *reinterpret_cast<u32x4*>(a.dst + o) = v;
+            if (a.bn_partial) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = bf16_bits_to_f32(v[q] & 0xffffu), hi = __uint_as_float(v[q] & 0xffff0000u);
+                    bs[2 * q] += lo; bq[2 * q] = fmaf(lo, lo, bq[2 * q]);
+                    bs[2 * q + 1] += hi; bq[2 * q + 1] = fmaf(hi, hi, bq[2 * q + 1]);
+                }
+            }
         }
     }
     if (a.bn_partial) {
-        // all 256 threads: channel tid % BN, row group tid / BN; groups are combined in fixed order through
-        // LDS scratch behind the tile, so each pixel tile contributes ONE partial row
-        constexpr int GROUPS = NT / BN, RPG = BM / GROUPS;
-        float* scratch = reinterpret_cast<float*>(smem + BM * PITCH);
-        const int ch = tid % BN, grp = tid / BN;
-        float sm = 0.f, q = 0.f;
-#pragma unroll 8
-        for (int row = grp * RPG; row < (grp + 1) * RPG; ++row) {
-            const float x = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(smem + row * PITCH + ch * 2));
-            sm += x; q = fmaf(x, x, q);
+        // lanes of a wave that share the chunk (lane % CPR), then the block's waves through LDS scratch behind the
+        // tile: fixed order, ONE partial row per pixel tile
+        constexpr int NWV = NT / 64;
+        float* scratch = reinterpret_cast<float*>(smem);                    // [NWV][2][BN], over the drained tile
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) { bs[q] += __shfl_xor(bs[q], o, 64); bq[q] += __shfl_xor(bq[q], o, 64); }
         }
-        scratch[tid] = sm; scratch[NT + tid] = q;
+        __syncthreads();                            // every thread has read its rows of the staged tile
+        const int lane = tid & 63, wv = tid >> 6;
+        if (lane < CPR) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                scratch[(wv * 2 + 0) * BN + lane * 8 + q] = bs[q];
+                scratch[(wv * 2 + 1) * BN + lane * 8 + q] = bq[q];
+            }
+        }
         __syncthreads();
         if (tid < BN && n0 + tid < a.Cd) {
             float s2 = 0.f, q2 = 0.f;
 #pragma unroll
-            for (int gi = 0; gi < GROUPS; ++gi) { s2 += scratch[gi * BN + tid]; q2 += scratch[NT + gi * BN + tid]; }
+            for (int w = 0; w < NWV; ++w) { s2 += scratch[(w * 2 + 0) * BN + tid]; q2 += scratch[(w * 2 + 1) * BN + tid]; }
             float* p = a.bn_partial + (int64_t)mt * 2 * a.dpitch + goff + n0 + tid;
             p[0] = s2; p[a.dpitch] = q2;
         }
