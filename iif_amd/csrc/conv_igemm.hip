@@ -656,6 +656,167 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_utap_kernel(ConvArgs a, un
     conv_igemm_dma_body<T, BN, OUTF32, true>(a, src_bytes, wgt_bytes);
 }
 
+
+// ---------------------------------------------------------------- 3x3 / stride 1 / pad 1 with an LDS halo window
+// The tap-by-tap kernel above pulls every source pixel through the vector L1 nine times (once per tap); the stamps
+// show that path, not the MFMA, bounding it.  Here a 256-pixel tile loads the (rows + 2) x (W + 2) window of its
+// source pixels ONCE per 32-channel chunk (a "halo" image in LDS, double buffered) and reads the nine taps'
+// fragments out of it at displaced rows; only the weights still stream per tap (a 6-deep ring, 8 KB per step).
+// L1 traffic per MFLOP drops from 16 KB (128x128 tap kernel) to ~6 KB.  Pixels are addressed in "virtual" rows
+// v = n*(H+2) + y + 1 so that every image carries its own zero rows above and below: halo pixels that fall on them,
+// or left/right of the image, are out-of-range lanes of the LDS-DMA (zeros, no traffic).
+// bf16, 8 waves x (64 pixels x 64 channels), forward and stride-1 data gradient (tap list), staged epilogue.
+__global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+    constexpr int BM = 256, BN = 128, CI = BN / 32;
+    constexpr int HR = 512, ABUF = HR * 64;          // halo rows per buffer, 64 B (32 channels) each
+    constexpr int BST = BN * 64, NBS = 6;            // weight stage and ring depth
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * ABUF + NBS * BST];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int mt = (j / a.ntiles) * 8 + xcd, nt = j % a.ntiles;
+    if (mt >= a.mtiles) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int H = a.Hd, W = a.Wd, HW = H * W, W2 = W + 2, H2 = H + 2;
+    // virtual row of the tile's first / last pixel
+    const int nf = m0 / HW, remf = m0 - nf * HW;
+    const int vfirst = nf * H2 + remf / W + 1;
+    const int mlast = (m0 + BM - 1 < a.M ? m0 + BM - 1 : a.M - 1);
+    const int nl = mlast / HW, reml = mlast - nl * HW;
+    const int vlast = nl * H2 + reml / W + 1;
+    const int vbase = vfirst - 1;
+    const int Hn = (vlast - vfirst + 3) * W2;        // halo rows in use (host guarantees <= HR)
+
+    const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src), 0, src_bytes, 0x00020000);
+    const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wgt), 0, wgt_bytes, 0x00020000);
+
+    // ---- DMA roles of this lane.  Halo piece p (16 halo rows) is issued by wave p % 8 as its (p / 8)-th piece.
+    unsigned avoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int hr = 16 * (wave + 8 * i) + (lane >> 2);
+        const int chunk = (lane & 3) ^ swz(hr);
+        const int vr = vbase + hr / W2, xx = hr % W2 - 1;
+        const int nn = vr / H2, yy = vr % H2 - 1;
+        const bool ok = hr < Hn && nn < a.N && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        avoff[i] = ok ? ((unsigned)((nn * H + yy) * W + xx) * (unsigned)a.spitch + (unsigned)(chunk * 8)) * 2u : OOB;
+    }
+    unsigned bvoff;
+    {
+        const int row = 16 * wave + (lane >> 2);
+        const int chunk = (lane & 3) ^ swz(row);
+        bvoff = n0 + row < a.Cd ? ((unsigned)(n0 + row) * (unsigned)a.ldw + (unsigned)(chunk * 8)) * 2u : OOB;
+    }
+    // ---- fragment addresses
+    const int fr = lane & 15, fc = lane >> 4;
+    int wofs[CI], hrow0[4];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+        const int row = wn * (BN / 2) + ci * 16 + fr;
+        wofs[ci] = row * 64 + ((fc ^ swz(row)) << 4);
+    }
+#pragma unroll
+    for (int pj = 0; pj < 4; ++pj) {
+        const int m = m0 + wm * 64 + pj * 16 + fr;
+        const int mm = m < a.M ? m : m0;
+        const int n = mm / HW, rem = mm - n * HW;
+        const int y = rem / W, x = rem - y * W;
+        hrow0[pj] = (n * H2 + y + 1 - vbase) * W2 + x + 1;
+    }
+    f32x4 acc[CI][4];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) acc[ci][pj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = a.Cs / 32;
+    const int G = nchunks * 9;
+    unsigned char* const Bring = smem + 2 * ABUF;
+    auto issue_a = [&](int c, int i) {                         // piece i of this wave for chunk c (c >= nchunks: no-op zeros)
+        unsigned char* dst = smem + (c & 1) * ABUF + (wave + 8 * i) * 1024;
+        const unsigned off = c < nchunks ? avoff[i] : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)dst, 16, off, (unsigned)(c * 64), 0, 0);
+    };
+    auto issue_b = [&](int g, int slot) {                       // weights of global step g = (chunk, tap)
+        const int c = g / 9, t = g - c * 9;
+        unsigned char* dst = Bring + slot * BST + wave * 1024;
+        const unsigned off = g < G ? bvoff : OOB;
+        const unsigned so = g < G ? (unsigned)(a.tap_w[t] * a.Cs + c * 32) * 2u : 0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)dst, 16, off, so, 0, 0);
+    };
+    // prologue: halo of chunk 0, then the first five weight stages (program order fixes the counted waits below)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_a(0, i);
+#pragma unroll
+    for (int g = 0; g < 5; ++g) issue_b(g, g);
+
+    // (Software-pipelining the fragment reads into a second register set was measured 5 % slower: 214 VGPRs.)
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) toff[t] = a.tap_dy[t] * W2 + a.tap_dx[t];
+    int slot = 0;                                               // ring slot of the step being fetched
+    // fetch(T, g, c): arrival sync of step g = (chunk c, tap T), refill DMAs, fragment reads of step g
+    auto fetch = [&](auto tc, int g, int c, u32x4 (&wf)[CI], u32x4 (&xf)[4]) {
+        constexpr int T = decltype(tc)::value;
+        // loads issued after this step's weights: 4 later weight stages + the halo pieces of the last 5 steps
+        constexpr int NPEND[9] = {4, 5, 6, 7, 8, 8, 7, 6, 5};
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPEND[T]) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the slot about to be refilled
+        __builtin_amdgcn_s_barrier();
+        const int refill = slot == 0 ? NBS - 1 : slot - 1;      // the slot read in the previous step
+        issue_b(g + 5, refill);
+        if constexpr (T < 4) issue_a(c + 1, T);
+        const unsigned char* Ab = smem + (c & 1) * ABUF;
+        const unsigned char* Bb = Bring + slot * BST;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) wf[ci] = *reinterpret_cast<const u32x4*>(Bb + wofs[ci]);
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) {
+            const int hr = hrow0[pj] + toff[T];
+            xf[pj] = *reinterpret_cast<const u32x4*>(Ab + hr * 64 + ((fc ^ swz(hr)) << 4));
+        }
+        slot = slot == NBS - 1 ? 0 : slot + 1;
+    };
+    auto mma = [&](const u32x4 (&wf)[CI], const u32x4 (&xf)[4]) {
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj)
+                acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wf[ci]), __builtin_bit_cast(bf16x8, xf[pj]), acc[ci][pj], 0, 0, 0);
+    };
+#ifdef IIF_CONV_STAMPS
+    unsigned long long st_fetch = 0, st_mma = 0, st_a, st_b, st_c, st_begin;
+    IIF_STAMP(st_begin);
+#endif
+    for (int c = 0; c < nchunks; ++c) {
+        const int g0 = c * 9;
+        u32x4 wf[CI], xf[4];
+#ifdef IIF_CONV_STAMPS
+#define IIF_HALO_STEP(T) IIF_STAMP(st_a); fetch(std::integral_constant<int, T>{}, g0 + T, c, wf, xf); IIF_STAMP(st_b); \
+                         mma(wf, xf); IIF_STAMP(st_c); st_fetch += st_b - st_a; st_mma += st_c - st_b;
+#else
+#define IIF_HALO_STEP(T) fetch(std::integral_constant<int, T>{}, g0 + T, c, wf, xf); mma(wf, xf);
+#endif
+        IIF_HALO_STEP(0) IIF_HALO_STEP(1) IIF_HALO_STEP(2) IIF_HALO_STEP(3) IIF_HALO_STEP(4)
+        IIF_HALO_STEP(5) IIF_HALO_STEP(6) IIF_HALO_STEP(7) IIF_HALO_STEP(8)
+#undef IIF_HALO_STEP
+    }
+#ifdef IIF_CONV_STAMPS
+    IIF_STAMP(st_c);
+    if (g_stamps && b < 512 && lane == 0 && wave < 4) {
+        unsigned long long* o = g_stamps + ((int64_t)b * 4 + wave) * 8;
+        o[0] = st_fetch; o[1] = 0; o[2] = 0; o[3] = st_mma; o[4] = 0; o[5] = st_c - st_begin; o[6] = (unsigned long long)G; o[7] = st_begin;
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the tail's no-op DMAs still write zeros to LDS
+    conv_epilogue_staged<BN, BM>(a, acc, smem, m0, n0, mt, wm, wn, fr, fc, 0);
+}
+
 template <typename T, bool OUTF32>
 __global__ void __launch_bounds__(512) conv_igemm_dma_utap256_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     conv_igemm_dma_body<T, 128, OUTF32, true, 8>(a, src_bytes, wgt_bytes);
@@ -673,9 +834,32 @@ inline bool use_bm256(const ConvArgs& a, bool utap, int esz) {
     return tiles >= 384 && a.ntaps * a.Cs >= 1024;
 }
 
+// halo kernel: bf16 3x3 / stride 1 / pad 1, dense, >= 128 output channels, window of a 256-pixel tile <= 512 halo rows
+inline bool use_halo(const ConvArgs& a, bool utap, int esz, bool outf32) {
+    static const char* off = getenv("IIF_CONV_NO_HALO");
+    if (off || !utap || esz != 2 || outf32 || a.groups > 1 || a.scatter || a.in_shift != 0) return false;
+    if (a.ntaps != 9 || a.R != 3 || a.S != 3 || a.pad != 1 || a.Hs != a.Hd || a.Ws != a.Wd) return false;
+    if (a.Cd < 128 || (a.Cd & 7) || a.bias || (a.Cs % 32)) return false;
+    const int HW = a.Hd * a.Wd;
+    const int span = (256 + a.Wd - 1) / a.Wd + 1 + 2 * (256 / HW + 1);       // virtual rows a tile can touch
+    if ((span + 2) * (a.Wd + 2) > 512) return false;
+    static const char* force = getenv("IIF_CONV_HALO_FORCE");                 // tests: small grids too
+    return force || (int64_t)((a.M + 255) / 256) * ((a.Cd + 127) / 128) >= 192;
+}
+
 template <typename T, bool OUTF32>
 int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
     static const bool force_v1_ = getenv("IIF_CONV_REGSTAGE") != nullptr;
+    if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_halo(a, utap, (int)sizeof(T), OUTF32)) {
+        a.mtiles = (a.M + 255) / 256;
+        a.ntiles = (a.Cd + 127) / 128;
+        const int64_t blocksh = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
+        if (blocksh > 0x7fffffff) return IIF_EUNSUPPORTED;
+        hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)blocksh), dim3(512), 0, st, a, (unsigned)src_bytes,
+                           (unsigned)wgt_bytes);
+        IIF_LAUNCH_CHECK();
+        return IIF_OK;
+    }
     if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_bm256(a, utap, (int)sizeof(T))) {
         a.mtiles = (a.M + 255) / 256;
         a.ntiles = (a.Cd + 127) / 128;
@@ -825,7 +1009,11 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
         ConvArgs p{};
         p.M = (int)M; p.Cd = d->cd; p.Cs = d->cs; p.ntaps = d->r * d->s; p.groups = d->groups > 1 ? d->groups : 1;
         const bool utap_p = getenv("IIF_CONV_GENERAL_ADDR") == nullptr && (d->cs % 32) == 0 && d->r * d->s <= 16;
-        const int64_t mt = use_bm256(p, utap_p && d->dtype == IIF_BF16, 2) ? (M + 255) / 256 : (M + 127) / 128;
+        p.R = d->r; p.S = d->s; p.pad = d->pad; p.Hs = d->hs; p.Ws = d->ws; p.Hd = d->hd; p.Wd = d->wd;
+        p.in_shift = d->stride - 1; p.bias = bias;
+        const bool big = use_bm256(p, utap_p && d->dtype == IIF_BF16, 2) ||
+                         use_halo(p, utap_p && d->dtype == IIF_BF16, 2, d->dst_dtype == IIF_F32);
+        const int64_t mt = big ? (M + 255) / 256 : (M + 127) / 128;
         const int64_t esz0 = 2;
         const int64_t groups = 1;
         const bool ok = d->dtype == IIF_BF16 && d->dst_dtype == IIF_BF16 && (d->cd % 8) == 0 && !bias && !res &&
