@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libiif_amd.so")
+# IIF_AMD_LIB: another build of the same C ABI (the stamped diagnostic build, A/B experiments)
+LIB_PATH = os.environ.get("IIF_AMD_LIB") or os.path.join(_HERE, "csrc", "libiif_amd.so")
 
 IIF_F32, IIF_BF16 = 0, 1
 VARIANT_CODE = {"raw": 0, "smooth": 1, "rel": 2, "normit": 3, "gombit": 4, "base2": 5, "base10": 6}
@@ -66,6 +67,8 @@ SIGNATURES = {
     "iif_class_accumulate": [_P, _P, _I, _I, _P, _P, _P],
     "iif_fasa_update": [_P, _P, _I, _I, _L, _I, _F, _P, _P, _P, _P],
     "iif_fasa_generate": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
+    "iif_conv_igemm_dgrad_bnbwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
+    "iif_bn_backward_partials": [_P, _P, _P, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P],
     "iif_rowmap_forward": [_P, _I, _I, _I, _L, _I, _F, _F, _P, _I, _L, _P, _P],
     "iif_rowmap_backward": [_P, _I, _P, _P, _I, _I, _I, _L, _L, _I, _F, _F, _P, _I, _L, _P],
     "iif_transpose_f32": [_P, _I, _I, _L, _P, _L, _P],

@@ -307,25 +307,42 @@ int bn_apply_t(const T* x, const float* stats, const T* r, const float* stats2, 
     return IIF_OK;
 }
 
+// ext_partial (nullable): [n_ext][2][C] rows of (sum dy, sum dy*xhat) already produced elsewhere (the epilogue of the
+// data-gradient convolution that wrote gy): the reduction pass over gy and x is skipped.
 template <typename T>
 int bn_backward_t(const T* gy, const T* ymask, const unsigned char* bits, const T* x, const float* stats, const float* gamma,
-                  int64_t M, int C, float* dgamma, float* dbeta, T* dx, T* gm, float* ws, int64_t ws_bytes, hipStream_t st) {
+                  int64_t M, int C, float* dgamma, float* dbeta, T* dx, T* gm, float* ws, int64_t ws_bytes, hipStream_t st,
+                  const float* ext_partial = nullptr, int n_ext = 0) {
     constexpr int V = VT<T>::V;
     Geo g = make_geo(M, C, V, 512);
     const int64_t need = ((int64_t)g.nblk * 2 * C + 3 * C) * 4;
     if (need > ws_bytes) return IIF_EINVAL;
     float* coef = ws + (int64_t)g.nblk * 2 * C;
     const dim3 rgrid(g.nblk, g.colblocks), blk(256);
-    if (bits) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
-    else if (ymask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
-    IIF_LAUNCH_CHECK();
+    const float* fin_src = ws;
+    if (ext_partial) {
+        fin_src = ext_partial;
+        g.nblk = n_ext;
+        if (n_ext > 512) {                       // many tile rows: 64 slices first (fixed order), as in the forward path
+            const int slices = 64, rps = (n_ext + slices - 1) / slices;
+            if ((int64_t)(slices * 2 * C + 3 * C) * 4 > ws_bytes) return IIF_EINVAL;
+            hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 31) / 32, slices), blk, 0, st, ext_partial, n_ext, C, rps, ws);
+            IIF_LAUNCH_CHECK();
+            fin_src = ws; g.nblk = slices;
+            coef = ws + (int64_t)slices * 2 * C;
+        }
+    } else {
+        if (bits) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
+        else if (ymask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
+        IIF_LAUNCH_CHECK();
+    }
     {
         const int cb = finalize_cb(g.nblk);
         const dim3 fgrid((C + cb - 1) / cb);
-        if (cb == 4) hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, fgrid, blk, 0, st, ws, g.nblk, C, (double)M, gamma, stats, dgamma, dbeta, coef);
-        else if (cb == 8) hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, fgrid, blk, 0, st, ws, g.nblk, C, (double)M, gamma, stats, dgamma, dbeta, coef);
-        else hipLaunchKernelGGL(bn_bwd_finalize_kernel<32>, fgrid, blk, 0, st, ws, g.nblk, C, (double)M, gamma, stats, dgamma, dbeta, coef);
+        if (cb == 4) hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, fgrid, blk, 0, st, fin_src, g.nblk, C, (double)M, gamma, stats, dgamma, dbeta, coef);
+        else if (cb == 8) hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, fgrid, blk, 0, st, fin_src, g.nblk, C, (double)M, gamma, stats, dgamma, dbeta, coef);
+        else hipLaunchKernelGGL(bn_bwd_finalize_kernel<32>, fgrid, blk, 0, st, fin_src, g.nblk, C, (double)M, gamma, stats, dgamma, dbeta, coef);
     }
     IIF_LAUNCH_CHECK();
     const int cv = C / V;
@@ -420,6 +437,18 @@ int iif_bn_backward(const void* gy, const void* y_mask, const uint8_t* relu_bits
                                              workspace_bytes, as_stream(stream));
     }
     return IIF_EINVAL;
+}
+
+int iif_bn_backward_partials(const void* gy, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,
+                             const float* stats, const float* gamma, const float* partial, int n_partials, float* dgamma,
+                             float* dbeta, void* dx, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!gy || !x || !stats || !gamma || !partial || n_partials <= 0 || !dgamma || !dbeta || !dx || !workspace || m <= 0 || c <= 0)
+        return IIF_EINVAL;
+    if (m > 0x7fffff00LL || bad_align(gy) || bad_align(x) || bad_align(dx)) return IIF_EUNSUPPORTED;
+    if (dtype != IIF_BF16 || c % 8) return IIF_EUNSUPPORTED;
+    return bn_backward_t<unsigned short>((const unsigned short*)gy, nullptr, relu_bits, (const unsigned short*)x, stats, gamma, m, c,
+                                         dgamma, dbeta, (unsigned short*)dx, nullptr, (float*)workspace, workspace_bytes,
+                                         as_stream(stream), partial, n_partials);
 }
 
 }  // extern "C"

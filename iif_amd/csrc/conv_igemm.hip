@@ -39,6 +39,14 @@ struct ConvArgs {
     const unsigned char* src; const unsigned char* wgt; unsigned char* dst; const unsigned char* res;
     const float* bias;
     const unsigned char* res_bits;   // nullable: 1 bit per residual element (ReLU decisions); the residual is masked by it
+    // nullable: the batch-norm BACKWARD partial sums of the unit whose output gradient this launch writes
+    // (dst = dL/dy of that unit): bw_x its pre-normalisation output, bw_bits its ReLU decisions (nullable = no
+    // ReLU), bw_stats its (mean at [c], invstd at [Cd + c]).  bn_partial then receives per tile
+    // (sum g, sum g*xhat) with g = dst * [bit] instead of the forward (sum, sum of squares).
+    const unsigned char* bw_x; const unsigned char* bw_bits; const float* bw_stats;
+    int bn_row0;           // first partial row of this launch (launches that share one partial buffer)
+    int* rows_out;         // host only: receives bn_row0 + tiles of the launch (the partial rows written so far)
+    long long bn_cap;      // host only: floats available behind bn_partial
     float* bn_partial;     // nullable: [mtiles][2][Cd] per-tile (sum, sum of squares) of the stored output
     int N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, sshift, pad, transposed, ldw, M, K, mtiles, ntiles;
     int spitch, dpitch, groups;   // channels per pixel of the source / destination TENSORS (= groups * Cs / Cd)
@@ -311,10 +319,15 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
     const int n = n0 + chunk * 8;
     // batch-norm partial sums of the STORED (bf16-rounded) values ride along with the store loop: every thread
     // already holds 8 channels of each row it writes
-    float bs[8], bq[8];
+    float bs[8], bq[8], bmean[8], bistd[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { bs[q] = 0.f; bq[q] = 0.f; }
+    for (int q = 0; q < 8; ++q) { bs[q] = 0.f; bq[q] = 0.f; bmean[q] = 0.f; bistd[q] = 0.f; }
+    if (a.bw_x && n < a.Cd) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[n + q]; bistd[q] = a.bw_stats[a.Cd + n + q]; }
+    }
     if (n < a.Cd) {
+        // (issuing the residual / upstream-x loads of 4 rows ahead of the stores was measured 2-3 % slower end to end)
 #pragma unroll 4
         for (int row = r0; row < BM; row += RPP) {
             const int m = m0 + row;
@@ -323,7 +336,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
             const int64_t o = (dst_row(a, m) * a.dpitch + goff + n) * 2;
             if (a.res) {
                 const u32x4 rr = *reinterpret_cast<const u32x4*>(a.res + o);
-                const unsigned rb = a.res_bits ? a.res_bits[o >> 4] : 0xffu;       // one byte per 16-byte vector
+                const unsigned rb = a.res_bits ? a.res_bits[o >> 4] : 0xffu;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float lo = bf16_bits_to_f32(v[q] & 0xffffu) + ((rb >> (2 * q)) & 1u ? bf16_bits_to_f32(rr[q] & 0xffffu) : 0.f);
@@ -332,7 +345,19 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
                 }
             }
             *reinterpret_cast<u32x4*>(a.dst + o) = v;
-            if (a.bn_partial) {
+            if (a.bw_x) {
+                const u32x4 xv = *reinterpret_cast<const u32x4*>(a.bw_x + o);
+                const unsigned mb = a.bw_bits ? a.bw_bits[o >> 4] : 0xffu;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float glo = (mb >> (2 * q)) & 1u ? bf16_bits_to_f32(v[q] & 0xffffu) : 0.f;
+                    const float ghi = (mb >> (2 * q + 1)) & 1u ? __uint_as_float(v[q] & 0xffff0000u) : 0.f;
+                    const float xlo = (bf16_bits_to_f32(xv[q] & 0xffffu) - bmean[2 * q]) * bistd[2 * q];
+                    const float xhi = (__uint_as_float(xv[q] & 0xffff0000u) - bmean[2 * q + 1]) * bistd[2 * q + 1];
+                    bs[2 * q] += glo; bq[2 * q] += glo * xlo;
+                    bs[2 * q + 1] += ghi; bq[2 * q + 1] += ghi * xhi;
+                }
+            } else if (a.bn_partial) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float lo = bf16_bits_to_f32(v[q] & 0xffffu), hi = __uint_as_float(v[q] & 0xffff0000u);
@@ -366,7 +391,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
             float s2 = 0.f, q2 = 0.f;
 #pragma unroll
             for (int w = 0; w < NWV; ++w) { s2 += scratch[(w * 2 + 0) * BN + tid]; q2 += scratch[(w * 2 + 1) * BN + tid]; }
-            float* p = a.bn_partial + (int64_t)mt * 2 * a.dpitch + goff + n0 + tid;
+            float* p = a.bn_partial + (int64_t)(a.bn_row0 + mt) * 2 * a.dpitch + goff + n0 + tid;
             p[0] = s2; p[a.dpitch] = q2;
         }
     }
@@ -834,6 +859,14 @@ inline bool use_bm256(const ConvArgs& a, bool utap, int esz) {
     return tiles >= 384 && a.ntaps * a.Cs >= 1024;
 }
 
+// partial-sum rows of this launch: [bn_row0, bn_row0 + mtiles) of the caller's buffer
+inline int claim_partial_rows(const ConvArgs& a) {
+    if (!a.bn_partial) return IIF_OK;
+    if ((long long)(a.bn_row0 + a.mtiles) * 2 * a.dpitch > a.bn_cap) return IIF_EINVAL;
+    if (a.rows_out) *a.rows_out = a.bn_row0 + a.mtiles;
+    return IIF_OK;
+}
+
 // halo kernel: bf16 3x3 / stride 1 / pad 1, dense, >= 128 output channels, window of a 256-pixel tile <= 512 halo rows
 inline bool use_halo(const ConvArgs& a, bool utap, int esz, bool outf32) {
     static const char* off = getenv("IIF_CONV_NO_HALO");
@@ -853,6 +886,7 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
     if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_halo(a, utap, (int)sizeof(T), OUTF32)) {
         a.mtiles = (a.M + 255) / 256;
         a.ntiles = (a.Cd + 127) / 128;
+        if (const int rc = claim_partial_rows(a)) return rc;
         const int64_t blocksh = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
         if (blocksh > 0x7fffffff) return IIF_EUNSUPPORTED;
         hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)blocksh), dim3(512), 0, st, a, (unsigned)src_bytes,
@@ -863,6 +897,7 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
     if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_bm256(a, utap, (int)sizeof(T))) {
         a.mtiles = (a.M + 255) / 256;
         a.ntiles = (a.Cd + 127) / 128;
+        if (const int rc = claim_partial_rows(a)) return rc;
         const int64_t blocks256 = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
         if (blocks256 > 0x7fffffff) return IIF_EUNSUPPORTED;
         hipLaunchKernelGGL((conv_igemm_dma_utap256_kernel<T, OUTF32>), dim3((unsigned)blocks256, (unsigned)a.groups), dim3(512), 0,
@@ -879,6 +914,8 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
     static const bool force_v1 = getenv("IIF_CONV_REGSTAGE") != nullptr;
     // LDS-DMA addressing is a 32-bit byte offset with a hardware range check: both operands must be < 2 GiB
     const bool dma = !force_v1 && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL;
+    if (a.bn_partial && !dma) return IIF_EUNSUPPORTED;     // partial sums come out of the staged epilogue only
+    if (const int rc = claim_partial_rows(a)) return rc;
     if (a.groups > 1 && !dma) return IIF_EUNSUPPORTED;     // grouped convolutions exist on the pipelined kernels only
     if (a.scatter && !(dma && utap)) return IIF_EUNSUPPORTED;
     const dim3 grid((unsigned)blocks, (unsigned)a.groups), blk(256);
@@ -944,7 +981,10 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
                     c.tap_w[t] = (unsigned char)(r * a.S + s);
                 }
             }
-            if (c.ntaps == 0 && c.res == c.dst) continue;      // this class receives no contribution: dst += 0
+            // a class without taps receives no contribution (dst += 0): skipped, unless the backward sums of the
+            // upstream unit ride on this launch (every pixel of dst has to be visited once)
+            if (c.ntaps == 0 && c.res == c.dst && !c.bw_x) continue;
+            if (c.rows_out) c.bn_row0 = *c.rows_out;
             const int rc = launch_one<T, OUTF32>(c, true, src_bytes, wgt_bytes, st);
             if (rc != IIF_OK) return rc;
         }
@@ -956,7 +996,18 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
 namespace {
 int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                const unsigned char* res_bits, const float* bias, float* bn_partial, int64_t bn_partial_floats,
-               int32_t* n_partials, void* stream);
+               int32_t* n_partials, void* stream, const void* bw_x = nullptr, const unsigned char* bw_bits = nullptr,
+               const float* bw_stats = nullptr);
+}
+
+extern "C" int iif_conv_igemm_dgrad_bnbwd(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                                          const unsigned char* res_bits, const void* up_x, const unsigned char* up_bits,
+                                          const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,
+                                          void* stream) {
+    if (!d || !up_x || !up_stats || !partial || !n_partials || !d->transposed) return IIF_EINVAL;
+    if (res_bits && (!res || d->stride != 1)) return IIF_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(up_x) & 15)) return IIF_EUNSUPPORTED;
+    return conv_entry(d, src, wgt, dst, res, res_bits, nullptr, partial, partial_floats, n_partials, stream, up_x, up_bits, up_stats);
 }
 
 extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
@@ -982,7 +1033,7 @@ extern "C" int iif_conv_igemm(const iif_conv_desc* d, const void* src, const voi
 namespace {
 int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                const unsigned char* res_bits, const float* bias, float* bn_partial, int64_t bn_partial_floats,
-               int32_t* n_partials, void* stream) {
+               int32_t* n_partials, void* stream, const void* bw_x, const unsigned char* bw_bits, const float* bw_stats) {
     if (!d || !src || !wgt || !dst) return IIF_EINVAL;
     if (d->n <= 0 || d->hs <= 0 || d->ws <= 0 || d->cs <= 0 || d->hd <= 0 || d->wd <= 0 || d->cd <= 0 ||
         d->r <= 0 || d->s <= 0 || d->pad < 0)
@@ -1003,26 +1054,19 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
     a.res_bits = res_bits;
     a.bn_partial = nullptr;
     if (n_partials) *n_partials = 0;
+    int rows = 0;
     if (bn_partial) {
-        // fused statistics need the LDS-staged bf16 epilogue of the pipelined kernel
-        // one partial row per pixel tile; the tile height is the one launch_one will pick for this shape
-        ConvArgs p{};
-        p.M = (int)M; p.Cd = d->cd; p.Cs = d->cs; p.ntaps = d->r * d->s; p.groups = d->groups > 1 ? d->groups : 1;
-        const bool utap_p = getenv("IIF_CONV_GENERAL_ADDR") == nullptr && (d->cs % 32) == 0 && d->r * d->s <= 16;
-        p.R = d->r; p.S = d->s; p.pad = d->pad; p.Hs = d->hs; p.Ws = d->ws; p.Hd = d->hd; p.Wd = d->wd;
-        p.in_shift = d->stride - 1; p.bias = bias;
-        const bool big = use_bm256(p, utap_p && d->dtype == IIF_BF16, 2) ||
-                         use_halo(p, utap_p && d->dtype == IIF_BF16, 2, d->dst_dtype == IIF_F32);
-        const int64_t mt = big ? (M + 255) / 256 : (M + 127) / 128;
+        // fused statistics (forward) / backward sums of the upstream unit need the LDS-staged bf16 epilogue of the
+        // pipelined kernels; one partial row per pixel tile, counted where the tile height is chosen (launch_one)
         const int64_t esz0 = 2;
-        const int64_t groups = 1;
-        const bool ok = d->dtype == IIF_BF16 && d->dst_dtype == IIF_BF16 && (d->cd % 8) == 0 && !bias && !res &&
-                        getenv("IIF_CONV_REGSTAGE") == nullptr &&
-                        (int64_t)d->n * d->hs * d->ws * d->cs * (d->groups > 1 ? d->groups : 1) * esz0 < 0x7f000000LL &&
-                        bn_partial_floats >= mt * groups * 2 * d->cd * (d->groups > 1 ? d->groups : 1);
+        const bool ok = d->dtype == IIF_BF16 && d->dst_dtype == IIF_BF16 && (d->cd % 8) == 0 && !bias && (bw_x || !res) &&
+                        (!bw_x || d->groups <= 1) && getenv("IIF_CONV_REGSTAGE") == nullptr &&
+                        (int64_t)d->n * d->hs * d->ws * d->cs * (d->groups > 1 ? d->groups : 1) * esz0 < 0x7f000000LL;
         if (!ok) return IIF_EUNSUPPORTED;
         a.bn_partial = bn_partial;
-        if (n_partials) *n_partials = (int32_t)(mt * groups);
+        a.bn_cap = bn_partial_floats;
+        a.rows_out = &rows;
+        a.bw_x = (const unsigned char*)bw_x; a.bw_bits = bw_bits; a.bw_stats = bw_stats;
     }
     a.N = d->n; a.Hs = d->hs; a.Ws = d->ws; a.Cs = d->cs; a.Hd = d->hd; a.Wd = d->wd; a.Cd = d->cd;
     a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.transposed = d->transposed ? 1 : 0;
@@ -1034,11 +1078,15 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
     const int64_t esz = d->dtype == IIF_F32 ? 4 : 2;
     const int64_t src_bytes = (int64_t)d->n * d->hs * d->ws * a.spitch * esz;
     const int64_t wgt_bytes = (int64_t)d->cd * d->ldw * esz;          // one group's weight matrix
+    int rc;
     if (d->dtype == IIF_BF16) {
-        if (d->dst_dtype == IIF_F32) return launch_conv<unsigned short, true>(a, src_bytes, wgt_bytes, st);
-        return launch_conv<unsigned short, false>(a, src_bytes, wgt_bytes, st);
+        if (d->dst_dtype == IIF_F32) rc = launch_conv<unsigned short, true>(a, src_bytes, wgt_bytes, st);
+        else rc = launch_conv<unsigned short, false>(a, src_bytes, wgt_bytes, st);
+    } else {
+        rc = launch_conv<float, true>(a, src_bytes, wgt_bytes, st);
     }
-    return launch_conv<float, true>(a, src_bytes, wgt_bytes, st);
+    if (n_partials) *n_partials = rows;
+    return rc;
 }
 }  // namespace
 

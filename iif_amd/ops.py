@@ -330,3 +330,26 @@ def weight_transpose_batched(arena, table, n_desc, total_blocks, out):
     check(lib().iif_weight_transpose_batched(ptr(arena), ptr(table), n_desc, total_blocks, dtype_code(out), ptr(out),
                                              stream_ptr()), "iif_weight_transpose_batched")
     return out
+
+
+# ------------------------------------------------------------ BN backward sums fused into the producing dgrad
+def conv_dgrad_bnbwd(dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits, up_stats, partial, res=None, res_bits=None):
+    """conv_dgrad that also writes the upstream unit's BN-backward partial sums; returns the partial row count."""
+    require_gpu(dy, wt, res, up_x)
+    n, ho, wo, cout = dy.shape
+    cin, ldw = wt.shape
+    h, w_ = in_hw
+    d = _desc(n, ho, wo, cout, h, w_, cin, r, s, stride, pad, 1, ldw, dtype_code(dy), dtype_code(out), 1)
+    nt = ctypes.c_int32(0)
+    check(lib().iif_conv_igemm_dgrad_bnbwd(ctypes.byref(d), ptr(dy), ptr(wt), ptr(out), ptr(res), ptr(res_bits), ptr(up_x),
+                                           ptr(up_bits), ptr(up_stats), ptr(partial), partial.numel(), ctypes.byref(nt),
+                                           stream_ptr()), "iif_conv_igemm_dgrad_bnbwd")
+    return nt.value
+
+
+def bn_backward_partials(gy, relu_bits, x2d, stats, gamma, partial, n_partials, dgamma, dbeta, dx, ws):
+    m, c = x2d.shape
+    check(lib().iif_bn_backward_partials(ptr(gy), ptr(relu_bits), ptr(x2d), dtype_code(x2d), m, c, ptr(stats), ptr(gamma),
+                                         ptr(partial), n_partials, ptr(dgamma), ptr(dbeta), ptr(dx), ptr(ws), ws.numel(),
+                                         stream_ptr()), "iif_bn_backward_partials")
+    return dx

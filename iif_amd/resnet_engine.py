@@ -679,6 +679,11 @@ class _Plan(object):
         self.bn_partial = torch.empty(max(((u.n * u.ho * u.wo + 127) // 128) * 2 * u.conv.cout for u in self.units),
                                       dtype=torch.float32, device=dev)
         self.bn_scratch = torch.empty(128 * cmax, dtype=torch.float32, device=dev)
+        # BN-backward partial sums written by the data-gradient epilogue that produces a unit's output gradient
+        self.bw_partial = torch.empty(max(((u.n * u.ho * u.wo + 127) // 128 + 8) * 2 * u.conv.cout for u in self.units),
+                                      dtype=torch.float32, device=dev)
+        self.fuse_bwd = dt == torch.bfloat16 and not os.environ.get("IIF_NO_BWD_FUSE")
+        self._bw_ready = None
         wmax = max(max(u.conv.cout * (u.dwp.shape[1] if u.dwp is not None else u.conv.ldw) for u in self.units),
                    head.out_padded * head.in_features)
         self.wg_ws = torch.empty(min(16 * wmax * 4, 512 << 20), dtype=torch.uint8, device=dev)
@@ -937,7 +942,7 @@ class _Plan(object):
             torch.cuda.current_stream().wait_event(old)
 
     def _unit_backward(self, u, gy, mask, gmasked=None, dgrad_out=None, dgrad_res=None, need_dgrad=True, par=0,
-                       keep_gy=False, mask_bits=None, dgrad_res_bits=None):
+                       keep_gy=False, mask_bits=None, dgrad_res_bits=None, fuse_up=None):
         """gy: grad w.r.t. the unit's activated output (NHWC).  Computes in place
         dx (into gy's storage unless gmasked is requested), the weight / BN
         gradients, and (optionally) the data gradient w.r.t. the unit's source."""
@@ -945,7 +950,13 @@ class _Plan(object):
         m = u.n * u.ho * u.wo
         g2 = gy.view(m, cv.cout)
         bits = mask_bits if mask_bits is not None else (None if mask is None else u.bits)
-        if gmasked is not None or keep_gy:
+        ready, self._bw_ready = self._bw_ready, None
+        if ready is not None and ready[0] is u and gmasked is None:
+            # the data gradient that wrote gy already reduced (sum g, sum g*xhat) per tile: no reduction pass
+            dx = self._gbuf(("dx", m, cv.cout, par), (m, cv.cout)) if keep_gy else g2
+            ops.bn_backward_partials(g2, bits, u.x.view(m, cv.cout), u.stats, bn.weight, self.bw_partial, ready[1],
+                                     bn._dgamma, bn._dbeta, dx, self.bn_ws)
+        elif gmasked is not None or keep_gy:
             # dx goes to its own buffer; gy is either overwritten by its masked copy (gmasked) or left as is
             dx = self._gbuf(("dx", m, cv.cout, par), (m, cv.cout))
             ops.bn_backward(g2, None if mask is None else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats, bn.weight,
@@ -976,6 +987,12 @@ class _Plan(object):
                                                      workspace=self.wg_ws))
         if not need_dgrad:
             return None
+        if fuse_up is not None and self.fuse_bwd and u.groups == 1 and dgrad_out is not None:
+            up, up_bits = fuse_up
+            nt = ops.conv_dgrad_bnbwd(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), dgrad_out, up.x, up_bits, up.stats,
+                                      self.bw_partial, res=dgrad_res, res_bits=dgrad_res_bits)
+            self._bw_ready = (up, nt)
+            return dgrad_out
         return ops.conv_dgrad(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), out=dgrad_out, res=dgrad_res,
                               groups=u.groups, res_bits=dgrad_res_bits)
 
@@ -984,6 +1001,7 @@ class _Plan(object):
         head = net._head
         n = self.n
         offs = net.block_offsets() if reducer is not None else None
+        self._bw_ready = None
         if reducer is not None:
             reducer.begin()
             reducer.extra_streams = [self.wg_stream] if self.wg_stream is not None else []
@@ -1045,32 +1063,45 @@ class _Plan(object):
             # The block's ReLU gates g on both paths.  With a convolutional shortcut or a plain identity no masked
             # copy of g is written: the shortcut's BN backward and the identity add read g through the ReLU bits.
             lazy_mask = "se" not in b and "sc" not in b
+            # the dgrad that writes a unit's output gradient also reduces that unit's BN-backward sums: inside the
+            # block each unit feeds the previous one; the dgrad that completes the block-input gradient feeds the
+            # previous block's last unit (gated by that block's ReLU bits)
+            prev = self.blocks[bi - 1] if bi > 0 else None
+            up_in = None
+            if prev is not None and "se" not in prev and "sc" not in prev:
+                up_in = (prev["units"][-1], prev["units"][-1].bits)
+            inner = lambda ui: (units[ui - 1], units[ui - 1].bits)       # noqa: E731
             if "se" in b:
                 G = self._se_backward(b, last, g, par)
-                d = self._unit_backward(last, G, None, par=par, dgrad_out=self._gbuf(dkey, last.src.shape))
+                d = self._unit_backward(last, G, None, par=par, dgrad_out=self._gbuf(dkey, last.src.shape),
+                                        fuse_up=inner(len(units) - 1))
             elif lazy_mask:
-                d = self._unit_backward(last, g, last.y, keep_gy=True, par=par, dgrad_out=self._gbuf(dkey, last.src.shape))
+                d = self._unit_backward(last, g, last.y, keep_gy=True, par=par, dgrad_out=self._gbuf(dkey, last.src.shape),
+                                        fuse_up=inner(len(units) - 1))
             else:
-                d = self._unit_backward(last, g, last.y, gmasked=g, par=par, dgrad_out=self._gbuf(dkey, last.src.shape))
+                d = self._unit_backward(last, g, last.y, gmasked=g, par=par, dgrad_out=self._gbuf(dkey, last.src.shape),
+                                        fuse_up=inner(len(units) - 1))
             for ui in range(len(units) - 2, 0, -1):
                 uu = units[ui]
-                d = self._unit_backward(uu, d, uu.y, par=par,
+                d = self._unit_backward(uu, d, uu.y, par=par, fuse_up=inner(ui),
                                         dgrad_out=self._gbuf(("d", tuple(uu.src.shape), ui, par), uu.src.shape))
             first = units[0]
             if "ds" in b:
                 self._unit_backward(first, d, first.y, dgrad_out=gin, par=par)
                 du = b["ds"]
                 if lazy_mask:       # in place: g is not needed after the shortcut's BN backward
-                    self._unit_backward(du, g, last.y, mask_bits=last.bits, dgrad_out=gin, dgrad_res=gin, par=par)
+                    self._unit_backward(du, g, last.y, mask_bits=last.bits, dgrad_out=gin, dgrad_res=gin, par=par,
+                                        fuse_up=up_in)
                 else:
-                    self._unit_backward(du, g, None, dgrad_out=gin, dgrad_res=gin, par=par)
+                    self._unit_backward(du, g, None, dgrad_out=gin, dgrad_res=gin, par=par, fuse_up=up_in)
             elif "sc" in b:
                 self._unit_backward(first, d, first.y, dgrad_out=gin, par=par)
                 ops.shortcut_a_backward_acc(g, gin)
             elif lazy_mask:
-                self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=g, dgrad_res_bits=last.bits, par=par)
+                self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=g, dgrad_res_bits=last.bits, par=par,
+                                    fuse_up=up_in)
             else:
-                self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=g, par=par)
+                self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=g, par=par, fuse_up=up_in)
             g = gin
             if reducer is not None:
                 reducer.gradients_ready_from(offs["blocks"][bi])

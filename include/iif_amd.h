@@ -381,6 +381,22 @@ int iif_fasa_generate(const float* rnd, const float* prob, const float* feature_
                       const float* feature_var, const float* normal, int c, int d, int* slot_class, int* count,
                       float* out, int64_t* out_labels, void* stream);
 
+/* Data gradient that also emits the batch-norm BACKWARD partial sums of the upstream unit.  dst (= dL/dy of the
+ * unit that produced this convolution's input) is gated by that unit's ReLU bits `up_bits` (nullable: no ReLU) and
+ * reduced per pixel tile against its pre-normalisation output `up_x` (same shape as dst) and statistics
+ * `up_stats` (mean at [c], invstd at [cd + c]): partial[t] = (sum g, sum g * xhat) per channel, *n_partials rows.
+ * iif_bn_backward_partials then finishes that unit's BN backward without the reduction pass over dst and up_x
+ * (what F.batch_norm's backward re-reads in resnet_pytorch.py:152-167).  bf16, cd % 8 == 0, dense;
+ * res / res_bits as in iif_conv_igemm / iif_conv_igemm_masked_res; stride-2 launches visit every pixel once. */
+int iif_conv_igemm_dgrad_bnbwd(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                               const unsigned char* res_bits, const void* up_x, const unsigned char* up_bits,
+                               const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,
+                               void* stream);
+int iif_bn_backward_partials(const void* gy, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,
+                             const float* stats, const float* gamma, const float* partial, int n_partials,
+                             float* dgamma, float* dbeta, void* dx, void* workspace, int64_t workspace_bytes,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

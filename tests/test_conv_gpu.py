@@ -315,3 +315,48 @@ print(json.dumps({"nt": nt, "m": m, "e_fwd": e_fwd, "e_sum": e_sum, "e_sq": e_sq
     assert tres["e_fwd"] <= 2.0 ** -7
     # same K order per output element is not guaranteed (chunk-major vs tap-major): compare digests loosely
     assert abs(hres["digest"] - tres["digest"]) <= 1e-3 * max(1.0, abs(tres["digest"]))
+
+
+@pytest.mark.parametrize("case", [(4, 64, 14, 14, 128, 1, 1, True, True), (4, 128, 14, 14, 64, 3, 1, False, False),
+                                  (3, 64, 16, 16, 128, 3, 2, False, True), (3, 256, 16, 16, 512, 1, 2, True, False),
+                                  (8, 256, 28, 28, 128, 3, 1, False, True), (2, 64, 15, 13, 128, 3, 2, False, True)])
+def test_dgrad_emits_upstream_bn_backward_sums(case):
+    """iif_conv_igemm_dgrad_bnbwd: the data gradient (stride 1 and the 4 parity classes of stride 2, with and without
+    residual) plus per-tile (sum g, sum g*xhat) of the upstream unit, g = stored gradient gated by its ReLU bits."""
+    from iif_amd import ops
+    n, cin, h, w, cout, k, stride, use_res, use_bits = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(cin + cout + k)
+    pad = k // 2
+    ho, wo = ops.conv_out_hw(h, w, k, k, stride, pad)
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dt)
+    dy = torch.randn(n, cout, ho, wo, generator=g).to(dt)
+    res = torch.randn(n, cin, h, w, generator=g).to(dt)
+    upx = torch.randn(n, cin, h, w, generator=g).to(dt)
+    pre = torch.randn(n, cin, h, w, generator=g).to(dt)
+    stats = torch.zeros(4, cin)
+    stats[0] = torch.randn(cin, generator=g) * 0.1
+    stats[1] = torch.rand(cin, generator=g) + 0.5
+    st_id = torch.zeros(4, cin)
+    st_id[2] = 1.0
+    y = torch.empty(n * h * w, cin, dtype=dt, device=DEV)
+    bits = torch.empty(n * h * w * cin // 8, dtype=torch.uint8, device=DEV)
+    ops.bn_apply(nhwc(pre.float()).to(dt).reshape(-1, cin).to(DEV), st_id.to(DEV), y, relu=True, relu_bits=bits)
+    wtt = krsc(wt.float().permute(1, 0, 2, 3).contiguous(), 8).to(dt)
+    out = torch.empty(n, h, w, cin, dtype=dt, device=DEV)
+    partial = torch.full(((n * h * w + 127) // 128 + 8, 2, cin), float("nan"), device=DEV)
+    nt = ops.conv_dgrad_bnbwd(nhwc(dy.float()).to(dt).to(DEV), wtt.to(DEV), k, k, stride, pad, (h, w), out,
+                              nhwc(upx.float()).to(dt).to(DEV), bits if use_bits else None, stats.to(DEV), partial.view(-1),
+                              res=nhwc(res.float()).to(dt).to(DEV) if use_res else None)
+    ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt.float(), dy.float(), stride, pad)
+    if use_res:
+        ref = ref + res.float()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    gq = got * ((pre.float() > 0) if use_bits else 1.0)             # the sums are over the STORED values
+    xhat = (upx.float() - stats[0][None, :, None, None]) * stats[1][None, :, None, None]
+    s1, s2 = gq.sum(dim=(0, 2, 3)), (gq * xhat).sum(dim=(0, 2, 3))
+    ps = partial[:nt].sum(0).cpu()
+    assert not torch.isnan(ps).any()
+    assert (ps[0] - s1).abs().max().item() <= 2e-6 * max(1.0, s1.abs().max().item())
+    assert (ps[1] - s2).abs().max().item() <= 2e-6 * max(1.0, s2.abs().max().item())
