@@ -59,10 +59,13 @@ class ConvTimer(object):
     def __init__(self):
         self.records = []      # (kind, flops, ideal_bytes, start_event, stop_event)
         self.shapes = []
+        self.active = True     # brackets are recorded on a sample of the timed steps only (they cost ~3 % when on)
+        self.sampled_steps = 0
 
     def wrap(self, ops):
         timer = self
-        orig = {k: getattr(ops, k) for k in ("conv_forward", "conv_dgrad", "conv_wgrad", "conv_forward_bnstats")}
+        orig = {k: getattr(ops, k) for k in ("conv_forward", "conv_dgrad", "conv_wgrad", "conv_forward_bnstats",
+                                             "conv_dgrad_bnbwd")}
 
         def alg_k(r, s, stride, pad, cin):
             # algorithmic K of one output: the space-to-depth stem (4x4/1 pad 2 on 32 channels) is charged
@@ -103,8 +106,16 @@ class ConvTimer(object):
             fl = flops_fwd(x, w, r, s, stride, pad, out_hw=(out.shape[1], out.shape[2]), **kw)
             return timer._timed("fwd", fl, nbytes(x, w, out), orig["conv_forward_bnstats"], x, w, r, s, stride, pad, out, partial, **kw)
 
+        def conv_dgrad_bnbwd(dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits, up_stats, partial, **kw):
+            n, ho, wo, cout = dy.shape
+            fl = 2.0 * n * ho * wo * cout * r * s * wt.shape[0]
+            by = nbytes(dy, wt, kw.get("res"), up_x) + out.numel() * out.element_size()
+            return timer._timed("dgrad", fl, by, orig["conv_dgrad_bnbwd"], dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits,
+                                up_stats, partial, **kw)
+
         ops.conv_forward, ops.conv_dgrad, ops.conv_wgrad = conv_forward, conv_dgrad, conv_wgrad
         ops.conv_forward_bnstats = conv_forward_bnstats
+        ops.conv_dgrad_bnbwd = conv_dgrad_bnbwd
         self._orig, self._ops = orig, ops
 
     def unwrap(self):
@@ -112,6 +123,8 @@ class ConvTimer(object):
             setattr(self._ops, k, v)
 
     def _timed(self, kind, flops, ideal_bytes, fn, *a, **kw):
+        if not self.active:
+            return fn(*a, **kw)
         self.shapes.append("%s %s x %s k%s s%s" % (kind, tuple(a[0].shape), tuple(a[1].shape), a[2], a[4]))
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
@@ -204,6 +217,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--per-shape", action="store_true", help="print the per-shape conv table to stderr")
+    ap.add_argument("--event-every", type=int, default=4, help="bracket the conv launches of every n-th timed step")
     ap.add_argument("--trace-loss", action="store_true", help="record the loss of every step (one tiny copy per step)")
     ap.add_argument("--force-reducer", action="store_true", help="drive the bucketed all-reduce path even with one rank")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -279,6 +293,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(args.steps):
+        if timer is not None:
+            timer.active = it % max(args.event_every, 1) == 0
+            timer.sampled_steps += 1 if timer.active else 0
         loss = step(args.warmup + it)
     torch.cuda.synchronize()
     if world > 1:
@@ -310,9 +327,10 @@ def main():
                                    "bs=%d/GPU, SGD momentum 0.9 wd 1e-4 with warm-up, random init" % (args.model, args.image, args.image, C, counts[0], B),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4)},
         }
+        nsamp = max(timer.sampled_steps, 1) if timer is not None else 1
         if timer is not None and args.per_shape:
             for sh, (cnt, ms, fl) in sorted(timer.per_shape().items(), key=lambda kv: -kv[1][1]):
-                print("[conv] %-70s n=%3d  %8.3f ms/step  %7.1f TFLOP/s" % (sh, cnt // args.steps, ms / args.steps, fl / (ms * 1e-3) / 1e12), file=sys.stderr)
+                print("[conv] %-70s n=%3d  %8.3f ms/step  %7.1f TFLOP/s" % (sh, cnt // nsamp, ms / nsamp, fl / (ms * 1e-3) / 1e12), file=sys.stderr)
         if timer is not None:
             tot_ms, tot_fl, by = timer.summary()
             nl = len(timer.records)
@@ -323,13 +341,14 @@ def main():
                 "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                 "traffic": profiled_traffic() if (args.model, B, C, args.image, args.dtype) == ("resnet50", 256, 1000, 224, "bf16") else None,
                 # shape-aware speed of light: per launch max(FLOPs / MFMA peak, ideal bytes / HBM peak)
-                "sol_ms_per_step": round(timer.sol_ms / max(args.steps, 1), 3),
+                "sol_ms_per_step": round(timer.sol_ms / nsamp, 3),
                 "frac_of_shape_sol": round(timer.sol_ms / tot_ms, 4) if tot_ms > 0 else None,
-                "launches_per_step": nl // max(args.steps, 1),
+                "bracketed_steps": timer.sampled_steps,
+                "launches_per_step": nl // nsamp,
                 "avg_launch_us": round(1000.0 * tot_ms / max(nl, 1), 2),
-                "algorithmic_gflop_per_step": round(tot_fl / max(args.steps, 1) / 1e9, 1),
-                "conv_ms_per_step": round(tot_ms / max(args.steps, 1), 3),
-                "by_kind_ms_per_step": {k: round(v[1] / max(args.steps, 1), 3) for k, v in by.items()},
+                "algorithmic_gflop_per_step": round(tot_fl / nsamp / 1e9, 1),
+                "conv_ms_per_step": round(tot_ms / nsamp, 3),
+                "by_kind_ms_per_step": {k: round(v[1] / nsamp, 3) for k, v in by.items()},
                 "by_kind_tflops": {k: round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0},
             }
         if world == 1 and not args.no_cpu_baseline:
