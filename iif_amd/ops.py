@@ -321,7 +321,7 @@ def wt_table(entries, device):
     blob, start = b"", 0
     for (so, do, cout, cin, rs, ldw, ldwt) in entries:
         blob += struct.pack("<qqiiiiii", so, do, cout, cin, rs, ldw, ldwt, start)
-        start += (cin * ldwt + 1023) // 1024
+        start += rs * ((cin + 31) // 32) * ((cout + 31) // 32)           # one block per 32x32 tile of one tap
     t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
     return t, start
 

@@ -330,7 +330,8 @@ int iif_rownorm_backward(const float* x, const float* row_scale, const float* no
 
 /* All dense convolutions' transposed copies ([cin][rs*cout], for the data gradient) in ONE launch.  `table` is a
  * DEVICE array of n_desc descriptors sorted by block_start; descriptor i owns the blocks
- * [block_start_i, block_start_{i+1}) and each block writes 1024 elements of its [cin, ldwt] output.
+ * [block_start_i, block_start_{i+1}): rs * ceil(cin/32) * ceil(cout/32) of them, one 32x32 tile of one tap each
+ * (tap-major, then cin tiles, then cout tiles).
  * src_off / dst_off are element offsets into the fp32 parameter arena / the output arena. */
 typedef struct iif_wt_desc {
     int64_t src_off, dst_off;

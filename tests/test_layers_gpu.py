@@ -284,3 +284,27 @@ def test_se_kernels_against_torch(dt, n, hw, c, res):
     ops.se_backward_form(gd, e.to(DEV), off.to(DEV), out)
     ref_o = gm.to(dt).float() * e[:, None, None, :] + off[:, None, None, :]
     assert (out.float().cpu() - ref_o).abs().max().item() <= tol_for(dt) * max(1.0, ref_o.abs().max().item())
+
+
+def test_weight_transpose_batched_matches_per_tensor():
+    """One-launch tiled transpose of several [cout][rs*cin] tensors out of a flat fp32 arena == iif_weight_transpose
+    of each (pad columns zero), for fp32 and bf16 outputs, ragged channel counts included."""
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(2)
+    shapes = [(64, 64, 9, 576), (1000, 2048, 1, 2048), (40, 24, 9, 224), (256, 64, 1, 64), (8, 8, 9, 80)]
+    arena = torch.randn(sum(co * ldw for co, _, _, ldw in shapes) + 64, generator=g).to(DEV)
+    for dt in (torch.float32, torch.bfloat16):
+        entries, off_in, off_out, views = [], 16, 0, []
+        for (co, ci, rs, ldw) in shapes:
+            ldwt = (rs * co + 15) // 16 * 16
+            entries.append((off_in, off_out, co, ci, rs, ldw, ldwt))
+            views.append((off_in, off_out, co, ci, rs, ldw, ldwt))
+            off_in += co * ldw
+            off_out += (ci * ldwt + 63) // 64 * 64
+        table, blocks = ops.wt_table(entries, DEV)
+        out = torch.full((off_out,), 7.0, dtype=dt, device=DEV)
+        ops.weight_transpose_batched(arena, table, len(entries), blocks, out)
+        for (oi, oo, co, ci, rs, ldw, ldwt) in views:
+            ref = torch.empty(ci, ldwt, dtype=dt, device=DEV)
+            ops.weight_transpose(arena[oi:oi + co * ldw].view(co, ldw), co, ci, rs, ref)
+            assert torch.equal(out[oo:oo + ci * ldwt].view(ci, ldwt), ref), (co, ci, rs)
