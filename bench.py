@@ -68,9 +68,9 @@ class ConvTimer(object):
                                              "conv_dgrad_bnbwd")}
 
         def alg_k(r, s, stride, pad, cin):
-            # algorithmic K of one output: the space-to-depth stem (4x4/1 pad 2 on 32 channels) is charged
+            # algorithmic K of one output: the space-to-depth stem (4x4/1 pad 2 on 16 padded channels) is charged
             # for the 7*7*3 MACs of the convolution it implements, not for its zero padding
-            return 147.0 if (r, s, stride, pad, cin) == (4, 4, 1, 2, 32) else float(r * s * cin)
+            return 147.0 if (r, s, stride, pad) == (4, 4, 1, 2) and cin in (16, 32) else float(r * s * cin)
 
         def flops_fwd(x, w, r, s, stride, pad, groups=1, out_hw=None, **kw):
             # algorithmic FLOPs: a chunked grouped conv is charged for its in-chunk MACs only

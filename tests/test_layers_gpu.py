@@ -210,13 +210,14 @@ def test_fused_sgd_matches_torch_optim():
         assert (pd.cpu() - ref_p[0]).abs().max().item() <= 1e-6
 
 
+@pytest.mark.parametrize("cpad", [16, 32])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_stem_space_to_depth_equals_7x7_stride2_conv(dt):
+def test_stem_space_to_depth_equals_7x7_stride2_conv(dt, cpad):
     """The s2d formulation of the ImageNet stem (4x4/1 conv on the 2x2 space-to-depth image) reproduces
     conv2d(7x7, stride 2, pad 3) forward and its weight gradient."""
     from iif_amd import ops
     g = torch.Generator().manual_seed(8)
-    n, hw, cout, cpad = 3, 32, 64, 32
+    n, hw, cout = 3, 32, 64
     img = torch.randn(n, 3, hw, hw, generator=g)
     w = (torch.randn(cout, 3, 7, 7, generator=g) * 0.1).to(dt).float()
     ref = F.conv2d(img.to(dt).float(), w, None, 2, 3)
