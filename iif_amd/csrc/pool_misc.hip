@@ -560,22 +560,50 @@ extern "C" int iif_group_unpack_grad(const float* packed, int channels, int cg, 
 // tap): input row i = 2I + di, original tap r = 2a + di - 1 for s2d tap a = 0..3 (r outside 0..6: zero
 // weight).  No patch matrix is materialised: the MFMA kernels gather the 16 taps themselves.
 namespace {
+// one thread per output pixel: 2 rows x float2 per image plane (consecutive threads read consecutive float2:
+// coalesced), then the pixel's cpad channels in one run of stores
 template <typename T>
 __global__ void __launch_bounds__(256) s2d_kernel(const float* img, int N, int C, int H, int W, int cpad, T* out) {
     const int H2 = H / 2, W2 = W / 2;
-    const int64_t total = (int64_t)N * H2 * W2 * cpad;
+    const int64_t total = (int64_t)N * H2 * W2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int q = (int)(i % cpad);
-        int64_t pix = i / cpad;
+        int64_t pix = i;
         const int x = (int)(pix % W2); pix /= W2;
         const int y = (int)(pix % H2);
         const int n = (int)(pix / H2);
-        float v = 0.f;
-        if (q < 4 * C) {
-            const int sub = q / C, c = q - sub * C;
-            v = img[(((int64_t)n * C + c) * H + 2 * y + (sub >> 1)) * W + 2 * x + (sub & 1)];
+        T* o = out + i * cpad;
+        float v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = 0.f;
+        if (C == 3) {                                                   // RGB: fully unrolled, values stay in registers
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* p = img + (((int64_t)n * 3 + c) * H + 2 * y) * W + 2 * x;
+                const float2 a = *reinterpret_cast<const float2*>(p), b2 = *reinterpret_cast<const float2*>(p + W);
+                v[c] = a.x; v[3 + c] = a.y; v[6 + c] = b2.x; v[9 + c] = b2.y;      // (di, dj) = (0,0) (0,1) (1,0) (1,1)
+            }
+            if constexpr (sizeof(T) == 2) {
+                for (int q0 = 0; q0 < cpad; q0 += 8) {
+                    u32x4 w;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w[k] = q0 < 16 ? pack_bf16x2(v[(q0 & 8) + 2 * k], v[(q0 & 8) + 2 * k + 1]) : 0u;
+                    *reinterpret_cast<u32x4*>(o + q0) = w;
+                }
+            } else {
+                for (int q0 = 0; q0 < cpad; q0 += 4)
+                    *reinterpret_cast<f32x4*>(o + q0) = q0 < 12 ? f32x4{v[q0 & 15], v[(q0 & 15) + 1], v[(q0 & 15) + 2], v[(q0 & 15) + 3]}
+                                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            continue;
         }
-        PT<T>::store1(out + i, v);
+        for (int c = 0; c < C; ++c) {
+            const float* p = img + (((int64_t)n * C + c) * H + 2 * y) * W + 2 * x;
+            PT<T>::store1(o + c, p[0]);
+            PT<T>::store1(o + C + c, p[1]);
+            PT<T>::store1(o + 2 * C + c, p[W]);
+            PT<T>::store1(o + 3 * C + c, p[W + 1]);
+        }
+        for (int q = 4 * C; q < cpad; ++q) PT<T>::store1(o + q, 0.f);
     }
 }
 // master [K][ldm] rows of (r, s, c) over R x R taps -> packed [K][A*A*cpad] rows of (a, b, q), A = (R+1)/2
@@ -612,8 +640,10 @@ __global__ void __launch_bounds__(256) stem_unpack_kernel(const float* p, int K,
 extern "C" int iif_space_to_depth_nchw(const float* img, int n, int c, int h, int w, int cpad, int out_dtype, void* out,
                                        void* stream) {
     if (!img || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || cpad < 4 * c) return IIF_EINVAL;
+    // vector stores: whole 16-byte groups per pixel, 8-byte aligned image rows
+    if (cpad % 8 || cpad > 32 || (reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(img) & 7)) return IIF_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
-    const int64_t tot = (int64_t)n * (h / 2) * (w / 2) * cpad;
+    const int64_t tot = (int64_t)n * (h / 2) * (w / 2);
     IIF_BY_DTYPE(out_dtype,
         hipLaunchKernelGGL(s2d_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, img, n, c, h, w, cpad, (float*)out),
         hipLaunchKernelGGL(s2d_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, img, n, c, h, w, cpad, (unsigned short*)out))
