@@ -100,9 +100,13 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* gy, const uns
                 const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + c;
                 float g[V];
                 PT<T>::load(gy + o, g);
+                // the V argmax codes of this vector in one load (o is a multiple of V)
+                unsigned long long codes;
+                if constexpr (V == 8) codes = *reinterpret_cast<const unsigned long long*>(idx + o);
+                else codes = *reinterpret_cast<const unsigned int*>(idx + o);
 #pragma unroll
                 for (int q = 0; q < V; ++q)
-                    if (idx[o + q] == code) acc[q] += g[q];
+                    if ((int)((codes >> (8 * q)) & 0xffu) == code) acc[q] += g[q];
             }
         PT<T>::store(dx + (((int64_t)n * H + h) * W + w) * C + c, acc);
     }
