@@ -13,6 +13,8 @@
 // Partials are reduced in a fixed order (no float atomics): deterministic.
 // Replaces torch's batch_norm / relu / add forward+backward under
 // classification/resnet_pytorch.py:152-167 and resnet_cifar.py:133-138.
+#include <stdlib.h>
+
 #include "common.h"
 #include "vec16.h"
 
@@ -261,6 +263,12 @@ __global__ void __launch_bounds__(256) bn_partial_reduce_kernel(const float* par
     }
 }
 
+// partial rows above which the sums are pre-reduced into 64 slices by a separate launch
+inline int two_stage_rows() {
+    static const int v = getenv("IIF_BN_TWO_STAGE_ROWS") ? atoi(getenv("IIF_BN_TWO_STAGE_ROWS")) : 512;
+    return v;
+}
+
 // channels per finalize block: few channels x many lanes when there are many partial rows
 inline int finalize_cb(int nblk) { return nblk > 2048 ? 4 : (nblk > 256 ? 8 : 32); }
 
@@ -323,7 +331,7 @@ int bn_backward_t(const T* gy, const T* ymask, const unsigned char* bits, const 
     if (ext_partial) {
         fin_src = ext_partial;
         g.nblk = n_ext;
-        if (n_ext > 512) {                       // many tile rows: 64 slices first (fixed order), as in the forward path
+        if (n_ext > two_stage_rows()) {          // many tile rows: 64 slices first (fixed order), as in the forward path
             const int slices = 64, rps = (n_ext + slices - 1) / slices;
             if ((int64_t)(slices * 2 * C + 3 * C) * 4 > ws_bytes) return IIF_EINVAL;
             hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 31) / 32, slices), blk, 0, st, ext_partial, n_ext, C, rps, ws);
@@ -388,7 +396,7 @@ int iif_bn_finalize_stats(const float* partial, int n_partials, int64_t m, int c
                           float* scratch, int64_t scratch_floats, void* stream) {
     if (!partial || !gamma || !beta || !stats || n_partials <= 0 || m <= 0 || c <= 0) return IIF_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (n_partials > 512 && scratch && scratch_floats >= (int64_t)64 * 2 * c) {
+    if (n_partials > two_stage_rows() && scratch && scratch_floats >= (int64_t)64 * 2 * c) {
         const int slices = 64, rps = (n_partials + slices - 1) / slices;
         hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((c + 31) / 32, slices), dim3(256), 0, st, partial, n_partials, c,
                            rps, scratch);
