@@ -681,6 +681,13 @@ class _Plan(object):
         self.bn_partial = torch.empty(max(((u.n * u.ho * u.wo + 127) // 128) * 2 * u.conv.cout for u in self.units),
                                       dtype=torch.float32, device=dev)
         self.bn_scratch = torch.empty(128 * cmax, dtype=torch.float32, device=dev)
+        # the convolutional shortcut of a stage's first block runs on the side stream next to the main branch
+        ds_units = [b["ds"] for b in self.blocks if "ds" in b]
+        self.fwd_side = bool(ds_units) and dt == torch.bfloat16 and not os.environ.get("IIF_NO_FWD_SIDE")
+        if self.fwd_side:
+            self.bn_partial_side = torch.empty(max(((u.n * u.ho * u.wo + 127) // 128) * 2 * u.conv.cout for u in ds_units),
+                                               dtype=torch.float32, device=dev)
+            self.bn_scratch_side = torch.empty(128 * max(u.conv.cout for u in ds_units), dtype=torch.float32, device=dev)
         # BN-backward partial sums written by the data-gradient epilogue that produces a unit's output gradient
         self.bw_partial = torch.empty(max(((u.n * u.ho * u.wo + 127) // 128 + 8) * 2 * u.conv.cout for u in self.units),
                                       dtype=torch.float32, device=dev)
@@ -783,16 +790,17 @@ class _Plan(object):
             ops.weight_transpose(self.head_wsrc, head.out_padded, head.in_features, 1, self.head_wt)
 
     # ---------------------------------------------------------------- forward
-    def _conv_bn(self, u, training):
+    def _conv_bn(self, u, training, side=False):
         cv = u.conv
         k, st, pd = u.geom
         m = u.n * u.ho * u.wo
         x2 = u.x.view(m, cv.cout)
         if training and self.dt == torch.bfloat16 and cv.cout % 8 == 0:
             # statistics come out of the convolution's epilogue: no extra pass over x
-            nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, self.bn_partial, groups=u.groups)
-            ops.bn_finalize_stats(self.bn_partial, nt, m, cv.cout, u.bn.weight, u.bn.bias, u.bn.running_mean,
-                                  u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM, scratch=self.bn_scratch)
+            partial, scratch = (self.bn_partial_side, self.bn_scratch_side) if side else (self.bn_partial, self.bn_scratch)
+            nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, partial, groups=u.groups)
+            ops.bn_finalize_stats(partial, nt, m, cv.cout, u.bn.weight, u.bn.bias, u.bn.running_mean,
+                                  u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM, scratch=scratch)
             return x2
         ops.conv_forward(u.src, u.w, k, k, st, pd, out=u.x, groups=u.groups, out_hw=(u.ho, u.wo))
         if training:
@@ -817,6 +825,16 @@ class _Plan(object):
             self._maxpool_fwd(u.y)
         for b in self.blocks:
             units = b["units"]
+            ds_done = None
+            if "ds" in b and "se" not in b and training and self.fwd_side and self.wg_stream is not None:
+                # shortcut convolution + its statistics: independent of the main branch until the block's last bn_apply
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(self.wg_stream):
+                    self.wg_stream.wait_event(ev)
+                    self._conv_bn(b["ds"], training, side=True)
+                    ds_done = torch.cuda.Event()
+                    ds_done.record()
             for uu in units[:-1]:
                 x2 = self._conv_bn(uu, training)
                 ops.bn_apply(x2, uu.stats, uu.y.view(x2.shape), relu=True, relu_bits=uu.bits)
@@ -827,7 +845,11 @@ class _Plan(object):
                 continue
             if "ds" in b:
                 du = b["ds"]
-                xd = self._conv_bn(du, training)
+                if ds_done is not None:
+                    torch.cuda.current_stream().wait_event(ds_done)
+                    xd = du.x.view(x2.shape)
+                else:
+                    xd = self._conv_bn(du, training)
                 ops.bn_apply(x2, last.stats, last.y.view(x2.shape), relu=True, residual=xd, residual_stats=du.stats,
                              relu_bits=last.bits)
             elif "sc" in b:
