@@ -703,6 +703,11 @@ class _Plan(object):
             pr = os.environ.get("IIF_WGRAD_STREAM_PRIORITY")
             self.wg_stream = torch.cuda.Stream(device=dev) if pr is None else torch.cuda.Stream(device=dev, priority=int(pr))
         self._wg_events = {}
+        # backward of the convolutional shortcut (BN backward + dgrad + wgrad of 4 blocks) on a third stream
+        self.ds_stream = None
+        if self.wg_stream is not None and ds_units and dt == torch.bfloat16 and not os.environ.get("IIF_NO_BWD_SIDE"):
+            self.ds_stream = torch.cuda.Stream(device=dev)
+            self.bn_ws_ds = ops.bn_workspace(max(u.n * u.ho * u.wo for u in ds_units), max(u.conv.cout for u in ds_units), dev)
 
     def _finish_weight_plan(self):
         """One arena for every dense transposed weight copy ([cin][k*k*cout], the data-gradient operand) and
@@ -966,7 +971,7 @@ class _Plan(object):
             torch.cuda.current_stream().wait_event(old)
 
     def _unit_backward(self, u, gy, mask, gmasked=None, dgrad_out=None, dgrad_res=None, need_dgrad=True, par=0,
-                       keep_gy=False, mask_bits=None, dgrad_res_bits=None, fuse_up=None):
+                       keep_gy=False, mask_bits=None, dgrad_res_bits=None, fuse_up=None, ws=None, dxkey="dx"):
         """gy: grad w.r.t. the unit's activated output (NHWC).  Computes in place
         dx (into gy's storage unless gmasked is requested), the weight / BN
         gradients, and (optionally) the data gradient w.r.t. the unit's source."""
@@ -974,22 +979,25 @@ class _Plan(object):
         m = u.n * u.ho * u.wo
         g2 = gy.view(m, cv.cout)
         bits = mask_bits if mask_bits is not None else (None if mask is None else u.bits)
-        ready, self._bw_ready = self._bw_ready, None
+        ws = self.bn_ws if ws is None else ws
+        ready = None
+        if ws is self.bn_ws:                     # (the shortcut branch on its own stream never consumes fused sums)
+            ready, self._bw_ready = self._bw_ready, None
         if ready is not None and ready[0] is u and gmasked is None:
             # the data gradient that wrote gy already reduced (sum g, sum g*xhat) per tile: no reduction pass
-            dx = self._gbuf(("dx", m, cv.cout, par), (m, cv.cout)) if keep_gy else g2
+            dx = self._gbuf((dxkey, m, cv.cout, par), (m, cv.cout)) if keep_gy else g2
             ops.bn_backward_partials(g2, bits, u.x.view(m, cv.cout), u.stats, bn.weight, self.bw_partial, ready[1],
-                                     bn._dgamma, bn._dbeta, dx, self.bn_ws)
+                                     bn._dgamma, bn._dbeta, dx, ws)
         elif gmasked is not None or keep_gy:
             # dx goes to its own buffer; gy is either overwritten by its masked copy (gmasked) or left as is
-            dx = self._gbuf(("dx", m, cv.cout, par), (m, cv.cout))
+            dx = self._gbuf((dxkey, m, cv.cout, par), (m, cv.cout))
             ops.bn_backward(g2, None if mask is None else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats, bn.weight,
-                            bn._dgamma, bn._dbeta, dx, self.bn_ws,
+                            bn._dgamma, bn._dbeta, dx, ws,
                             gmasked=None if gmasked is None else gmasked.view(m, cv.cout), relu_bits=bits)
         else:
             dx = g2
             ops.bn_backward(g2, None if mask is None else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats, bn.weight,
-                            bn._dgamma, bn._dbeta, dx, self.bn_ws, relu_bits=bits)
+                            bn._dgamma, bn._dbeta, dx, ws, relu_bits=bits)
         dx4 = dx.view(u.n, u.ho, u.wo, cv.cout)
         if u.s2d:
             def stem():
@@ -1095,6 +1103,18 @@ class _Plan(object):
             if prev is not None and "se" not in prev and "sc" not in prev:
                 up_in = (prev["units"][-1], prev["units"][-1].bits)
             inner = lambda ui: (units[ui - 1], units[ui - 1].bits)       # noqa: E731
+            ds_done = gin_ds = None
+            if "ds" in b and lazy_mask and self.ds_stream is not None:
+                du = b["ds"]
+                gin_ds = self._gbuf(("ginds", tuple(inp.shape), par), inp.shape)
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(self.ds_stream):
+                    self.ds_stream.wait_event(ev)
+                    self._unit_backward(du, g, last.y, mask_bits=last.bits, keep_gy=True, dgrad_out=gin_ds, par=par,
+                                        ws=self.bn_ws_ds, dxkey="dxds")
+                    ds_done = torch.cuda.Event()
+                    ds_done.record()
             if "se" in b:
                 G = self._se_backward(b, last, g, par)
                 d = self._unit_backward(last, G, None, par=par, dgrad_out=self._gbuf(dkey, last.src.shape),
@@ -1110,7 +1130,11 @@ class _Plan(object):
                 d = self._unit_backward(uu, d, uu.y, par=par, fuse_up=inner(ui),
                                         dgrad_out=self._gbuf(("d", tuple(uu.src.shape), ui, par), uu.src.shape))
             first = units[0]
-            if "ds" in b:
+            if "ds" in b and ds_done is not None:
+                # the shortcut's gradient was computed next to the main branch: the first unit's dgrad adds it
+                torch.cuda.current_stream().wait_event(ds_done)
+                self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=gin_ds, par=par, fuse_up=up_in)
+            elif "ds" in b:
                 self._unit_backward(first, d, first.y, dgrad_out=gin, par=par)
                 du = b["ds"]
                 if lazy_mask:       # in place: g is not needed after the shortcut's BN backward
