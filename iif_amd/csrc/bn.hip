@@ -131,17 +131,36 @@ template <typename T, bool RELU, int RES>   // RES 0: none, 1: + r, 2: + a2*r + 
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* x, const float* stats, const T* r, const float* stats2,
                                                        T* y, int64_t total_vec, int cv, int C, unsigned char* relu_bits) {
     constexpr int V = VT<T>::V;
+    // cv divides the grid stride (host guarantees it when cv divides 256): a thread keeps ONE channel vector for all
+    // its rows, so the 2 x V (4 x V with a normalised residual) coefficients are loaded once, not per 16-byte vector
+    const bool fixed = (256 % cv) == 0;
+    float ca[V], cb[V], ra[V], rb[V];
+    int c0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cv) * V;
+    if (fixed) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            ca[k] = stats[2 * C + c0 + k]; cb[k] = stats[3 * C + c0 + k];
+            if (RES == 2) { ra[k] = stats2[2 * C + c0 + k]; rb[k] = stats2[3 * C + c0 + k]; }
+        }
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)(i % cv) * V;
+        if (!fixed) {
+            c0 = (int)(i % cv) * V;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                ca[k] = stats[2 * C + c0 + k]; cb[k] = stats[3 * C + c0 + k];
+                if (RES == 2) { ra[k] = stats2[2 * C + c0 + k]; rb[k] = stats2[3 * C + c0 + k]; }
+            }
+        }
         float v[V], w[V];
         VT<T>::load(x + i * V, v);
         if (RES) VT<T>::load(r + i * V, w);
         unsigned bits = 0;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            float t = fmaf(stats[2 * C + c0 + k], v[k], stats[3 * C + c0 + k]);   // one rounding, as vec fmadd
+            float t = fmaf(ca[k], v[k], cb[k]);   // one rounding, as vec fmadd
             if (RES == 1) t += w[k];
-            if (RES == 2) t += fmaf(stats2[2 * C + c0 + k], w[k], stats2[3 * C + c0 + k]);
+            if (RES == 2) t += fmaf(ra[k], w[k], rb[k]);
             bits |= (t > 0.f ? 1u : 0u) << k;
             v[k] = RELU ? fmaxf(t, 0.f) : t;
         }
@@ -221,8 +240,19 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T*
                                                            const float* stats, const float* coef, T* dx, T* gm,
                                                            int64_t total_vec, int cv, int C) {
     constexpr int V = VT<T>::V;
+    const bool fixed = (256 % cv) == 0;          // see bn_apply_kernel: one channel vector per thread
+    float k1[V], k2[V], k3[V], mu[V];
+    int c0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cv) * V;
+    if (fixed) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) { k1[k] = coef[c0 + k]; k2[k] = coef[C + c0 + k]; k3[k] = coef[2 * C + c0 + k]; mu[k] = stats[c0 + k]; }
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)(i % cv) * V;
+        if (!fixed) {
+            c0 = (int)(i % cv) * V;
+#pragma unroll
+            for (int k = 0; k < V; ++k) { k1[k] = coef[c0 + k]; k2[k] = coef[C + c0 + k]; k3[k] = coef[2 * C + c0 + k]; mu[k] = stats[c0 + k]; }
+        }
         float dy[V], xv[V], yv[V];
         VT<T>::load(g_ + i * V, dy);
         VT<T>::load(x + i * V, xv);
@@ -234,7 +264,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T*
             const bool on = MASK == 0 ? true : (MASK == 1 ? yv[k] > 0.f : ((mb >> k) & 1u) != 0);
             const float d = on ? dy[k] : 0.f;
             dy[k] = d;
-            xv[k] = coef[c0 + k] * (d - coef[C + c0 + k] - (xv[k] - stats[c0 + k]) * coef[2 * C + c0 + k]);
+            xv[k] = k1[k] * (d - k2[k] - (xv[k] - mu[k]) * k3[k]);
         }
         VT<T>::store(dx + i * V, xv);
         if (GMOUT) VT<T>::store(gm + i * V, dy);
@@ -284,8 +314,9 @@ inline int launch_bn_finalize(const float* partial, int nblk, int C, double coun
 }
 
 inline int stream_blocks(int64_t total_vec) {
+    static const int cap = getenv("IIF_BN_BLOCKS") ? atoi(getenv("IIF_BN_BLOCKS")) : 4096;
     const int64_t b = (total_vec + 255) / 256;
-    return (int)(b < 4096 ? b : 4096);
+    return (int)(b < cap ? b : cap);
 }
 
 template <typename T>
