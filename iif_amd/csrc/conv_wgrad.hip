@@ -221,7 +221,7 @@ template <typename T, int COLS> struct Swz {
     // physical 16-byte chunk p of LDS row `row` holds logical chunk:
     static __device__ __forceinline__ int logical(int p, int row) {
         if constexpr (sizeof(T) == 2) {
-            const int key = RB == 256 ? (row & 7) : ((row >> 1) & 3);
+            const int key = RB >= 256 ? (row & 7) : ((row >> 1) & 3);
             return (((p >> 1) ^ key) << 1) | (p & 1);
         } else {
             return (((p >> 2) ^ (row & 1)) << 2) | (p & 3);
@@ -230,7 +230,7 @@ template <typename T, int COLS> struct Swz {
     // byte address (within the tile) of logical byte column `colb` of row `row`
     static __device__ __forceinline__ int addr(int row, int colb) {
         if constexpr (sizeof(T) == 2) {
-            const int key = RB == 256 ? (row & 7) : ((row >> 1) & 3);
+            const int key = RB >= 256 ? (row & 7) : ((row >> 1) & 3);
             return row * RB + ((((colb >> 5) ^ key)) << 5) + (colb & 31);
         } else {
             return row * RB + ((((colb >> 6) ^ (row & 1))) << 6) + (colb & 63);
@@ -238,24 +238,28 @@ template <typename T, int COLS> struct Swz {
     }
 };
 
-template <typename T, int BC>
-__global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(WgArgs a, unsigned x_bytes, unsigned dy_bytes) {
+// WK wave groups along the output channels (2 x WK waves): 128 kernel columns x BC channels, BC = 64 | 128 with
+// WK = 2, or 256 with WK = 4 (8 waves: 12 instead of 16 KB through the vector L1 per MFLOP, see conv_igemm.hip)
+template <typename T, int BC, int WK = 2>
+__global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsigned x_bytes, unsigned dy_bytes) {
     constexpr int PE = WT<T>::PE, ROWS = WT<T>::ROWS;
     constexpr int BNW = 128;
+    constexpr int NWV = 2 * WK;          // waves
+    constexpr int CW = BC / WK;          // output channels per wave
     using SX = Swz<T, BNW>;
     using SY = Swz<T, BC>;
     constexpr int XB = ROWS * SX::RB, YB = ROWS * SY::RB, STAGE = XB + YB;
-    constexpr int LPRX = SX::RB / 16, RPIX = 64 / LPRX, NIX = ROWS / RPIX / 4;   // X: lanes/row, rows/instr, instr/wave
-    constexpr int LPRY = SY::RB / 16, RPIY = 64 / LPRY, NIY = ROWS / RPIY / 4;
+    constexpr int LPRX = SX::RB / 16, RPIX = 64 / LPRX, NIX = ROWS / RPIX / NWV;   // X: lanes/row, rows/instr, instr/wave
+    constexpr int LPRY = SY::RB / 16, RPIY = 64 / LPRY, NIY = ROWS / RPIY / NWV;
     constexpr int LPS = NIX + NIY;
-    constexpr int KJ = BC / 32;
+    constexpr int KJ = CW / 16;
     constexpr unsigned OOB = 0xfffffff0u;
-    static_assert(NIX == 2 && (NIY == 1 || NIY == 2), "tile geometry");
+    static_assert((NIX == 1 || NIX == 2) && (NIY == 1 || NIY == 2), "tile geometry");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = wave / WK, wk = wave % WK;
     // XCD-aware map (workgroups are dealt round-robin over the 8 XCDs): all tiles of one pixel split run
     // back-to-back on ONE XCD, so the split's pixel rows of x / dy are fetched from HBM once and re-read
     // from that XCD's L2 by the other tiles.
@@ -360,7 +364,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(WgArgs a, unsigned 
             }
 #pragma unroll
             for (int kj = 0; kj < KJ; ++kj) {
-                const int colb = (wk * (BC / 2) + kj * 16 + 4 * p) * 2;
+                const int colb = (wk * CW + kj * 16 + 4 * p) * 2;
                 const s16x4 lo = tr_read(Y + SY::addr(4 * g + q, colb)), hi = tr_read(Y + SY::addr(16 + 4 * g + q, colb));
                 yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             }
@@ -379,7 +383,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(WgArgs a, unsigned 
                     xf[ni] = *reinterpret_cast<const float*>(X + SX::addr(4 * qq + g, (wn * 64 + ni * 16 + li) * 4));
 #pragma unroll
                 for (int kj = 0; kj < KJ; ++kj)
-                    yf[kj] = *reinterpret_cast<const float*>(Y + SY::addr(4 * qq + g, (wk * (BC / 2) + kj * 16 + li) * 4));
+                    yf[kj] = *reinterpret_cast<const float*>(Y + SY::addr(4 * qq + g, (wk * CW + kj * 16 + li) * 4));
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -393,7 +397,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(WgArgs a, unsigned 
     float* out = a.out + (int64_t)split * a.slab + (int64_t)grp * a.Cd * a.ldw;
 #pragma unroll
     for (int kj = 0; kj < KJ; ++kj) {
-        const int k = k0 + wk * (BC / 2) + kj * 16 + li;
+        const int k = k0 + wk * CW + kj * 16 + li;
         if (k >= a.Cd) continue;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -427,7 +431,12 @@ template <typename T>
 int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_req, int64_t x_bytes, int64_t dy_bytes,
                  hipStream_t st) {
     constexpr int ROWS = WT<T>::ROWS;
-    const int bc = a.Cd <= 64 ? 64 : 128;
+    // 256-channel tiles (8 waves): bf16, dense, >= 256 output channels, the LDS-DMA path
+    static const char* wide_env = getenv("IIF_WGRAD_BC");
+    const bool dma_ok = getenv("IIF_CONV_REGSTAGE") == nullptr && x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL;
+    bool wide = sizeof(T) == 2 && dma_ok && a.groups == 1 && a.Cd >= 256 && a.Cd % 256 == 0;
+    if (wide && wide_env) wide = atoi(wide_env) == 256;
+    const int bc = wide ? 256 : (a.Cd <= 64 ? 64 : 128);
     a.ktiles = (a.Cd + bc - 1) / bc;
     a.ntiles = (a.K + 127) / 128;
     a.nsteps = (a.M + ROWS - 1) / ROWS;
@@ -436,7 +445,7 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     if (splits <= 0) {
         // one full co-resident round: 256 CUs x (3 | 4) workgroups (LDS 48 | 36 KB each), so every
         // workgroup gets the same number of steps and there is no tail round
-        const int slots = 256 * (bc == 64 ? 4 : 3);
+        const int slots = 256 * (bc == 64 ? 4 : (bc == 256 ? 2 : 3));
         splits = slots / (tiles * a.groups);
         if (splits < 1) splits = 1;
         const int max_by_work = a.nsteps / 8 > 0 ? a.nsteps / 8 : 1;
@@ -463,7 +472,9 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     if (dma) {
         const unsigned xb = (unsigned)x_bytes, yb = (unsigned)dy_bytes;
         if (bc == 64) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64>), grid1d, dim3(256), 0, st, a, xb, yb);
-        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128>), grid1d, dim3(256), 0, st, a, xb, yb);
+        else if (bc == 256) {
+            if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 256, 4>), grid1d, dim3(512), 0, st, a, xb, yb);
+        } else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128>), grid1d, dim3(256), 0, st, a, xb, yb);
     } else {
         if (bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, st, a);
