@@ -69,7 +69,12 @@ __device__ __forceinline__ int64_t dst_row(const ConvArgs& a, int m) {
     return ((int64_t)n * a.Hfull + ((y << a.ds_shift) + a.doy)) * a.Wfull + ((x << a.ds_shift) + a.dox);
 }
 
-__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+// XOR key of the 16-byte chunk index of a 64-byte LDS row.  ds_read_b128 serves lanes in the groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with lane = chunk*16 + row that is 16 distinct rows per group, rows
+// 0-3 and 12-15 reading chunk a and rows 4-11 chunk a^1.  Flipping chunk bit 1 on every other group of 4 rows keeps
+// the 16 slots of a group distinct for ANY first row (the halo kernel reads fragments at tap-displaced rows;
+// the former key {0,2,3,1}[(row>>2)&3] was conflict-free for 16-aligned fragments only: 45 % conflict cycles there).
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 2; }
 
 #ifdef IIF_CONV_STAMPS
 // Diagnostic build only (make stamps): per-wave cycle sums of the K-step phases of the LDS-DMA kernel, written to

@@ -216,6 +216,16 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgArgs a) {
 // Out-of-image taps / pixels >= M / channels >= Cd are addressed out of range (hardware zeros).
 typedef __attribute__((address_space(3))) void lds_void_w;
 
+#ifdef IIF_CONV_STAMPS
+__device__ unsigned long long* g_wstamps = nullptr;
+#define IIF_WSTAMP(var)                                                                            \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#endif
+
 template <typename T, int COLS> struct Swz {
     static constexpr int RB = COLS * (int)sizeof(T);      // row bytes
     // physical 16-byte chunk p of LDS row `row` holds logical chunk:
@@ -346,11 +356,24 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
     if (nst > 0) issue(0, step0);
     if (nst > 1) { advance(); issue(1, step0 + 1); }
     int stage = 0;
+#ifdef IIF_CONV_STAMPS
+    unsigned long long w_wait = 0, w_issue = 0, w_rest = 0, w0, w1, w2, w3, wb;
+    IIF_WSTAMP(wb); w3 = wb;
+#endif
     for (int t = 0; t < nst; ++t) {
+#ifdef IIF_CONV_STAMPS
+        IIF_WSTAMP(w0); w_rest += w0 - w3;
+#endif
         if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef IIF_CONV_STAMPS
+        IIF_WSTAMP(w1);
+#endif
         if (t + 2 < nst) { advance(); issue(stage == 0 ? 2 : stage - 1, step0 + t + 2); }
+#ifdef IIF_CONV_STAMPS
+        IIF_WSTAMP(w2); w_wait += w1 - w0; w_issue += w2 - w1; w3 = w2;
+#endif
         const unsigned char* X = smem + stage * STAGE;
         const unsigned char* Y = X + XB;
         if constexpr (sizeof(T) == 2) {
@@ -394,6 +417,13 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
         stage = stage == 2 ? 0 : stage + 1;
     }
 
+#ifdef IIF_CONV_STAMPS
+    IIF_WSTAMP(w0); w_rest += w0 - w3;
+    if (g_wstamps && blockIdx.x < 512 && lane == 0 && wave < 4) {
+        unsigned long long* o = g_wstamps + ((int64_t)blockIdx.x * 4 + wave) * 8;
+        o[0] = w_wait; o[1] = 0; o[2] = w_issue; o[3] = w_rest; o[4] = 0; o[5] = w0 - wb; o[6] = (unsigned long long)nst; o[7] = wb;
+    }
+#endif
     float* out = a.out + (int64_t)split * a.slab + (int64_t)grp * a.Cd * a.ldw;
 #pragma unroll
     for (int kj = 0; kj < KJ; ++kj) {
@@ -539,3 +569,9 @@ extern "C" int iif_conv_wgrad(const iif_conv_desc* d, const void* x, const void*
         return launch_wgrad<unsigned short>(a, dw, (float*)workspace, workspace_bytes, splits, x_bytes, dy_bytes, st);
     return launch_wgrad<float>(a, dw, (float*)workspace, workspace_bytes, splits, x_bytes, dy_bytes, st);
 }
+
+#ifdef IIF_CONV_STAMPS
+extern "C" int iif_debug_set_wgrad_stamps(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), &buf, sizeof(buf)) == hipSuccess ? IIF_OK : IIF_ELAUNCH;
+}
+#endif

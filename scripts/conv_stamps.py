@@ -25,11 +25,17 @@ lib = _lib.lib()
 lib.iif_debug_set_stamps.argtypes = [ctypes.c_void_p]
 lib.iif_debug_set_stamps.restype = ctypes.c_int
 assert lib.iif_debug_set_stamps(stamps.data_ptr()) == 0
+lib.iif_debug_set_wgrad_stamps.argtypes = [ctypes.c_void_p]
+lib.iif_debug_set_wgrad_stamps.restype = ctypes.c_int
+assert lib.iif_debug_set_wgrad_stamps(stamps.data_ptr()) == 0
+ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 
 
 def run():
     if kind == 'fwd':
         ops.conv_forward(x, w, k, k, stride, pad)
+    elif kind == 'wgrad':          # columns: wait = vmcnt+barrier, DMA issue = address arithmetic + DMA, MFMA issue = fragments + MFMA
+        ops.conv_wgrad(x, dy, k, k, stride, pad, workspace=ws)
     else:
         ops.conv_dgrad(dy, wt, k, k, stride, pad, (h, h))
 
