@@ -696,12 +696,18 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_utap_kernel(ConvArgs a, un
 // v = n*(H+2) + y + 1 so that every image carries its own zero rows above and below: halo pixels that fall on them,
 // or left/right of the image, are out-of-range lanes of the LDS-DMA (zeros, no traffic).
 // bf16, 8 waves x (64 pixels x 64 channels), forward and stride-1 data gradient (tap list), staged epilogue.
-__global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
-    constexpr int BM = 256, BN = 128, CI = BN / 32;
-    constexpr int HR = 512, ABUF = HR * 64;          // halo rows per buffer, 64 B (32 channels) each
-    constexpr int BST = BN * 64, NBS = 6;            // weight stage and ring depth
+// BM = 256: 8 waves, one block per CU (112 KB).  BM = 128: 4 waves, 70 KB, TWO blocks per CU: two independent barrier
+// domains, so one block's fetch phase overlaps the other's MFMAs (weight ring 4 deep, 2 weight pieces per wave and step).
+template <int BM>
+__device__ __forceinline__ void conv3x3_halo_body(const ConvArgs& a, unsigned src_bytes, unsigned wgt_bytes) {
+    constexpr int BN = 128, CI = BN / 32, NW = BM / 32;
+    constexpr int HR = BM == 256 ? 512 : 304, ABUF = HR * 64;   // halo rows per buffer, 64 B (32 channels) each
+    constexpr int BST = BN * 64, NBS = BM == 256 ? 6 : 4;       // weight stage and ring depth
+    constexpr int NAP = BM == 256 ? 4 : 5;           // halo pieces per wave and chunk
+    constexpr int NBP = 8 / NW;                      // weight pieces per wave and step
+    constexpr int AHEAD = NBS - 1;                   // weight stages in flight
     constexpr unsigned OOB = 0x80000000u;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * ABUF + NBS * BST];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * ABUF + NBS * BST + 1024];   // + dump piece
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -725,21 +731,22 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a, unsigned 
     const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wgt), 0, wgt_bytes, 0x00020000);
 
     // ---- DMA roles of this lane.  Halo piece p (16 halo rows) is issued by wave p % 8 as its (p / 8)-th piece.
-    unsigned avoff[4];
+    unsigned avoff[NAP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int hr = 16 * (wave + 8 * i) + (lane >> 2);
+    for (int i = 0; i < NAP; ++i) {
+        const int hr = 16 * (wave + NW * i) + (lane >> 2);
         const int chunk = (lane & 3) ^ swz(hr);
         const int vr = vbase + hr / W2, xx = hr % W2 - 1;
         const int nn = vr / H2, yy = vr % H2 - 1;
-        const bool ok = hr < Hn && nn < a.N && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const bool ok = hr < Hn && hr < HR && nn < a.N && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
         avoff[i] = ok ? ((unsigned)((nn * H + yy) * W + xx) * (unsigned)a.spitch + (unsigned)(chunk * 8)) * 2u : OOB;
     }
-    unsigned bvoff;
-    {
-        const int row = 16 * wave + (lane >> 2);
+    unsigned bvoff[NBP];
+#pragma unroll
+    for (int q = 0; q < NBP; ++q) {
+        const int row = 16 * (wave * NBP + q) + (lane >> 2);
         const int chunk = (lane & 3) ^ swz(row);
-        bvoff = n0 + row < a.Cd ? ((unsigned)(n0 + row) * (unsigned)a.ldw + (unsigned)(chunk * 8)) * 2u : OOB;
+        bvoff[q] = n0 + row < a.Cd ? ((unsigned)(n0 + row) * (unsigned)a.ldw + (unsigned)(chunk * 8)) * 2u : OOB;
     }
     // ---- fragment addresses
     const int fr = lane & 15, fc = lane >> 4;
@@ -767,22 +774,26 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a, unsigned 
     const int G = nchunks * 9;
     unsigned char* const Bring = smem + 2 * ABUF;
     auto issue_a = [&](int c, int i) {                         // piece i of this wave for chunk c (c >= nchunks: no-op zeros)
-        unsigned char* dst = smem + (c & 1) * ABUF + (wave + 8 * i) * 1024;
-        const unsigned off = c < nchunks ? avoff[i] : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)dst, 16, off, (unsigned)(c * 64), 0, 0);
+        const int p = wave + NW * i;
+        unsigned char* dst = smem + (c & 1) * ABUF + (p < HR / 16 ? p : 0) * 1024;
+        const unsigned off = (c < nchunks && p < HR / 16) ? avoff[i] : OOB;     // surplus slots: zeros over piece 0's OOB lanes?
+        if (p < HR / 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)dst, 16, off, (unsigned)(c * 64), 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(smem + 2 * ABUF + NBS * BST), 16, OOB, 0, 0, 0);
     };
     auto issue_b = [&](int g, int slot) {                       // weights of global step g = (chunk, tap)
         const int c = g / 9, t = g - c * 9;
-        unsigned char* dst = Bring + slot * BST + wave * 1024;
-        const unsigned off = g < G ? bvoff : OOB;
         const unsigned so = g < G ? (unsigned)(a.tap_w[t] * a.Cs + c * 32) * 2u : 0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)dst, 16, off, so, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NBP; ++q) {
+            unsigned char* dst = Bring + slot * BST + (wave * NBP + q) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)dst, 16, g < G ? bvoff[q] : OOB, so, 0, 0);
+        }
     };
     // prologue: halo of chunk 0, then the first five weight stages (program order fixes the counted waits below)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_a(0, i);
+    for (int i = 0; i < NAP; ++i) issue_a(0, i);
 #pragma unroll
-    for (int g = 0; g < 5; ++g) issue_b(g, g);
+    for (int g = 0; g < AHEAD; ++g) issue_b(g, g);
 
     // (Software-pipelining the fragment reads into a second register set was measured 5 % slower: 214 VGPRs.)
     int toff[9];
@@ -792,14 +803,16 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a, unsigned 
     // fetch(T, g, c): arrival sync of step g = (chunk c, tap T), refill DMAs, fragment reads of step g
     auto fetch = [&](auto tc, int g, int c, u32x4 (&wf)[CI], u32x4 (&xf)[4]) {
         constexpr int T = decltype(tc)::value;
-        // loads issued after this step's weights: 4 later weight stages + the halo pieces of the last 5 steps
-        constexpr int NPEND[9] = {4, 5, 6, 7, 8, 8, 7, 6, 5};
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPEND[T]) : "memory");
+        // loads issued after this step's weights: the later weight stages in flight (NBP each) + the halo pieces
+        // issued in the last AHEAD steps (one per step at taps < NAP)
+        constexpr int NP256[9] = {4, 5, 6, 7, 8, 8, 7, 6, 5};
+        constexpr int NP128[9] = {4, 5, 6, 7, 7, 7, 6, 5, 4};
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM == 256 ? NP256[T] : NP128[T]) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the slot about to be refilled
         __builtin_amdgcn_s_barrier();
         const int refill = slot == 0 ? NBS - 1 : slot - 1;      // the slot read in the previous step
-        issue_b(g + 5, refill);
-        if constexpr (T < 4) issue_a(c + 1, T);
+        issue_b(g + AHEAD, refill);
+        if constexpr (T < NAP) issue_a(c + 1, T);
         const unsigned char* Ab = smem + (c & 1) * ABUF;
         const unsigned char* Bb = Bring + slot * BST;
 #pragma unroll
@@ -847,6 +860,14 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a, unsigned 
     conv_epilogue_staged<BN, BM>(a, acc, smem, m0, n0, mt, wm, wn, fr, fc, 0);
 }
 
+// plain kernel names around the body template (see the note on conv_igemm_dma_kernel: host stubs)
+__global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+    conv3x3_halo_body<256>(a, src_bytes, wgt_bytes);
+}
+__global__ void __launch_bounds__(256) conv3x3_halo128_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+    conv3x3_halo_body<128>(a, src_bytes, wgt_bytes);
+}
+
 template <typename T, bool OUTF32>
 __global__ void __launch_bounds__(512) conv_igemm_dma_utap256_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     conv_igemm_dma_body<T, 128, OUTF32, true, 8>(a, src_bytes, wgt_bytes);
@@ -881,6 +902,8 @@ inline bool use_halo(const ConvArgs& a, bool utap, int esz, bool outf32) {
     const int HW = a.Hd * a.Wd;
     const int span = (256 + a.Wd - 1) / a.Wd + 1 + 2 * (256 / HW + 1);       // virtual rows a tile can touch
     if ((span + 2) * (a.Wd + 2) > 512) return false;
+    const int span1 = (128 + a.Wd - 1) / a.Wd + 1 + 2 * (128 / HW + 1);      // the same for a 128-pixel tile
+    if ((span1 + 2) * (a.Wd + 2) > 304) return false;
     static const char* force = getenv("IIF_CONV_HALO_FORCE");                 // tests: small grids too
     return force || (int64_t)((a.M + 255) / 256) * ((a.Cd + 127) / 128) >= 192;
 }
@@ -889,13 +912,18 @@ template <typename T, bool OUTF32>
 int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
     static const bool force_v1_ = getenv("IIF_CONV_REGSTAGE") != nullptr;
     if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_halo(a, utap, (int)sizeof(T), OUTF32)) {
-        a.mtiles = (a.M + 255) / 256;
+        // measured (scripts/halo_ab.sh): two 128-row blocks per CU win at 28x28 (+8 %), one 256-row block elsewhere
+        static const char* hbm = getenv("IIF_CONV_HALO_BM");
+        const int bm = hbm ? atoi(hbm) : (a.Wd >= 28 ? 128 : 256);
+        a.mtiles = (a.M + bm - 1) / bm;
         a.ntiles = (a.Cd + 127) / 128;
         if (const int rc = claim_partial_rows(a)) return rc;
         const int64_t blocksh = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
         if (blocksh > 0x7fffffff) return IIF_EUNSUPPORTED;
-        hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)blocksh), dim3(512), 0, st, a, (unsigned)src_bytes,
-                           (unsigned)wgt_bytes);
+        if (bm == 128) hipLaunchKernelGGL(conv3x3_halo128_kernel, dim3((unsigned)blocksh), dim3(256), 0, st, a, (unsigned)src_bytes,
+                                          (unsigned)wgt_bytes);
+        else hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)blocksh), dim3(512), 0, st, a, (unsigned)src_bytes,
+                                (unsigned)wgt_bytes);
         IIF_LAUNCH_CHECK();
         return IIF_OK;
     }

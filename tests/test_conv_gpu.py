@@ -307,7 +307,7 @@ print(json.dumps({"nt": nt, "m": m, "e_fwd": e_fwd, "e_sum": e_sum, "e_sq": e_sq
     n, cin, h, w, cout = case
     span = (256 + w - 1) // w + 1 + 2 * (256 // (h * w) + 1)
     if cin % 32 == 0 and cout >= 128 and cout % 8 == 0 and (span + 2) * (w + 2) <= 512:
-        assert hres["nt"] == (hres["m"] + 255) // 256               # the halo kernel ran (256-pixel tiles)
+        assert hres["nt"] in ((hres["m"] + 255) // 256, (hres["m"] + 127) // 128)   # halo kernel: 256- or 128-pixel tiles
     else:
         assert hres["nt"] == tres["nt"]                             # window too large / shape not covered: tap kernel
     assert hres["e_fwd"] <= 2.0 ** -7 and hres["e_dx"] <= 2.0 ** -7
