@@ -248,8 +248,12 @@ def main():
     counts = lt_counts(C, 1280 if C == 1000 else 4980)   # ImageNet-LT / Places-LT shaped profiles
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    net = getattr(resnet_pytorch, args.model)(num_classes=C, use_norm="None", pretrained="None", device=dev,
-                                              compute_dtype=cdt)
+    if hasattr(resnet_pytorch, args.model):
+        net = getattr(resnet_pytorch, args.model)(num_classes=C, use_norm="None", pretrained="None", device=dev,
+                                                  compute_dtype=cdt)
+    else:                                       # CIFAR-style nets (BASELINE config 0: resnet32, 32x32, C=100)
+        from iif_amd import resnet_cifar
+        net = getattr(resnet_cifar, args.model)(num_classes=C, use_norm="None", device=dev, compute_dtype=cdt)
     net.train()
     broadcast_parameters(net)
     crit = IIFLoss(_Counts(counts), variant="raw", reduction="mean", device=dev)
