@@ -170,7 +170,9 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* x, const float* 
 }
 
 // ----------------------------------------------------------------- backward
-template <typename T, int MASK>     // 0: no ReLU, 1: mask from the activated tensor, 2: mask from the bit bytes
+// MASK 0: no ReLU, 1: mask from the activated tensor, 2: mask from the bit bytes, 3: recomputed as a*x + b > 0 (the
+// same fmaf as bn_apply: identical decisions) for units whose activation is never stored (stem fused with the max pool)
+template <typename T, int MASK>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* g_, const T* ymask, const unsigned char* bits,
                                                             const T* x, const float* stats, Geo g, float* partial) {
     constexpr int V = VT<T>::V;
@@ -178,14 +180,18 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* g_, const T
     const int tid = threadIdx.x;
     const int cvl = tid % g.cvb, rl = tid / g.cvb;
     const int cvec = blockIdx.y * g.cvb + cvl;
-    float s1[V], s2[V], mean[V], istd[V];
+    float s1[V], s2[V], mean[V], istd[V], aa[V], bb[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) { s1[i] = 0.f; s2[i] = 0.f; mean[i] = 0.f; istd[i] = 0.f; }
+    for (int i = 0; i < V; ++i) { s1[i] = 0.f; s2[i] = 0.f; mean[i] = 0.f; istd[i] = 0.f; aa[i] = 0.f; bb[i] = 0.f; }
     const int r0 = blockIdx.x * g.rows_per_block;
     int r1 = r0 + g.rows_per_block; if (r1 > g.M) r1 = g.M;
     if (rl < g.rpb && cvec < g.cv) {
 #pragma unroll
         for (int i = 0; i < V; ++i) { mean[i] = stats[cvec * V + i]; istd[i] = stats[g.C + cvec * V + i]; }
+        if (MASK == 3) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) { aa[i] = stats[2 * g.C + cvec * V + i]; bb[i] = stats[3 * g.C + cvec * V + i]; }
+        }
         for (int r = r0 + rl; r < r1; r += g.rpb) {
             const int64_t o = (int64_t)r * g.C + cvec * V;
             float dy[V], xv[V], yv[V];
@@ -196,7 +202,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* g_, const T
             if (MASK == 2) mb = bits[(int64_t)r * g.cv + cvec];
 #pragma unroll
             for (int i = 0; i < V; ++i) {
-                const bool on = MASK == 0 ? true : (MASK == 1 ? yv[i] > 0.f : ((mb >> i) & 1u) != 0);
+                const bool on = MASK == 0 ? true : (MASK == 1 ? yv[i] > 0.f : (MASK == 2 ? ((mb >> i) & 1u) != 0
+                                                                                                : fmaf(aa[i], xv[i], bb[i]) > 0.f));
                 const float d = on ? dy[i] : 0.f;
                 s1[i] += d;
                 s2[i] += d * ((xv[i] - mean[i]) * istd[i]);
@@ -241,17 +248,23 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T*
                                                            int64_t total_vec, int cv, int C) {
     constexpr int V = VT<T>::V;
     const bool fixed = (256 % cv) == 0;          // see bn_apply_kernel: one channel vector per thread
-    float k1[V], k2[V], k3[V], mu[V];
+    float k1[V], k2[V], k3[V], mu[V], aa[V], bb[V];
     int c0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cv) * V;
     if (fixed) {
 #pragma unroll
-        for (int k = 0; k < V; ++k) { k1[k] = coef[c0 + k]; k2[k] = coef[C + c0 + k]; k3[k] = coef[2 * C + c0 + k]; mu[k] = stats[c0 + k]; }
+        for (int k = 0; k < V; ++k) {
+            k1[k] = coef[c0 + k]; k2[k] = coef[C + c0 + k]; k3[k] = coef[2 * C + c0 + k]; mu[k] = stats[c0 + k];
+            if (MASK == 3) { aa[k] = stats[2 * C + c0 + k]; bb[k] = stats[3 * C + c0 + k]; }
+        }
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
         if (!fixed) {
             c0 = (int)(i % cv) * V;
 #pragma unroll
-            for (int k = 0; k < V; ++k) { k1[k] = coef[c0 + k]; k2[k] = coef[C + c0 + k]; k3[k] = coef[2 * C + c0 + k]; mu[k] = stats[c0 + k]; }
+            for (int k = 0; k < V; ++k) {
+                k1[k] = coef[c0 + k]; k2[k] = coef[C + c0 + k]; k3[k] = coef[2 * C + c0 + k]; mu[k] = stats[c0 + k];
+                if (MASK == 3) { aa[k] = stats[2 * C + c0 + k]; bb[k] = stats[3 * C + c0 + k]; }
+            }
         }
         float dy[V], xv[V], yv[V];
         VT<T>::load(g_ + i * V, dy);
@@ -261,7 +274,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T*
         if (MASK == 2) mb = bits[i];
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const bool on = MASK == 0 ? true : (MASK == 1 ? yv[k] > 0.f : ((mb >> k) & 1u) != 0);
+            const bool on = MASK == 0 ? true : (MASK == 1 ? yv[k] > 0.f : (MASK == 2 ? ((mb >> k) & 1u) != 0
+                                                                                            : fmaf(aa[k], xv[k], bb[k]) > 0.f));
             const float d = on ? dy[k] : 0.f;
             dy[k] = d;
             xv[k] = k1[k] * (d - k2[k] - (xv[k] - mu[k]) * k3[k]);
@@ -351,7 +365,7 @@ int bn_apply_t(const T* x, const float* stats, const T* r, const float* stats2, 
 template <typename T>
 int bn_backward_t(const T* gy, const T* ymask, const unsigned char* bits, const T* x, const float* stats, const float* gamma,
                   int64_t M, int C, float* dgamma, float* dbeta, T* dx, T* gm, float* ws, int64_t ws_bytes, hipStream_t st,
-                  const float* ext_partial = nullptr, int n_ext = 0) {
+                  const float* ext_partial = nullptr, int n_ext = 0, bool recompute = false) {
     constexpr int V = VT<T>::V;
     Geo g = make_geo(M, C, V, 512);
     const int64_t need = ((int64_t)g.nblk * 2 * C + 3 * C) * 4;
@@ -371,7 +385,8 @@ int bn_backward_t(const T* gy, const T* ymask, const unsigned char* bits, const 
             coef = ws + (int64_t)slices * 2 * C;
         }
     } else {
-        if (bits) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
+        if (recompute) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 3>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
+        else if (bits) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
         else if (ymask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
         IIF_LAUNCH_CHECK();
@@ -388,7 +403,8 @@ int bn_backward_t(const T* gy, const T* ymask, const unsigned char* bits, const 
     const int64_t tv = M * cv;
     const dim3 agrid(stream_blocks(tv));
 #define IIF_BAPPLY(MK, GO) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MK, GO>), agrid, blk, 0, st, gy, ymask, bits, x, stats, coef, dx, gm, tv, cv, C)
-    if (bits) { if (gm) IIF_BAPPLY(2, true); else IIF_BAPPLY(2, false); }
+    if (recompute) { if (gm) IIF_BAPPLY(3, true); else IIF_BAPPLY(3, false); }
+    else if (bits) { if (gm) IIF_BAPPLY(2, true); else IIF_BAPPLY(2, false); }
     else if (ymask) { if (gm) IIF_BAPPLY(1, true); else IIF_BAPPLY(1, false); }
     else { if (gm) IIF_BAPPLY(0, true); else IIF_BAPPLY(0, false); }
 #undef IIF_BAPPLY
@@ -474,6 +490,25 @@ int iif_bn_backward(const void* gy, const void* y_mask, const uint8_t* relu_bits
                                              (const unsigned short*)x, stats, gamma, m, c, dgamma, dbeta,
                                              (unsigned short*)dx, (unsigned short*)gmasked, (float*)workspace,
                                              workspace_bytes, as_stream(stream));
+    }
+    return IIF_EINVAL;
+}
+
+int iif_bn_backward_relu_recompute(const void* gy, const void* x, int dtype, int64_t m, int c, const float* stats,
+                                   const float* gamma, float* dgamma, float* dbeta, void* dx, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    if (!gy || !x || !stats || !gamma || !dgamma || !dbeta || !dx || !workspace || m <= 0 || c <= 0) return IIF_EINVAL;
+    if (m > 0x7fffff00LL || bad_align(gy) || bad_align(x) || bad_align(dx)) return IIF_EUNSUPPORTED;
+    if (dtype == IIF_F32) {
+        if (c % 4) return IIF_EUNSUPPORTED;
+        return bn_backward_t<float>((const float*)gy, nullptr, nullptr, (const float*)x, stats, gamma, m, c, dgamma, dbeta, (float*)dx,
+                                    nullptr, (float*)workspace, workspace_bytes, as_stream(stream), nullptr, 0, true);
+    }
+    if (dtype == IIF_BF16) {
+        if (c % 8) return IIF_EUNSUPPORTED;
+        return bn_backward_t<unsigned short>((const unsigned short*)gy, nullptr, nullptr, (const unsigned short*)x, stats, gamma, m, c,
+                                             dgamma, dbeta, (unsigned short*)dx, nullptr, (float*)workspace, workspace_bytes,
+                                             as_stream(stream), nullptr, 0, true);
     }
     return IIF_EINVAL;
 }

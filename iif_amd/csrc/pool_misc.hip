@@ -74,6 +74,49 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* x, int N, int
     }
 }
 
+// max pool over relu(a*x + b) of the RAW convolution output: the stem's activation (resnet_pytorch.py:284-287: bn1, relu,
+// maxpool) is never written.  Every candidate is rounded to the storage type before the comparison, so value and
+// argmax are exactly those of bn_apply followed by maxpool_fwd_kernel.
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const T* x, const float* stats, int N, int H, int W, int C, int k,
+                                                             int s, int p, int Ho, int Wo, T* y, unsigned char* idx) {
+    constexpr int V = PT<T>::V;
+    const int cv = C / V;
+    const int64_t total = (int64_t)N * Ho * Wo * cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cv) * V;
+        int64_t pix = i / cv;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        float best[V], ca[V], cb[V]; unsigned char bi[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) { best[q] = -INFINITY; bi[q] = 0; ca[q] = stats[2 * C + c + q]; cb[q] = stats[3 * C + c + q]; }
+        bool first = true;
+        for (int kh = 0; kh < k; ++kh) {
+            const int h = ho * s - p + kh;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int w = wo * s - p + kw;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float v[V];
+                PT<T>::load(x + (((int64_t)n * H + h) * W + w) * C + c, v);
+#pragma unroll
+                for (int q = 0; q < V; ++q) {
+                    float t = fmaxf(fmaf(ca[q], v[q], cb[q]), 0.f);
+                    if constexpr (sizeof(T) == 2) t = bf16_bits_to_f32(f32_to_bf16_bits(t));
+                    if (first || t > best[q] || t != t) { best[q] = t; bi[q] = (unsigned char)(kh * k + kw); }
+                }
+                first = false;
+            }
+        }
+        const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + c;
+        PT<T>::store(y + o, best);
+#pragma unroll
+        for (int q = 0; q < V; ++q) idx[o + q] = bi[q];
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* gy, const unsigned char* idx, int N, int H, int W,
                                                           int C, int k, int s, int p, int Ho, int Wo, T* dx) {
@@ -349,6 +392,22 @@ int iif_maxpool_forward(const void* x, int dtype, int n, int h, int w, int c, in
     IIF_BY_DTYPE(dtype,
         hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, (const float*)x, n, h, w, c, k, stride, pad, ho, wo, (float*)y, argmax),
         hipLaunchKernelGGL(maxpool_fwd_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, (const unsigned short*)x, n, h, w, c, k, stride, pad, ho, wo, (unsigned short*)y, argmax))
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+int iif_maxpool_bn_forward(const void* x, int dtype, const float* stats, int n, int h, int w, int c, int k, int stride, int pad,
+                           void* y, uint8_t* argmax, void* stream) {
+    if (!x || !stats || !y || !argmax || n <= 0 || h <= 0 || w <= 0 || c <= 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0)
+        return IIF_EINVAL;
+    const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+    if (ho <= 0 || wo <= 0) return IIF_EINVAL;
+    if (mis(x) || mis(y) || c % (dtype == IIF_F32 ? 4 : 8)) return IIF_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = (int64_t)n * ho * wo * (c / (dtype == IIF_F32 ? 4 : 8));
+    IIF_BY_DTYPE(dtype,
+        hipLaunchKernelGGL(maxpool_bn_fwd_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, (const float*)x, stats, n, h, w, c, k, stride, pad, ho, wo, (float*)y, argmax),
+        hipLaunchKernelGGL(maxpool_bn_fwd_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, (const unsigned short*)x, stats, n, h, w, c, k, stride, pad, ho, wo, (unsigned short*)y, argmax))
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }

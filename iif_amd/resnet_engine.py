@@ -605,6 +605,7 @@ class _Plan(object):
             u.w = torch.empty((c1.cout, 16 * S2D_CPAD), dtype=dt, device=dev)
             u.dwp = torch.empty((c1.cout, 16 * S2D_CPAD), dtype=torch.float32, device=dev)
         self.stem = u
+        self.pool_fused = net.style == "imagenet" and not os.environ.get("IIF_NO_POOL_FUSE")
         if net.style == "imagenet":
             self.pool_hw = ((ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1)
             self.pool_out = E(n, self.pool_hw[0], self.pool_hw[1], c1.cout)
@@ -825,9 +826,15 @@ class _Plan(object):
             ops.im2col_nchw(img, c1.k, c1.k, c1.stride, c1.pad, c1.ldw, self.dt, out=self.patches)
         u = self.stem
         x2 = self._conv_bn(u, training)
-        ops.bn_apply(x2, u.stats, u.y.view(x2.shape), relu=True, relu_bits=u.bits)
-        if net.style == "imagenet":
-            self._maxpool_fwd(u.y)
+        if self.pool_fused:
+            # bn1 + relu + maxpool in one pass over the raw stem output: the stem's activation is never stored
+            _lib.check(_lib.lib().iif_maxpool_bn_forward(_lib.ptr(u.x), _lib.dtype_code(u.x), _lib.ptr(u.stats), u.n, u.ho, u.wo,
+                                                         u.conv.cout, 3, 2, 1, _lib.ptr(self.pool_out), _lib.ptr(self.pool_idx),
+                                                         _lib.stream_ptr()), "iif_maxpool_bn_forward")
+        else:
+            ops.bn_apply(x2, u.stats, u.y.view(x2.shape), relu=True, relu_bits=u.bits)
+            if net.style == "imagenet":
+                self._maxpool_fwd(u.y)
         for b in self.blocks:
             units = b["units"]
             ds_done = None
@@ -970,6 +977,25 @@ class _Plan(object):
         if old is not None:
             torch.cuda.current_stream().wait_event(old)
 
+    def _stem_wgrad(self, u, dx4):
+        cv = u.conv
+        if u.s2d:
+            def stem():
+                ops.conv_wgrad(u.src, dx4, 4, 4, 1, 2, ldw=u.dwp.shape[1], out=u.dwp, workspace=self.wg_ws)
+                ops.stem_s2d_unpack_grad(u.dwp, cv.cout, cv.cin, cv.k, S2D_CPAD, cv._g2d)
+            self._wgrad_async(stem)
+        else:
+            self._wgrad_async(lambda: ops.conv_wgrad(u.src, dx4, 1, 1, 1, 0, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws))
+
+    def stem_activation(self):
+        """The stem's activated output (tests replay its ReLU decisions): stored, or — when bn1/relu/maxpool run
+        fused — recomputed by the same bn_apply arithmetic."""
+        u = self.stem
+        if self.pool_fused:
+            x2 = u.x.view(-1, u.conv.cout)
+            ops.bn_apply(x2, u.stats, u.y.view(x2.shape), relu=True)
+        return u.y
+
     def _unit_backward(self, u, gy, mask, gmasked=None, dgrad_out=None, dgrad_res=None, need_dgrad=True, par=0,
                        keep_gy=False, mask_bits=None, dgrad_res_bits=None, fuse_up=None, ws=None, dxkey="dx"):
         """gy: grad w.r.t. the unit's activated output (NHWC).  Computes in place
@@ -999,14 +1025,8 @@ class _Plan(object):
             ops.bn_backward(g2, None if mask is None else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats, bn.weight,
                             bn._dgamma, bn._dbeta, dx, ws, relu_bits=bits)
         dx4 = dx.view(u.n, u.ho, u.wo, cv.cout)
-        if u.s2d:
-            def stem():
-                ops.conv_wgrad(u.src, dx4, 4, 4, 1, 2, ldw=u.dwp.shape[1], out=u.dwp, workspace=self.wg_ws)
-                ops.stem_s2d_unpack_grad(u.dwp, cv.cout, cv.cin, cv.k, S2D_CPAD, cv._g2d)
-            self._wgrad_async(stem)
-            return None
         if u.is_patch_gemm:
-            self._wgrad_async(lambda: ops.conv_wgrad(u.src, dx4, 1, 1, 1, 0, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws))
+            self._stem_wgrad(u, dx4)
             return None
         if u.groups > 1:
             def grouped():
@@ -1161,7 +1181,18 @@ class _Plan(object):
                                                        u.wo, u.conv.cout, 3, 2, 1, _lib.ptr(dy0), _lib.stream_ptr()),
                        "iif_maxpool_backward")
             g = dy0
-        self._unit_backward(u, g, u.y, need_dgrad=False)
+        if self.pool_fused:
+            cv, bn = u.conv, u.bn
+            m = u.n * u.ho * u.wo
+            g2 = g.view(m, cv.cout)
+            _lib.check(_lib.lib().iif_bn_backward_relu_recompute(_lib.ptr(g2), _lib.ptr(u.x), _lib.dtype_code(u.x), m, cv.cout,
+                                                                 _lib.ptr(u.stats), _lib.ptr(bn.weight), _lib.ptr(bn._dgamma),
+                                                                 _lib.ptr(bn._dbeta), _lib.ptr(g2), _lib.ptr(self.bn_ws),
+                                                                 self.bn_ws.numel(), _lib.stream_ptr()),
+                       "iif_bn_backward_relu_recompute")
+            self._stem_wgrad(u, g2.view(u.n, u.ho, u.wo, cv.cout))
+        else:
+            self._unit_backward(u, g, u.y, need_dgrad=False)
         if self.wg_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wg_stream)
             self._wg_events.clear()

@@ -398,6 +398,17 @@ int iif_bn_backward_partials(const void* gy, const uint8_t* relu_bits, const voi
                              float* dgamma, float* dbeta, void* dx, void* workspace, int64_t workspace_bytes,
                              void* stream);
 
+/* Stem without a stored activation (resnet_pytorch.py:284-287: bn1 -> relu -> maxpool):
+ *   iif_maxpool_bn_forward           max pool over relu(a*x + b) of the RAW convolution output x (stats: scale at [2c],
+ *                                    shift at [3c]); candidates are rounded to the storage type first, so value and
+ *                                    argmax equal iif_bn_apply followed by iif_maxpool_forward
+ *   iif_bn_backward_relu_recompute   iif_bn_backward with the ReLU mask recomputed as a*x + b > 0 (same fmaf) */
+int iif_maxpool_bn_forward(const void* x, int dtype, const float* stats, int n, int h, int w, int c, int k, int stride,
+                           int pad, void* y, uint8_t* argmax, void* stream);
+int iif_bn_backward_relu_recompute(const void* gy, const void* x, int dtype, int64_t m, int c, const float* stats,
+                                   const float* gamma, float* dgamma, float* dbeta, void* dx, void* workspace,
+                                   int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

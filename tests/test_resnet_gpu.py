@@ -51,7 +51,7 @@ def gpu_relu_masks(net):
     """The ReLU decisions the GPU step actually took (stored activated outputs > 0),
     in forward order, as NCHW bool tensors for oracle.ReluMasks."""
     plan = net._saved
-    ys = [plan.stem.y] + [u.y for b in plan.blocks for u in b["units"]]
+    ys = [plan.stem_activation()] + [u.y for b in plan.blocks for u in b["units"]]
     return [(y > 0).permute(0, 3, 1, 2).cpu() for y in ys]
 
 
