@@ -334,12 +334,28 @@ __global__ void __launch_bounds__(256) shortcut_a_bwd_kernel(const T* g, int N, 
 }
 
 // ---------------------------------------------------------------- column sums (bias gradient)
+// 32 columns x 8 row lanes per block, 4 independent loads in flight per thread, row lanes combined in fixed order
 __global__ void __launch_bounds__(256) colsum_kernel(const float* a, int rows, int cols, int64_t ld, float* out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += a[(int64_t)r * ld + c];
-    out[c] = s;
+    __shared__ float sh[8][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cols) {
+        int r = rl;
+        for (; r + 24 < rows; r += 32) {
+            s0 += a[(int64_t)r * ld + c]; s1 += a[(int64_t)(r + 8) * ld + c];
+            s2 += a[(int64_t)(r + 16) * ld + c]; s3 += a[(int64_t)(r + 24) * ld + c];
+        }
+        for (; r < rows; r += 8) s0 += a[(int64_t)r * ld + c];
+    }
+    sh[rl][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += sh[j][cl];
+        out[c] = s;
+    }
 }
 
 // ---------------------------------------------------------------- fused SGD over a flat arena
@@ -535,7 +551,7 @@ int iif_shortcut_a_backward_acc(const void* g, int dtype, int n, int h, int w, i
 
 int iif_colsum_f32(const float* a, int rows, int cols, int64_t ld, float* out, void* stream) {
     if (!a || !out || rows <= 0 || cols <= 0 || ld < cols) return IIF_EINVAL;
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, as_stream(stream), a, rows, cols, ld, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 31) / 32), dim3(256), 0, as_stream(stream), a, rows, cols, ld, out);
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }
