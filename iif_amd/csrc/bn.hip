@@ -88,8 +88,19 @@ __device__ __forceinline__ void reduce_partials(const float* partial, int nblk, 
                                                 double* sh /* [2][256] */, int cl, double& s, double& q) {
     constexpr int LN = 256 / CB;
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int r = ln; r < nblk; r += LN) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
+    if (c < C) {
+        // 4 rows in flight per lane (the loads are independent; the sums keep their fixed order)
+        int r = ln;
+        for (; r + 3 * LN < nblk; r += 4 * LN) {
+            const float a0 = partial[(int64_t)r * 2 * C + c], b0 = partial[(int64_t)r * 2 * C + C + c];
+            const float a1 = partial[(int64_t)(r + LN) * 2 * C + c], b1 = partial[(int64_t)(r + LN) * 2 * C + C + c];
+            const float a2 = partial[(int64_t)(r + 2 * LN) * 2 * C + c], b2 = partial[(int64_t)(r + 2 * LN) * 2 * C + C + c];
+            const float a3 = partial[(int64_t)(r + 3 * LN) * 2 * C + c], b3 = partial[(int64_t)(r + 3 * LN) * 2 * C + C + c];
+            a += a0; a += a1; a += a2; a += a3;
+            b += b0; b += b1; b += b2; b += b3;
+        }
+        for (; r < nblk; r += LN) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
+    }
     sh[ln * CB + cl] = a; sh[256 + ln * CB + cl] = b;
     __syncthreads();
     s = 0.0; q = 0.0;
@@ -295,8 +306,18 @@ __global__ void __launch_bounds__(256) bn_partial_reduce_kernel(const float* par
     const int r0 = blockIdx.y * rows_per_slice;
     int r1 = r0 + rows_per_slice; if (r1 > nblk) r1 = nblk;
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int r = r0 + ln; r < r1; r += 8) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
+    if (c < C) {
+        int r = r0 + ln;
+        for (; r + 24 < r1; r += 32) {                  // 4 rows in flight per lane, sums in row order
+            const float a0 = partial[(int64_t)r * 2 * C + c], b0 = partial[(int64_t)r * 2 * C + C + c];
+            const float a1 = partial[(int64_t)(r + 8) * 2 * C + c], b1 = partial[(int64_t)(r + 8) * 2 * C + C + c];
+            const float a2 = partial[(int64_t)(r + 16) * 2 * C + c], b2 = partial[(int64_t)(r + 16) * 2 * C + C + c];
+            const float a3 = partial[(int64_t)(r + 24) * 2 * C + c], b3 = partial[(int64_t)(r + 24) * 2 * C + C + c];
+            a += a0; a += a1; a += a2; a += a3;
+            b += b0; b += b1; b += b2; b += b3;
+        }
+        for (; r < r1; r += 8) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
+    }
     sh[ln * 32 + cl] = a; sh[256 + ln * 32 + cl] = b;
     __syncthreads();
     if (ln == 0 && c < C) {
@@ -314,7 +335,10 @@ inline int two_stage_rows() {
 }
 
 // channels per finalize block: few channels x many lanes when there are many partial rows
-inline int finalize_cb(int nblk) { return nblk > 2048 ? 4 : (nblk > 256 ? 8 : 32); }
+inline int finalize_cb(int nblk) {
+    static const int t32 = getenv("IIF_BN_FIN_T32") ? atoi(getenv("IIF_BN_FIN_T32")) : 256;
+    return nblk > 2048 ? 4 : (nblk > t32 ? 8 : 32);
+}
 
 inline int launch_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
                               float eps, float momentum, float* rm, float* rv, float* stats, hipStream_t st) {

@@ -452,7 +452,15 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int 
         const int n = (int)(e % ldw);
         if (n >= K) continue;
         f32x4 s = *reinterpret_cast<const f32x4*>(ws + (int64_t)s0 * slab + e);
-        for (int j = s0 + 1; j < s1; ++j) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)j * slab + e);
+        int j = s0 + 1;
+        for (; j + 3 < s1; j += 4) {                      // 4 slabs in flight, added in slab order
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(ws + (int64_t)j * slab + e);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(ws + (int64_t)(j + 1) * slab + e);
+            const f32x4 t2 = *reinterpret_cast<const f32x4*>(ws + (int64_t)(j + 2) * slab + e);
+            const f32x4 t3 = *reinterpret_cast<const f32x4*>(ws + (int64_t)(j + 3) * slab + e);
+            s += t0; s += t1; s += t2; s += t3;
+        }
+        for (; j < s1; ++j) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)j * slab + e);
         *reinterpret_cast<f32x4*>(dst + e) = s;
     }
 }
