@@ -117,6 +117,12 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partial, 
     __shared__ double sh[512];
     const int cl = threadIdx.x % CB, ln = threadIdx.x / CB;
     const int c = blockIdx.x * CB + cl;
+    // per-channel parameters are fetched together with the partial rows, not in a second round trip after them
+    float ga = 0.f, be = 0.f, rm = 0.f, rv = 0.f;
+    if (ln == 0 && c < C) {
+        ga = gamma[c]; be = beta[c];
+        if (running_mean) { rm = running_mean[c]; rv = running_var[c]; }
+    }
     double s, q;
     reduce_partials<CB>(partial, nblk, C, c, ln, sh, cl, s, q);
     if (ln != 0 || c >= C) return;
@@ -124,15 +130,15 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partial, 
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float a = gamma[c] * invstd;
+    const float a = ga * invstd;
     stats[c] = (float)mean;
     stats[C + c] = invstd;
     stats[2 * C + c] = a;
-    stats[3 * C + c] = beta[c] - (float)mean * a;
+    stats[3 * C + c] = be - (float)mean * a;
     if (running_mean) {
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        running_mean[c] = (1.f - momentum) * rm + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * rv + momentum * (float)unbiased;
     }
 }
 
@@ -242,13 +248,14 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* parti
     __shared__ double sh[512];
     const int cl = threadIdx.x % CB, ln = threadIdx.x / CB;
     const int c = blockIdx.x * CB + cl;
+    float ga = 0.f, invstd = 0.f;
+    if (ln == 0 && c < C) { ga = gamma[c]; invstd = stats[C + c]; }
     double s1, s2;
     reduce_partials<CB>(partial, nblk, C, c, ln, sh, cl, s1, s2);
     if (ln != 0 || c >= C) return;
     dgamma[c] = (float)s2;
     dbeta[c] = (float)s1;
-    const float invstd = stats[C + c];
-    coef[c] = gamma[c] * invstd;
+    coef[c] = ga * invstd;
     coef[C + c] = (float)(s1 / count);
     coef[2 * C + c] = (float)(s2 / count) * invstd;
 }
