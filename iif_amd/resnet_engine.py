@@ -801,7 +801,7 @@ class _Plan(object):
         k, st, pd = u.geom
         m = u.n * u.ho * u.wo
         x2 = u.x.view(m, cv.cout)
-        if training and self.dt == torch.bfloat16 and cv.cout % 8 == 0:
+        if training and self.dt == torch.bfloat16 and cv.cout % 8 == 0 and _dma_ok(u.src):
             # statistics come out of the convolution's epilogue: no extra pass over x
             partial, scratch = (self.bn_partial_side, self.bn_scratch_side) if side else (self.bn_partial, self.bn_scratch)
             nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, partial, groups=u.groups)
@@ -1039,7 +1039,7 @@ class _Plan(object):
                                                      workspace=self.wg_ws))
         if not need_dgrad:
             return None
-        if fuse_up is not None and self.fuse_bwd and u.groups == 1 and dgrad_out is not None:
+        if fuse_up is not None and self.fuse_bwd and u.groups == 1 and dgrad_out is not None and _dma_ok(dx4):
             up, up_bits = fuse_up
             nt = ops.conv_dgrad_bnbwd(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), dgrad_out, up.x, up_bits, up.stats,
                                       self.bw_partial, res=dgrad_res, res_bits=dgrad_res_bits)
@@ -1198,6 +1198,15 @@ class _Plan(object):
             self._wg_events.clear()
         if reducer is not None:
             reducer.finish()
+
+
+_DMA_LIMIT = int(os.environ.get("IIF_DMA_LIMIT", str(0x7f000000)))      # lowered in tests to walk the unfused path
+
+
+def _dma_ok(t):
+    """The pipelined kernels address their operands with 32-bit LDS-DMA offsets (< 2 GiB); beyond that the
+    register-staged fallback runs and the fused epilogue options are not available."""
+    return t.numel() * t.element_size() < _DMA_LIMIT
 
 
 def _eval_stats(bn, stats):
