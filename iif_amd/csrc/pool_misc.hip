@@ -2,6 +2,7 @@
 // fused SGD update — the HBM-bound glue of the ResNet step on gfx950.  NHWC, 16-byte
 // channel vectors per lane wherever alignment allows.
 #include "common.h"
+#include "pool_gather.h"
 
 namespace {
 
@@ -152,6 +153,24 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* gy, const uns
                     if ((int)((codes >> (8 * q)) & 0xffu) == code) acc[q] += g[q];
             }
         PT<T>::store(dx + (((int64_t)n * H + h) * W + w) * C + c, acc);
+    }
+}
+
+// 3x3 / stride 2 / pad 1 (the ResNet stem pool): unrolled, all window loads in flight at once
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool321_bwd_kernel(const T* gy, const unsigned char* idx, int N, int H, int W,
+                                                             int C, int Ho, int Wo, T* dx) {
+    constexpr int V = PT<T>::V;
+    const unsigned cv = C / V, rowv = (unsigned)W * cv;
+    // one image row per block pass: h is uniform, only 32-bit index arithmetic
+    for (unsigned row = blockIdx.x; row < (unsigned)(N * H); row += gridDim.x) {
+        const unsigned n = row / (unsigned)H, h = row - n * H;
+        for (unsigned j = threadIdx.x; j < rowv; j += 256) {
+            const unsigned w = j / cv, c = (j - w * cv) * V;
+            float acc[V];
+            pool321_gather<T>(gy, idx, (int)n, (int)h, (int)w, (int)c, C, Ho, Wo, acc);
+            PT<T>::store(dx + ((int64_t)row * W + w) * C + c, acc);
+        }
     }
 }
 
@@ -437,6 +456,14 @@ int iif_maxpool_backward(const void* gy, const uint8_t* argmax, int dtype, int n
     if (mis(gy) || mis(dx) || c % (dtype == IIF_F32 ? 4 : 8)) return IIF_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
     const int64_t tot = (int64_t)n * h * w * (c / (dtype == IIF_F32 ? 4 : 8));
+    if (k == 3 && stride == 2 && pad == 1 && (int64_t)n * h < 0x7fffffffLL) {
+        const int rowblocks = (int)((int64_t)n * h < 16384 ? (int64_t)n * h : 16384);
+        IIF_BY_DTYPE(dtype,
+            hipLaunchKernelGGL(maxpool321_bwd_kernel<float>, dim3(rowblocks), dim3(256), 0, st, (const float*)gy, argmax, n, h, w, c, ho, wo, (float*)dx),
+            hipLaunchKernelGGL(maxpool321_bwd_kernel<unsigned short>, dim3(rowblocks), dim3(256), 0, st, (const unsigned short*)gy, argmax, n, h, w, c, ho, wo, (unsigned short*)dx))
+        IIF_LAUNCH_CHECK();
+        return IIF_OK;
+    }
     IIF_BY_DTYPE(dtype,
         hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, (const float*)gy, argmax, n, h, w, c, k, stride, pad, ho, wo, (float*)dx),
         hipLaunchKernelGGL(maxpool_bwd_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, (const unsigned short*)gy, argmax, n, h, w, c, k, stride, pad, ho, wo, (unsigned short*)dx))
