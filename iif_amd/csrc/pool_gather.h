@@ -1,7 +1,7 @@
 // Gradient of a 3x3 / stride-2 / pad-1 max pool seen from an INPUT pixel: the sum of the pooled gradients of the
 // (at most four) windows whose arg-max code points at this pixel.  Row h lies in window (h+1)>>1 and, when h is
-// odd, also in the one before it; same for columns.  All eight loads are issued up front (clamped addresses,
-// predicated use), windows are added in (row, column) order: the same order as the general-geometry loop.
+// odd, also in the one before it; same for columns.  One window row at a time (both columns' loads in flight,
+// clamped addresses, predicated use); windows are added in (row, column) order, the order of the general loop.
 #pragma once
 #include "vec16.h"
 
