@@ -438,6 +438,135 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 weight gradient with ALL NINE TAPS per block ("halo window", bf16).
+//
+// The tap-per-tile kernel above moves (128 + BC) * 2 B through the LDS-DMA path per pixel for 128 * BC MACs
+// (43 MAC/B at BC = 256) and is bound by DMA issue.  Here a block owns a 64 (ci) x 64 (co) tile of ALL taps:
+// 9 * 64 * 64 MACs per pixel for (64 + 64) * 2 B = 144 MAC/B.  The contraction runs over VIRTUAL pixels of the
+// zero-padded image, v = n*(H+2)*(W+2) + yp*(W+2) + xp: padding pixels are out-of-range DMA lanes (zeros in LDS,
+// free), so tap (r, s) is a plain row shift (r-1)*(W+2) + (s-1) of the x window with no border masks and no
+// wrap-around.  x rows live in a 256-row LDS ring (each 32-row block is loaded ONCE and read by the nine taps at
+// nine shifts), dy rows in a 128-row ring; per K step every wave issues one 1-KB piece of each, two steps ahead.
+// Wave w owns input channels 16w..16w+15: 9 taps x 4 output-channel blocks = 36 MFMAs and 144 accumulator
+// registers, 18 + 8 transposing LDS reads per step.  Output: the same split-K slabs as above.
+struct WgHaloArgs {
+    const unsigned char* x; const unsigned char* dy; float* out;
+    int N, H, W, Cs, Cd, ldw;
+    int ci_tiles, co_tiles, steps_per_split, nsteps, nsplits, HB;     // HB: ring lead in rows (32 | 64)
+    int64_t slab;
+};
+
+__global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, unsigned x_bytes, unsigned dy_bytes) {
+    constexpr int RB = 128;                       // row bytes of both tiles (64 bf16)
+    constexpr int XR = 256, YR = 128;             // ring rows
+    constexpr unsigned OOB = 0xfffffff0u;
+    using SW = Swz<unsigned short, 64>;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[(XR + YR) * RB];
+    unsigned char* const XS = smem;
+    unsigned char* const YS = smem + XR * RB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = a.ci_tiles * a.co_tiles;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int split = (jj / tiles) * 8 + xcd, tile = jj % tiles;
+    if (split >= a.nsplits) return;
+    const int ci0 = (tile % a.ci_tiles) * 64, co0 = (tile / a.ci_tiles) * 64;
+    const int step0 = split * a.steps_per_split;
+    int step1 = step0 + a.steps_per_split;
+    if (step1 > a.nsteps) step1 = a.nsteps;
+    const int nst = step1 - step0;
+    const int Wp = a.W + 2, PV = (a.H + 2) * Wp, HW = a.H * a.W;
+    const int V0 = step0 * 32, LEAD = a.HB >> 4;          // x blocks ahead of the dy block of the same step (2*HB/32)
+
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x), 0, x_bytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.dy), 0, dy_bytes, 0x00020000);
+
+    // ---- DMA lanes: this lane's row inside a 32-row block and its 16-byte chunk
+    const int lrow = 8 * wave + (lane >> 3);
+    struct Cur { int n, yp, xp; };
+    auto start = [&](int v) {                                 // v >= -64 > -PV
+        Cur c; const int t = v + PV; c.n = t / PV - 1; const int rem = t - (c.n + 1) * PV; c.yp = rem / Wp; c.xp = rem - c.yp * Wp;
+        return c;
+    };
+    auto advance = [&](Cur& c) {
+        c.xp += 32;
+        while (c.xp >= Wp) { c.xp -= Wp; if (++c.yp == a.H + 2) { c.yp = 0; ++c.n; } }
+    };
+    Cur cx = start(V0 - a.HB + lrow), cy = start(V0 + lrow);
+    int xblk = 0, yblk = 0;                                   // next block to load (ring position)
+    auto issue_x = [&]() {
+        const int prow = (xblk * 32 + lrow) & (XR - 1);
+        const int lc = SW::logical(lane & 7, prow);
+        const bool ok = (unsigned)cx.n < (unsigned)a.N && (unsigned)(cx.yp - 1) < (unsigned)a.H && (unsigned)(cx.xp - 1) < (unsigned)a.W;
+        const unsigned off = ok ? ((unsigned)(cx.n * HW + (cx.yp - 1) * a.W + cx.xp - 1) * (unsigned)a.Cs + (unsigned)(ci0 + lc * 8)) * 2u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_w*)(XS + ((xblk * 32 + 8 * wave) & (XR - 1)) * RB), 16, off, 0, 0, 0);
+        advance(cx); ++xblk;
+    };
+    auto issue_y = [&]() {
+        const int prow = (yblk * 32 + lrow) & (YR - 1);
+        const int lc = SW::logical(lane & 7, prow);
+        const bool ok = (unsigned)cy.n < (unsigned)a.N && (unsigned)(cy.yp - 1) < (unsigned)a.H && (unsigned)(cy.xp - 1) < (unsigned)a.W;
+        const unsigned off = ok ? ((unsigned)(cy.n * HW + (cy.yp - 1) * a.W + cy.xp - 1) * (unsigned)a.Cd + (unsigned)(co0 + lc * 8)) * 2u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)(YS + ((yblk * 32 + 8 * wave) & (YR - 1)) * RB), 16, off, 0, 0, 0);
+        advance(cy); ++yblk;
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj) acc[t][kj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: the x lead, then the (x, dy) pairs of steps 0 and 1 -- every later step issues exactly one pair
+    for (int j = 0; j < LEAD; ++j) issue_x();
+    issue_x(); issue_y();
+    issue_x(); issue_y();
+
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+    const int xcolb = (16 * wave + 4 * p) * 2;
+    for (int t = 0; t < nst; ++t) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // everything but the newest pair has landed
+        __builtin_amdgcn_s_barrier();
+        issue_x(); issue_y();                                   // blocks t+LEAD+2 / t+2: their ring slots were last read at step t-2
+        const int rb = 32 * t + a.HB + 4 * g + q;               // ring row of this lane's first pixel of the step, tap shift 0
+        s16x8 yf[4];
+        {
+            const int r0 = (32 * t + 4 * g + q) & (YR - 1), r1 = (r0 + 16) & (YR - 1);
+#pragma unroll
+            for (int kj = 0; kj < 4; ++kj) {
+                const int colb = (16 * kj + 4 * p) * 2;
+                const s16x4 lo = tr_read(YS + SW::addr(r0, colb)), hi = tr_read(YS + SW::addr(r1, colb));
+                yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int sh = (tap / 3 - 1) * Wp + (tap % 3 - 1);
+            const int r0 = (rb + sh) & (XR - 1), r1 = (r0 + 16) & (XR - 1);
+            const s16x4 lo = tr_read(XS + SW::addr(r0, xcolb)), hi = tr_read(XS + SW::addr(r1, xcolb));
+            const s16x8 xf = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int kj = 0; kj < 4; ++kj)
+                acc[tap][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf), __builtin_bit_cast(bf16x8, yf[kj]),
+                                                                        acc[tap][kj], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the trailing prefetches write LDS: drain before exit
+
+    float* out = a.out + (int64_t)split * a.slab;
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) {
+        const int k = co0 + kj * 16 + li;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int n = tap * a.Cs + ci0 + wave * 16 + g * 4;
+            *reinterpret_cast<f32x4*>(out + (int64_t)k * a.ldw + n) = acc[tap][kj];
+        }
+    }
+}
+
 // dw[k][n] = sum_s slab[s][k][n] for n < K (pad columns untouched), fixed order.  blockIdx.y selects a chunk
 // of `chunk` consecutive slabs; with gridDim.y > 1 the chunk sums go to out + blockIdx.y*slab (second stage
 // then runs with the chunk sums as its slabs).
@@ -465,6 +594,66 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int 
     }
 }
 
+// sum the split-K slabs into dw (fixed order)
+inline int reduce_slabs(float* ws, int64_t ws_bytes, int splits, int64_t slab, int rows, int ldw, int K, float* dw, hipStream_t st) {
+    const int64_t total4 = slab / 4;
+    const int blocks = (int)(cdiv64(total4, 256) < 2048 ? cdiv64(total4, 256) : 2048);
+    // few elements x many slabs: sum chunks of 16 slabs in parallel first (into the slab area itself:
+    // chunk c writes slab c, which only chunk 0 reads, and chunk 0's own slab 0 is read before written
+    // by the same thread), then one pass over the <= ceil(splits/16) chunk sums
+    if (splits > 32 && blocks * 256 < 65536) {
+        const int chunk = 16, nch = (splits + chunk - 1) / chunk;
+        float* stage = ws + (int64_t)splits * slab;       // needs nch more slabs of workspace
+        if ((int64_t)(splits + nch) * slab * 4 <= ws_bytes) {
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, nch), dim3(256), 0, st, ws, splits, chunk, slab, rows, ldw, K, stage, slab);
+            IIF_LAUNCH_CHECK();
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, stage, nch, nch, slab, rows, ldw, K, dw, (int64_t)0);
+            IIF_LAUNCH_CHECK();
+            return IIF_OK;
+        }
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, ws, splits, splits, slab, rows, ldw, K, dw, (int64_t)0);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+// all nine taps per block (conv3x3_wgrad_halo_kernel): 3x3 / stride 1 / pad 1, dense, bf16, channels in 64s, W <= 61
+inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_bytes, int splits_req, int64_t x_bytes,
+                             int64_t dy_bytes, hipStream_t st) {
+    WgHaloArgs h{};
+    h.x = a.x; h.dy = a.dy; h.N = a.N; h.H = a.Hd; h.W = a.Wd; h.Cs = a.Cs; h.Cd = a.Cd; h.ldw = a.ldw;
+    h.ci_tiles = a.Cs / 64; h.co_tiles = a.Cd / 64;
+    h.HB = a.Wd + 3 <= 32 ? 32 : 64;
+    const int64_t vt = (int64_t)a.N * (a.Hd + 2) * (a.Wd + 2);
+    if (vt > 0x7fff0000LL) return IIF_EUNSUPPORTED;
+    h.nsteps = (int)((vt + 31) / 32);
+    const int tiles = h.ci_tiles * h.co_tiles;
+    int splits = splits_req;
+    if (splits <= 0) {
+        static const int per_cu = getenv("IIF_WGRAD_HALO_BLOCKS") ? atoi(getenv("IIF_WGRAD_HALO_BLOCKS")) : 2;
+        splits = 256 * per_cu / tiles;
+        if (splits < 1) splits = 1;
+        const int max_by_work = h.nsteps / 8 > 0 ? h.nsteps / 8 : 1;
+        if (splits > max_by_work) splits = max_by_work;
+    }
+    const int64_t slab = (int64_t)a.Cd * a.ldw;
+    const int64_t fit = ws ? ws_bytes / (slab * 4) : 0;
+    if (splits > fit) splits = (int)fit;
+    if (splits < 1) splits = 1;
+    if (splits > h.nsteps) splits = h.nsteps;
+    if (splits > 65535) splits = 65535;
+    h.steps_per_split = (h.nsteps + splits - 1) / splits;
+    splits = (h.nsteps + h.steps_per_split - 1) / h.steps_per_split;
+    h.slab = splits > 1 ? slab : 0;
+    h.out = splits > 1 ? ws : dw;
+    h.nsplits = splits;
+    const dim3 grid((unsigned)(tiles * ((splits + 7) / 8) * 8));
+    hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, grid, dim3(256), 0, st, h, (unsigned)x_bytes, (unsigned)dy_bytes);
+    IIF_LAUNCH_CHECK();
+    if (splits > 1) return reduce_slabs(ws, ws_bytes, splits, slab, a.Cd, a.ldw, a.K, dw, st);
+    return IIF_OK;
+}
+
 template <typename T>
 int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_req, int64_t x_bytes, int64_t dy_bytes,
                  hipStream_t st) {
@@ -472,6 +661,13 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     // 256-channel tiles (8 waves): bf16, dense, >= 256 output channels, the LDS-DMA path
     static const char* wide_env = getenv("IIF_WGRAD_BC");
     const bool dma_ok = getenv("IIF_CONV_REGSTAGE") == nullptr && x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL;
+    if constexpr (sizeof(T) == 2) {
+        static const char* halo_env = getenv("IIF_WGRAD_HALO");          // "0": keep the tap-per-tile kernel
+        const bool halo = dma_ok && a.groups == 1 && a.R == 3 && a.S == 3 && a.sshift == 0 && a.pad == 1 && a.Hs == a.Hd &&
+                          a.Ws == a.Wd && a.Cs % 64 == 0 && a.Cd % 64 == 0 && a.Wd + 3 <= 64 && a.xpitch == a.Cs &&
+                          a.ypitch == a.Cd && !(halo_env && atoi(halo_env) == 0);
+        if (halo) return launch_wgrad_halo(a, dw, ws, ws_bytes, splits_req, x_bytes, dy_bytes, st);
+    }
     bool wide = sizeof(T) == 2 && dma_ok && a.groups == 1 && a.Cd >= 256 && a.Cd % 256 == 0;
     if (wide && wide_env) wide = atoi(wide_env) == 256;
     const int bc = wide ? 256 : (a.Cd <= 64 ? 64 : 128);
@@ -518,29 +714,7 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
         else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, st, a);
     }
     IIF_LAUNCH_CHECK();
-    if (splits > 1) {
-        const int64_t total4 = slab / 4;
-        const int blocks = (int)(cdiv64(total4, 256) < 2048 ? cdiv64(total4, 256) : 2048);
-        // few elements x many slabs: sum chunks of 16 slabs in parallel first (into the slab area itself:
-        // chunk c writes slab c, which only chunk 0 reads, and chunk 0's own slab 0 is read before written
-        // by the same thread), then one pass over the <= ceil(splits/16) chunk sums
-        if (splits > 32 && blocks * 256 < 65536) {
-            const int chunk = 16, nch = (splits + chunk - 1) / chunk;
-            float* stage = ws + (int64_t)splits * slab;       // needs nch more slabs of workspace
-            if ((int64_t)(splits + nch) * slab * 4 <= ws_bytes) {
-                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, nch), dim3(256), 0, st, ws, splits, chunk, slab,
-                                   a.groups * a.Cd, a.ldw, a.K, stage, slab);
-                IIF_LAUNCH_CHECK();
-                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, stage, nch, nch, slab,
-                                   a.groups * a.Cd, a.ldw, a.K, dw, (int64_t)0);
-                IIF_LAUNCH_CHECK();
-                return IIF_OK;
-            }
-        }
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, ws, splits, splits, slab,
-                           a.groups * a.Cd, a.ldw, a.K, dw, (int64_t)0);
-        IIF_LAUNCH_CHECK();
-    }
+    if (splits > 1) return reduce_slabs(ws, ws_bytes, splits, slab, a.groups * a.Cd, a.ldw, a.K, dw, st);
     return IIF_OK;
 }
 

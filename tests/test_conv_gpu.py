@@ -99,7 +99,13 @@ def test_conv_rejects_bad_shapes():
         ops.conv_forward(x, w, 3, 3, 3, 1)            # stride 3 unsupported
 
 
-@pytest.mark.parametrize("case", CASES + [(4, 64, 28, 28, 64, 3, 1, 1), (2, 64, 33, 31, 256, 1, 1, 0)])
+# 3x3/s1/p1 with channels in 64s run the nine-taps-per-block kernel in bf16 (conv3x3_wgrad_halo_kernel): both ring
+# leads (W+3 <= 32 | 64), non-square images, W not a multiple of anything, several channel tiles, one image
+HALO_WGRAD = [(2, 64, 14, 14, 64, 3, 1, 1), (3, 128, 7, 7, 64, 3, 1, 1), (2, 64, 56, 56, 64, 3, 1, 1), (1, 128, 28, 28, 128, 3, 1, 1),
+              (4, 64, 9, 13, 128, 3, 1, 1), (2, 64, 37, 61, 64, 3, 1, 1), (1, 256, 5, 30, 64, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("case", CASES + [(4, 64, 28, 28, 64, 3, 1, 1), (2, 64, 33, 31, 256, 1, 1, 0)] + HALO_WGRAD)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_conv_wgrad(case, dt):
     from iif_amd import ops
