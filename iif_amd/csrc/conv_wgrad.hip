@@ -457,9 +457,12 @@ struct WgHaloArgs {
     int64_t slab;
 };
 
+// XB / YB: 32-row blocks in the x / dy rings, D: (x, dy) block pairs in flight ahead of the step being multiplied.
+// A new block may only land on a slot last read two steps ago: D <= XB - 2 - LEAD and D <= YB - 2.
+template <int XB, int YB, int D>
 __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, unsigned x_bytes, unsigned dy_bytes) {
     constexpr int RB = 128;                       // row bytes of both tiles (64 bf16)
-    constexpr int XR = 256, YR = 128;             // ring rows
+    constexpr int XR = 32 * XB, YR = 32 * YB;     // ring rows
     constexpr unsigned OOB = 0xfffffff0u;
     using SW = Swz<unsigned short, 64>;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[(XR + YR) * RB];
@@ -485,6 +488,8 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, u
 
     // ---- DMA lanes: this lane's row inside a 32-row block and its 16-byte chunk
     const int lrow = 8 * wave + (lane >> 3);
+    // (image, padded row, padded column) of the lane's next pixel, advanced by 32 virtual pixels per block: cheaper
+    // than recomputing the decomposition by reciprocal multiplication (measured: fp32 / fp64 reciprocals 10 % slower)
     struct Cur { int n, yp, xp; };
     auto start = [&](int v) {                                 // v >= -64 > -PV
         Cur c; const int t = v + PV; c.n = t / PV - 1; const int rem = t - (c.n + 1) * PV; c.yp = rem / Wp; c.xp = rem - c.yp * Wp;
@@ -519,41 +524,64 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, u
 #pragma unroll
         for (int kj = 0; kj < 4; ++kj) acc[t][kj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // prologue: the x lead, then the (x, dy) pairs of steps 0 and 1 -- every later step issues exactly one pair
+    // prologue: the x lead, then the (x, dy) pairs of steps 0 .. D-1 -- every later step issues exactly one pair
     for (int j = 0; j < LEAD; ++j) issue_x();
-    issue_x(); issue_y();
-    issue_x(); issue_y();
+#pragma unroll
+    for (int j = 0; j < D; ++j) { issue_x(); issue_y(); }
 
     const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
-    const int xcolb = (16 * wave + 4 * p) * 2;
-    for (int t = 0; t < nst; ++t) {
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // everything but the newest pair has landed
-        __builtin_amdgcn_s_barrier();
-        issue_x(); issue_y();                                   // blocks t+LEAD+2 / t+2: their ring slots were last read at step t-2
-        const int rb = 32 * t + a.HB + 4 * g + q;               // ring row of this lane's first pixel of the step, tap shift 0
-        s16x8 yf[4];
-        {
-            const int r0 = (32 * t + 4 * g + q) & (YR - 1), r1 = (r0 + 16) & (YR - 1);
+    // LDS byte offsets of this lane's fragment reads at step 0.  A step moves every row by 32: the swizzle key
+    // ((row >> 1) & 3) is unchanged, so the offset just advances by 32 rows modulo the ring.
+    int xo[9], yo[4];
 #pragma unroll
-            for (int kj = 0; kj < 4; ++kj) {
-                const int colb = (16 * kj + 4 * p) * 2;
-                const s16x4 lo = tr_read(YS + SW::addr(r0, colb)), hi = tr_read(YS + SW::addr(r1, colb));
-                yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            }
+    for (int tap = 0; tap < 9; ++tap)
+        xo[tap] = SW::addr((a.HB + 4 * g + q + (tap / 3 - 1) * Wp + (tap % 3 - 1)) & (XR - 1), (16 * wave + 4 * p) * 2);
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) yo[kj] = SW::addr(4 * g + q, (16 * kj + 4 * p) * 2);
+#ifdef IIF_CONV_STAMPS
+    unsigned long long w_wait = 0, w_issue = 0, w_rest = 0, w0, w1, w2, w3, wb;
+    IIF_WSTAMP(wb); w3 = wb;
+#endif
+    for (int t = 0; t < nst; ++t) {
+#ifdef IIF_CONV_STAMPS
+        IIF_WSTAMP(w0); w_rest += w0 - w3;
+#endif
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");       // this step's pair has landed, D-1 pairs still in flight
+        __builtin_amdgcn_s_barrier();
+#ifdef IIF_CONV_STAMPS
+        IIF_WSTAMP(w1);
+#endif
+        issue_x(); issue_y();                                   // blocks t+LEAD+D / t+D: their ring slots were last read at step t-2 or earlier
+#ifdef IIF_CONV_STAMPS
+        IIF_WSTAMP(w2); w_wait += w1 - w0; w_issue += w2 - w1; w3 = w2;
+#endif
+        const int xs = t * (32 * RB), ys = t * (32 * RB);
+        s16x8 yf[4], xf[9];
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj) {
+            const s16x4 lo = tr_read(YS + ((yo[kj] + ys) & (YR * RB - 1))), hi = tr_read(YS + ((yo[kj] + ys + 16 * RB) & (YR * RB - 1)));
+            yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int sh = (tap / 3 - 1) * Wp + (tap % 3 - 1);
-            const int r0 = (rb + sh) & (XR - 1), r1 = (r0 + 16) & (XR - 1);
-            const s16x4 lo = tr_read(XS + SW::addr(r0, xcolb)), hi = tr_read(XS + SW::addr(r1, xcolb));
-            const s16x8 xf = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const s16x4 lo = tr_read(XS + ((xo[tap] + xs) & (XR * RB - 1))), hi = tr_read(XS + ((xo[tap] + xs + 16 * RB) & (XR * RB - 1)));
+            xf[tap] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
             for (int kj = 0; kj < 4; ++kj)
-                acc[tap][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf), __builtin_bit_cast(bf16x8, yf[kj]),
+                acc[tap][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf[tap]), __builtin_bit_cast(bf16x8, yf[kj]),
                                                                         acc[tap][kj], 0, 0, 0);
-        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the trailing prefetches write LDS: drain before exit
+#ifdef IIF_CONV_STAMPS
+    IIF_WSTAMP(w0); w_rest += w0 - w3;
+    if (g_wstamps && blockIdx.x < 512 && lane == 0 && wave < 4) {
+        unsigned long long* o = g_wstamps + ((int64_t)blockIdx.x * 4 + wave) * 8;
+        o[0] = w_wait; o[1] = 0; o[2] = w_issue; o[3] = w_rest; o[4] = 0; o[5] = w0 - wb; o[6] = (unsigned long long)nst; o[7] = wb;
+    }
+#endif
 
     float* out = a.out + (int64_t)split * a.slab;
 #pragma unroll
@@ -625,7 +653,7 @@ inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_b
     h.ci_tiles = a.Cs / 64; h.co_tiles = a.Cd / 64;
     h.HB = a.Wd + 3 <= 32 ? 32 : 64;
     const int64_t vt = (int64_t)a.N * (a.Hd + 2) * (a.Wd + 2);
-    if (vt > 0x7fff0000LL) return IIF_EUNSUPPORTED;
+    if (vt > 0x7fff0000LL) return -100;            // beyond the 32-bit virtual index: caller falls back
     h.nsteps = (int)((vt + 31) / 32);
     const int tiles = h.ci_tiles * h.co_tiles;
     int splits = splits_req;
@@ -648,7 +676,10 @@ inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_b
     h.out = splits > 1 ? ws : dw;
     h.nsplits = splits;
     const dim3 grid((unsigned)(tiles * ((splits + 7) / 8) * 8));
-    hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, grid, dim3(256), 0, st, h, (unsigned)x_bytes, (unsigned)dy_bytes);
+    // 8-block x ring, 4-block dy ring, two block pairs in flight (48 KB, two blocks per CU).  Deeper rings were
+    // measured: <8,8,4> equal at W <= 29, <16,8,6> (one block per CU) 10 % slower at 56x56 -- the issue phase is
+    // bound by the DMA path, not by latency.
+    hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<8, 4, 2>), grid, dim3(256), 0, st, h, (unsigned)x_bytes, (unsigned)dy_bytes);
     IIF_LAUNCH_CHECK();
     if (splits > 1) return reduce_slabs(ws, ws_bytes, splits, slab, a.Cd, a.ldw, a.K, dw, st);
     return IIF_OK;
@@ -666,7 +697,10 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
         const bool halo = dma_ok && a.groups == 1 && a.R == 3 && a.S == 3 && a.sshift == 0 && a.pad == 1 && a.Hs == a.Hd &&
                           a.Ws == a.Wd && a.Cs % 64 == 0 && a.Cd % 64 == 0 && a.Wd + 3 <= 64 && a.xpitch == a.Cs &&
                           a.ypitch == a.Cd && !(halo_env && atoi(halo_env) == 0);
-        if (halo) return launch_wgrad_halo(a, dw, ws, ws_bytes, splits_req, x_bytes, dy_bytes, st);
+        if (halo) {
+            const int rc = launch_wgrad_halo(a, dw, ws, ws_bytes, splits_req, x_bytes, dy_bytes, st);
+            if (rc != -100) return rc;
+        }
     }
     bool wide = sizeof(T) == 2 && dma_ok && a.groups == 1 && a.Cd >= 256 && a.Cd % 256 == 0;
     if (wide && wide_env) wide = atoi(wide_env) == 256;

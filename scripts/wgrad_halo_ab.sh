@@ -1,5 +1,5 @@
 #!/bin/bash
-# nine-taps-per-block 3x3 weight gradient vs the tap-per-tile kernel: isolated shapes, then the whole step
+# nine-taps-per-block 3x3 weight gradient: tap-per-tile kernel (HALO=0) vs the halo-window kernel
 for a in "wgrad 256 56 64 64 3 1" "wgrad 256 28 128 128 3 1" "wgrad 256 14 256 256 3 1" "wgrad 256 7 512 512 3 1"; do
   IIF_WGRAD_HALO=0 python scripts/prof_conv.py $a 20
   python scripts/prof_conv.py $a 20
