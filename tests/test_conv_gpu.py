@@ -103,9 +103,11 @@ def test_conv_rejects_bad_shapes():
 # leads (W+3 <= 32 | 64), non-square images, W not a multiple of anything, several channel tiles, one image
 HALO_WGRAD = [(2, 64, 14, 14, 64, 3, 1, 1), (3, 128, 7, 7, 64, 3, 1, 1), (2, 64, 56, 56, 64, 3, 1, 1), (1, 128, 28, 28, 128, 3, 1, 1),
               (4, 64, 9, 13, 128, 3, 1, 1), (2, 64, 37, 61, 64, 3, 1, 1), (1, 256, 5, 30, 64, 3, 1, 1)]
+# >= 256 output channels with long kernel rows (the 256-channel tile, 8 waves)
+SQUARE_WGRAD = [(2, 512, 14, 14, 256, 1, 1, 0), (2, 256, 15, 13, 256, 3, 2, 1), (3, 768, 7, 7, 512, 1, 1, 0)]
 
 
-@pytest.mark.parametrize("case", CASES + [(4, 64, 28, 28, 64, 3, 1, 1), (2, 64, 33, 31, 256, 1, 1, 0)] + HALO_WGRAD)
+@pytest.mark.parametrize("case", CASES + [(4, 64, 28, 28, 64, 3, 1, 1), (2, 64, 33, 31, 256, 1, 1, 0)] + HALO_WGRAD + SQUARE_WGRAD)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_conv_wgrad(case, dt):
     from iif_amd import ops
