@@ -148,8 +148,8 @@ class ConvTimer(object):
             ms = e0.elapsed_time(e1)
             tot_ms += ms; tot_fl += fl
             self.sol_ms += 1e3 * max(fl / (MFMA_BF16_PEAK_TFLOPS * 1e12), nb / (HBM_PEAK_GBS * 1e9))
-            k = by.setdefault(kind, [0, 0.0, 0.0])
-            k[0] += 1; k[1] += ms; k[2] += fl
+            k = by.setdefault(kind, [0, 0.0, 0.0, 0.0])
+            k[0] += 1; k[1] += ms; k[2] += fl; k[3] += nb
         return tot_ms, tot_fl, by
 
 
@@ -370,6 +370,8 @@ def main():
                 "conv_ms_per_step": round(tot_ms / nsamp, 3),
                 "by_kind_ms_per_step": {k: round(v[1] / nsamp, 3) for k, v in by.items()},
                 "by_kind_tflops": {k: round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0},
+                # every operand / result of a launch moved exactly once (what `traffic_detail` is to be compared with)
+                "by_kind_ideal_GB_per_step": {k: round(v[3] / nsamp / 1e9, 2) for k, v in by.items()},
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(counts, args.cpu_batch, args.cpu_steps)
