@@ -179,7 +179,7 @@ def profiled_traffic():
             "all_kernels_GB_per_step": round(step_mb / 1e3, 2), "source": os.path.relpath(files[-1], ROOT)}
 
 
-def cpu_baseline(counts, sample_bs, steps):
+def cpu_baseline(counts, sample_bs, steps, device=None):
     """The CPU oracle (torch-CPU fp32 restatement of the reference training step)
     on a bounded sample: same model, same loss, same SGD, `sample_bs` images."""
     from oracle import iif_oracle as O
@@ -198,14 +198,39 @@ def cpu_baseline(counts, sample_bs, steps):
     y = torch.multinomial(prior / prior.sum(), sample_bs, replacement=True, generator=g)
     table = O.iif_tables(counts)["raw"]
     bufs = {}
-    R.train_step(sd, bufs, x, y, table, "resnet50", 1e-4)            # warm-up
+    sd0 = {k: v.clone() for k, v in sd.items()}
+    losses = [float(R.train_step(sd, bufs, x, y, table, "resnet50", 1e-4)[0])]            # warm-up
     t0 = time.time()
     for it in range(steps):
-        R.train_step(sd, bufs, x, y, table, "resnet50", 1e-4)
+        losses.append(float(R.train_step(sd, bufs, x, y, table, "resnet50", 1e-4)[0]))
     dt = time.time() - t0
-    return {"value": round(sample_bs * steps / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "oracle.resnet_oracle.train_step, ResNet50+IIF(raw) fp32, bs=%d 224x224, %d steps after 1 warm-up "
-                      "(%.1f s)" % (sample_bs, steps, dt)}
+    out = {"value": round(sample_bs * steps / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": "oracle.resnet_oracle.train_step, ResNet50+IIF(raw) fp32, bs=%d 224x224, %d steps after 1 warm-up "
+                     "(%.1f s)" % (sample_bs, steps, dt)}
+    # loss delta vs CPU on identical inputs: the same initial weights, batch and SGD steps through the HIP path
+    if device is not None:
+        from iif_amd import resnet_pytorch
+        from iif_amd.custom import IIFLoss
+        crit = IIFLoss(_Counts(counts), variant="raw", reduction="mean", device=device)
+        for name, dt_ in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            net = resnet_pytorch.resnet50(num_classes=len(counts), use_norm="None", pretrained="None", device=device, compute_dtype=dt_)
+            net.load_state_dict(sd0)
+            net.train()
+            xd, yd = x.to(device), y.to(device)
+            deltas = []
+            for it in range(steps + 1):
+                loss, _ = net.loss_and_backward(xd, yd, crit)
+                net.sgd_step(1e-4, 0.9, 1e-4)
+                deltas.append(abs(float(loss) - losses[it]) / max(abs(losses[it]), 1e-12))
+            out["loss_rel_delta_first_step_" + name] = float("%.3g" % deltas[0])
+            out["loss_max_rel_delta_" + name] = float("%.3g" % max(deltas))
+            del net
+        out["loss_steps_compared"] = steps + 1
+        out["loss_note"] = ("same weights, batch and SGD steps (lr 1e-4) through the HIP path; random-init raw-IIF training is chaotic: the "
+                            "CPU oracle run with 8 vs 3 threads differs by 4.8e-2 over the same 9 steps (DESIGN.md section 6), so only the "
+                            "first step isolates arithmetic; controlled-condition curves are asserted to 1e-4 in tests/test_resnet_gpu.py")
+        out["cpu_losses"] = [round(v, 4) for v in losses]
+    return out
 
 
 def main():
@@ -374,7 +399,7 @@ def main():
                 "by_kind_ideal_GB_per_step": {k: round(v[3] / nsamp / 1e9, 2) for k, v in by.items()},
             }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(counts, args.cpu_batch, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(counts, args.cpu_batch, args.cpu_steps, dev if args.model == "resnet50" else None)
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
