@@ -491,7 +491,9 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, u
     // (image, padded row, padded column) of the lane's next pixel, advanced by 32 virtual pixels per block: cheaper
     // than recomputing the decomposition by reciprocal multiplication (measured: fp32 / fp64 reciprocals 10 % slower)
     struct Cur { int n, yp, xp; };
-    auto start = [&](int v) {                                 // v >= -64 > -PV
+    // For v < 0 (before the first image) the truncating divisions leave a non-canonical but linearly consistent
+    // (n < 0, yp <= 0, xp <= 0): such pixels are out of range anyway, and advance() walks back into canonical form.
+    auto start = [&](int v) {
         Cur c; const int t = v + PV; c.n = t / PV - 1; const int rem = t - (c.n + 1) * PV; c.yp = rem / Wp; c.xp = rem - c.yp * Wp;
         return c;
     };

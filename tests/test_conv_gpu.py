@@ -102,7 +102,9 @@ def test_conv_rejects_bad_shapes():
 # 3x3/s1/p1 with channels in 64s run the nine-taps-per-block kernel in bf16 (conv3x3_wgrad_halo_kernel): both ring
 # leads (W+3 <= 32 | 64), non-square images, W not a multiple of anything, several channel tiles, one image
 HALO_WGRAD = [(2, 64, 14, 14, 64, 3, 1, 1), (3, 128, 7, 7, 64, 3, 1, 1), (2, 64, 56, 56, 64, 3, 1, 1), (1, 128, 28, 28, 128, 3, 1, 1),
-              (4, 64, 9, 13, 128, 3, 1, 1), (2, 64, 37, 61, 64, 3, 1, 1), (1, 256, 5, 30, 64, 3, 1, 1)]
+              (4, 64, 9, 13, 128, 3, 1, 1), (2, 64, 37, 61, 64, 3, 1, 1), (1, 256, 5, 30, 64, 3, 1, 1),
+              # padded images shorter than the ring lead (the cursor starts more than one image before pixel 0)
+              (4, 64, 2, 2, 64, 3, 1, 1), (3, 128, 1, 1, 64, 3, 1, 1), (2, 64, 4, 3, 128, 3, 1, 1), (40, 64, 1, 2, 64, 3, 1, 1)]
 # >= 256 output channels with long kernel rows (the 256-channel tile, 8 waves)
 SQUARE_WGRAD = [(2, 512, 14, 14, 256, 1, 1, 0), (2, 256, 15, 13, 256, 3, 2, 1), (3, 768, 7, 7, 512, 1, 1, 0)]
 
