@@ -597,6 +597,130 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, u
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the space-to-depth stem (4x4 / stride 1 / pad 2 top-left, 1 bottom-right over [N, H, W, 16] ->
+// [N, H, W, 64], bf16): the same virtual-pixel scheme as conv3x3_wgrad_halo_kernel with ALL SIXTEEN TAPS per block.
+// An x pixel is only 32 bytes, so the tap-per-tile kernel gathers 16-byte pieces sixteen times over (21 MAC per DMA
+// byte); here a 32-pixel block of x is ONE 1-KB piece, loaded once into a 512-row ring and read at sixteen row
+// shifts (r-2)*(W+3) + (s-2): 16*16*64 MACs per pixel for 32 + 128 B = 102 MAC/B.  Wave w owns tap row r = w:
+// 4 taps x 4 output-channel blocks = 16 MFMAs into 64 accumulator registers per step.  This launch is the tail of
+// the backward pass (nothing left to overlap it with), so its duration is exposed one to one.
+struct WgStemArgs {
+    const unsigned char* x; const unsigned char* dy; float* out;
+    int N, H, W, ldw, steps_per_split, nsteps, nsplits, LB, LEAD;     // LB: ring blocks before the step's own, LEAD: blocks ahead in total
+    int64_t slab;
+};
+
+__global__ void __launch_bounds__(256) conv4x4_s2d_wgrad_kernel(WgStemArgs a, unsigned x_bytes, unsigned dy_bytes) {
+    constexpr int XRB = 32, YRB = 128;            // row bytes: 16 / 64 bf16
+    constexpr int XR = 512, YR = 128;             // ring rows (16 + 4 blocks of 32)
+    constexpr int D = 2;                          // block pairs in flight; needs LEAD + D <= 14 (host-checked)
+    constexpr unsigned OOB = 0xfffffff0u;
+    using SW = Swz<unsigned short, 64>;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[XR * XRB + YR * YRB];
+    unsigned char* const XS = smem;
+    unsigned char* const YS = smem + XR * XRB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int split = jj * 8 + xcd;
+    if (split >= a.nsplits) return;
+    const int step0 = split * a.steps_per_split;
+    int step1 = step0 + a.steps_per_split;
+    if (step1 > a.nsteps) step1 = a.nsteps;
+    const int nst = step1 - step0;
+    const int Wp = a.W + 3, Hp = a.H + 3, PV = Hp * Wp, HW = a.H * a.W;
+    const int V0 = step0 * 32;
+
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x), 0, x_bytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.dy), 0, dy_bytes, 0x00020000);
+
+    // cursors over virtual pixels (see conv3x3_wgrad_halo_kernel); the pixel at padded (yp, xp) is (yp - 2, xp - 2)
+    struct Cur { int n, yp, xp; };
+    auto start = [&](int v) {
+        const int t = v + 32 * PV;                       // v >= -32 * LB > -32 * PV
+        Cur c; c.n = t / PV - 32; const int rem = t - (c.n + 32) * PV; c.yp = rem / Wp; c.xp = rem - c.yp * Wp;
+        return c;
+    };
+    auto advance = [&](Cur& c) {
+        c.xp += 32;
+        while (c.xp >= Wp) { c.xp -= Wp; if (++c.yp == Hp) { c.yp = 0; ++c.n; } }
+    };
+    const int xrow = lane >> 1, yrow = 8 * wave + (lane >> 3);      // the lane's row inside a 32-row block (x: wave 0 only)
+    Cur cx = start(V0 - 32 * a.LB + xrow), cy = start(V0 + yrow);
+    int xblk = 0, yblk = 0;
+    auto issue_x = [&]() {
+        const bool ok = (unsigned)cx.n < (unsigned)a.N && (unsigned)(cx.yp - 2) < (unsigned)a.H && (unsigned)(cx.xp - 2) < (unsigned)a.W;
+        const unsigned off = ok ? ((unsigned)(cx.n * HW + (cx.yp - 2) * a.W + cx.xp - 2) * 16u + (unsigned)((lane & 1) * 8)) * 2u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_w*)(XS + ((xblk * 32) & (XR - 1)) * XRB), 16, off, 0, 0, 0);
+        advance(cx); ++xblk;
+    };
+    auto issue_y = [&]() {
+        const int prow = (yblk * 32 + yrow) & (YR - 1);
+        const int lc = SW::logical(lane & 7, prow);
+        const bool ok = (unsigned)cy.n < (unsigned)a.N && (unsigned)(cy.yp - 2) < (unsigned)a.H && (unsigned)(cy.xp - 2) < (unsigned)a.W;
+        const unsigned off = ok ? ((unsigned)(cy.n * HW + (cy.yp - 2) * a.W + cy.xp - 2) * 64u + (unsigned)(lc * 8)) * 2u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)(YS + ((yblk * 32 + 8 * wave) & (YR - 1)) * YRB), 16, off, 0, 0, 0);
+        advance(cy); ++yblk;
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj) acc[t][kj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (wave == 0) for (int j = 0; j < a.LEAD; ++j) issue_x();
+#pragma unroll
+    for (int j = 0; j < D; ++j) { if (wave == 0) issue_x(); issue_y(); }
+
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+    int xo[4], yo[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+        xo[s_] = ((32 * a.LB + 4 * g + q + (wave - 2) * Wp + (s_ - 2)) & (XR - 1)) * XRB + 4 * p * 2;
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) yo[kj] = SW::addr(4 * g + q, (16 * kj + 4 * p) * 2);
+    for (int t = 0; t < nst; ++t) {
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave == 0) issue_x();
+        issue_y();
+        const int xs = t * (32 * XRB), ys = t * (32 * YRB);
+        s16x8 yf[4], xf[4];
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj) {
+            const s16x4 lo = tr_read(YS + ((yo[kj] + ys) & (YR * YRB - 1))), hi = tr_read(YS + ((yo[kj] + ys + 16 * YRB) & (YR * YRB - 1)));
+            yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const s16x4 lo = tr_read(XS + ((xo[s_] + xs) & (XR * XRB - 1))), hi = tr_read(XS + ((xo[s_] + xs + 16 * XRB) & (XR * XRB - 1)));
+            xf[s_] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int kj = 0; kj < 4; ++kj)
+                acc[s_][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf[s_]), __builtin_bit_cast(bf16x8, yf[kj]),
+                                                                       acc[s_][kj], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    float* out = a.out + (int64_t)split * a.slab;
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) {
+        const int k = kj * 16 + li;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const int n = (wave * 4 + s_) * 16 + g * 4;
+            *reinterpret_cast<f32x4*>(out + (int64_t)k * a.ldw + n) = acc[s_][kj];
+        }
+    }
+}
+
 // dw[k][n] = sum_s slab[s][k][n] for n < K (pad columns untouched), fixed order.  blockIdx.y selects a chunk
 // of `chunk` consecutive slabs; with gridDim.y > 1 the chunk sums go to out + blockIdx.y*slab (second stage
 // then runs with the chunk sums as its slabs).
@@ -687,6 +811,43 @@ inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_b
     return IIF_OK;
 }
 
+// all sixteen taps per block for the space-to-depth stem (conv4x4_s2d_wgrad_kernel)
+inline int launch_wgrad_stem(const WgArgs& a, float* dw, float* ws, int64_t ws_bytes, int splits_req, int64_t x_bytes,
+                             int64_t dy_bytes, hipStream_t st) {
+    WgStemArgs h{};
+    h.x = a.x; h.dy = a.dy; h.N = a.N; h.H = a.Hd; h.W = a.Wd; h.ldw = a.ldw;
+    const int Wp = a.Wd + 3;
+    h.LB = (2 * Wp + 2 + 31) / 32;
+    h.LEAD = h.LB + (31 + Wp + 1) / 32;
+    if (h.LEAD + 2 > 14) return -100;                // the 16-block x ring cannot hold the window: caller falls back
+    const int64_t vt = (int64_t)a.N * (a.Hd + 3) * Wp;
+    if (vt > 0x7fff0000LL) return -100;
+    h.nsteps = (int)((vt + 31) / 32);
+    int splits = splits_req;
+    if (splits <= 0) {
+        static const int per_cu = getenv("IIF_WGRAD_STEM_BLOCKS") ? atoi(getenv("IIF_WGRAD_STEM_BLOCKS")) : 2;
+        splits = 256 * per_cu;
+        const int max_by_work = h.nsteps / 8 > 0 ? h.nsteps / 8 : 1;
+        if (splits > max_by_work) splits = max_by_work;
+    }
+    const int64_t slab = (int64_t)a.Cd * a.ldw;
+    const int64_t fit = ws ? ws_bytes / (slab * 4) : 0;
+    if (splits > fit) splits = (int)fit;
+    if (splits < 1) splits = 1;
+    if (splits > h.nsteps) splits = h.nsteps;
+    if (splits > 65535) splits = 65535;
+    h.steps_per_split = (h.nsteps + splits - 1) / splits;
+    splits = (h.nsteps + h.steps_per_split - 1) / h.steps_per_split;
+    h.slab = splits > 1 ? slab : 0;
+    h.out = splits > 1 ? ws : dw;
+    h.nsplits = splits;
+    hipLaunchKernelGGL(conv4x4_s2d_wgrad_kernel, dim3((unsigned)(((splits + 7) / 8) * 8)), dim3(256), 0, st, h, (unsigned)x_bytes,
+                       (unsigned)dy_bytes);
+    IIF_LAUNCH_CHECK();
+    if (splits > 1) return reduce_slabs(ws, ws_bytes, splits, slab, a.Cd, a.ldw, a.K, dw, st);
+    return IIF_OK;
+}
+
 template <typename T>
 int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_req, int64_t x_bytes, int64_t dy_bytes,
                  hipStream_t st) {
@@ -701,6 +862,14 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
                           a.ypitch == a.Cd && !(halo_env && atoi(halo_env) == 0);
         if (halo) {
             const int rc = launch_wgrad_halo(a, dw, ws, ws_bytes, splits_req, x_bytes, dy_bytes, st);
+            if (rc != -100) return rc;
+        }
+        static const char* stem_env = getenv("IIF_WGRAD_STEM");          // "0": keep the tap-per-tile kernel
+        const bool stem = dma_ok && a.groups == 1 && a.R == 4 && a.S == 4 && a.sshift == 0 && a.pad == 2 && a.Hs == a.Hd &&
+                          a.Ws == a.Wd && a.Cs == 16 && a.Cd == 64 && a.xpitch == 16 && a.ypitch == 64 &&
+                          !(stem_env && atoi(stem_env) == 0);
+        if (stem) {
+            const int rc = launch_wgrad_stem(a, dw, ws, ws_bytes, splits_req, x_bytes, dy_bytes, st);
             if (rc != -100) return rc;
         }
     }

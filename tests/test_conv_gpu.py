@@ -370,3 +370,25 @@ def test_dgrad_emits_upstream_bn_backward_sums(case):
     assert not torch.isnan(ps).any()
     assert (ps[0] - s1).abs().max().item() <= 2e-6 * max(1.0, s1.abs().max().item())
     assert (ps[1] - s2).abs().max().item() <= 2e-6 * max(1.0, s2.abs().max().item())
+
+
+@pytest.mark.parametrize("n,h,w", [(8, 32, 32), (3, 112, 112), (2, 17, 23), (5, 1, 3), (1, 40, 120)])
+def test_stem_s2d_weight_gradient_all_taps_per_block(n, h, w):
+    """4x4 / stride 1 / pad 2 (top-left) over the 16-channel space-to-depth image with output size = input size:
+    conv4x4_s2d_wgrad_kernel (W <= 112; (1, 40, 120) exceeds its ring and takes the tap-per-tile kernel) against an
+    fp64 evaluation of the same bf16 operands."""
+    import torch.nn.functional as F
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(n * 100 + w)
+    x = torch.randn(n, h, w, 16, generator=g).bfloat16()
+    dy = torch.randn(n, h, w, 64, generator=g).bfloat16()
+    ws = torch.empty(128 << 20, dtype=torch.uint8, device=DEV)
+    xp = F.pad(x.double().permute(0, 3, 1, 2), (2, 1, 2, 1))
+    wref = torch.zeros(64, 16, 4, 4, dtype=torch.float64, requires_grad=True)
+    out = F.conv2d(xp, wref)
+    assert tuple(out.shape[-2:]) == (h, w)
+    (gw,) = torch.autograd.grad(out, wref, dy.double().permute(0, 3, 1, 2))
+    ref = gw.permute(0, 2, 3, 1).reshape(64, 256)
+    for splits in (0, 1, 5):
+        dw = ops.conv_wgrad(x.to(DEV), dy.to(DEV), 4, 4, 1, 2, workspace=ws, splits=splits)
+        assert (dw.double().cpu() - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-6), (n, h, w, splits)
