@@ -2,19 +2,26 @@
 import sys, time
 sys.path.insert(0, '.')
 import torch
-from iif_amd import resnet_pytorch
+from iif_amd import resnet_cifar, resnet_pytorch
 from iif_amd.custom import IIFLoss
 import bench as B
 
+#   python scripts/graph_probe.py [model] [batch] [image] [classes]
 dev = torch.device('cuda', 0)
-C, bs = 1000, 256
+model = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+img = int(sys.argv[3]) if len(sys.argv) > 3 else 224
+C = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
 counts = B.lt_counts(C, 1280)
 torch.manual_seed(0)
-net = resnet_pytorch.resnet50(num_classes=C, use_norm="None", pretrained="None", device=dev, compute_dtype=torch.bfloat16)
+if hasattr(resnet_pytorch, model):
+    net = getattr(resnet_pytorch, model)(num_classes=C, use_norm="None", pretrained="None", device=dev, compute_dtype=torch.bfloat16)
+else:
+    net = getattr(resnet_cifar, model)(num_classes=C, use_norm="None", device=dev, compute_dtype=torch.bfloat16)
 net.train()
 crit = IIFLoss(B._Counts(counts), variant="raw", reduction="mean", device=dev)
 g = torch.Generator().manual_seed(1)
-x = torch.randn(bs, 3, 224, 224, generator=g).to(dev)
+x = torch.randn(bs, 3, img, img, generator=g).to(dev)
 y = torch.randint(0, C, (bs,), generator=g).to(dev)
 
 def step():
