@@ -155,11 +155,16 @@ class ConvTimer(object):
 
 def profiled_traffic():
     """HBM bytes per launch of the convolution family from the committed rocprofv3 PMC passes
-    (profiles/r1_*_pmc_hbm_traffic.csv: FETCH_SIZE x2 + WRITE_SIZE of the same bench command, collected in
+    (profiles/r<round>_*_pmc_hbm_traffic.csv, the newest round: FETCH_SIZE x2 + WRITE_SIZE of the same bench command, collected in
     separate --pmc runs; counters cannot be read from inside the timed run).  None if no summary is there."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")))
+    import re
+
+    def order(path):       # newest = highest round number, then the letter / text after it ("r10_a" > "r2_z")
+        m = re.match(r"r(\d+)_(.*)", os.path.basename(path))
+        return (int(m.group(1)), m.group(2)) if m else (-1, os.path.basename(path))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")), key=order)
     if not files:
         return None
     mb, launches, step_mb = 0.0, 0.0, 0.0

@@ -6,9 +6,22 @@
 // gradient written in the same pass (classification/custom.py:28-36 does the
 // same work as >= 6 elementwise/reduction launches plus autograd).
 // The kernels are HBM/latency-bound; there is no GEMM shape here, so no MFMA.
+//
+// Arithmetic: the softmax runs in base 2 on the hardware transcendentals (v_exp_f32 / v_log_f32, ~1 ulp):
+// z2 = x * (iif * log2 e), p = 2^(z2 - max z2) / sum, lse = ln 2 * (max z2 + log2 sum).  The lane keeps
+// iif * log2 e in registers next to iif, so the base change costs no instruction per element; a full-precision
+// expf() here made the kernel VALU-bound (1.9-3.0 TB/s at [65536, 1000]).  The one-hot term of the gradient is
+// patched by the one lane that owns the target column instead of being compared in every lane.
+// The scalar loss comes out of the SAME launch when the caller passes a ticket word: the last block to finish
+// (atomic ticket, agent-scope fence) sums the per-row losses in a fixed order — deterministic, no second launch.
 #include "common.h"
 
 namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+__device__ __forceinline__ float fast_exp2(float v) { return __builtin_amdgcn_exp2f(v); }
+__device__ __forceinline__ float fast_log2(float v) { return __builtin_amdgcn_logf(v); }
 
 // ---------------------------------------------------------------- element I/O
 template <typename T> struct Io;
@@ -47,7 +60,42 @@ struct CeArgs {
     float* loss_row;
     void* dx; int64_t lddx;
     int32_t* status;
+    float* loss_out;       // scalar loss = scale * sum(loss_row), written by the last block when ticket != nullptr
+    int32_t* ticket;       // zero on entry, zero again on exit
 };
+
+// Fixed-order sum of the per-row losses by the calling block (all of its threads).  Rows were written by other
+// blocks (other XCDs, other L2s): they are read with agent-scope atomic loads after the ticket's acquire.
+__device__ __forceinline__ void block_loss_sum(const CeArgs& a) {
+    __shared__ float sh[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < a.B; i += blockDim.x)
+        acc += __hip_atomic_load(a.loss_row + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *a.loss_out = sh[0] * a.scale;
+}
+
+// Called by every thread of every block once its rows are stored.  Returns after the last block has reduced.
+__device__ __forceinline__ void finish_with_ticket(const CeArgs& a) {
+    if (a.ticket == nullptr) return;                // block-uniform
+    __shared__ int last;
+    __syncthreads();                                // all loss_row stores of this block issued
+    if (threadIdx.x == 0) {
+        __threadfence();                            // release: rows visible at agent scope before the ticket
+        const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    block_loss_sum(a);
+    if (threadIdx.x == 0) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Per-row scalars shared by the register and the streaming variants.
 struct RowCoef {
@@ -82,14 +130,14 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
     const int wpb = blockDim.x >> 6;
     const int nwaves = gridDim.x * wpb;
     int row = blockIdx.x * wpb + (threadIdx.x >> 6);
-    if (row >= a.B) return;                       // wave-uniform
-    f32x4 t[NCH], xn[NCH];
+    f32x4 t[NCH], t2[NCH], xn[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c0 = (j * 64 + lane) * 4;
         t[j] = c0 < a.C ? *reinterpret_cast<const f32x4*>(a.tab + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        t2[j] = t[j] * kLog2e;
     }
-    {
+    if (row < a.B) {                              // wave-uniform
         const T* x0 = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -105,7 +153,7 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
         for (int j = 0; j < NCH; ++j) {
             const int c0 = (j * 64 + lane) * 4;
             if (c0 < a.C) {
-                z[j] = xn[j] * t[j];
+                z[j] = xn[j] * t2[j];
                 m = fmaxf(m, fmaxf(fmaxf(z[j].x, z[j].y), fmaxf(z[j].z, z[j].w)));
             } else {
                 z[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -123,8 +171,8 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            z[j].x = expf(z[j].x - m); z[j].y = expf(z[j].y - m);
-            z[j].z = expf(z[j].z - m); z[j].w = expf(z[j].w - m);
+            z[j].x = fast_exp2(z[j].x - m); z[j].y = fast_exp2(z[j].y - m);
+            z[j].z = fast_exp2(z[j].z - m); z[j].w = fast_exp2(z[j].w - m);
             s += (z[j].x + z[j].y) + (z[j].z + z[j].w);
         }
         s = wave_sum(s);
@@ -138,7 +186,7 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
             }
             continue;
         }
-        const float lse = m + logf(s);
+        const float lse = kLn2 * (m + fast_log2(s));
         const RowCoef rc = row_coef(a, row);
         float r = 0.f;
         if (rc.ta >= 0) r += rc.wa * (lse - Io<T>::load1(x + rc.ta) * a.tab[rc.ta]);
@@ -154,14 +202,18 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
             const int c0 = (j * 64 + lane) * 4;
             if (c0 < a.C) {
                 f32x4 p = z[j] * gs;
-                p.x -= (ia == c0 ? ga : 0.f) + (ib == c0 ? gb : 0.f);
-                p.y -= (ia == c0 + 1 ? ga : 0.f) + (ib == c0 + 1 ? gb : 0.f);
-                p.z -= (ia == c0 + 2 ? ga : 0.f) + (ib == c0 + 2 ? gb : 0.f);
-                p.w -= (ia == c0 + 3 ? ga : 0.f) + (ib == c0 + 3 ? gb : 0.f);
+                const unsigned da = (unsigned)(ia - c0), db = (unsigned)(ib - c0);
+                if ((da < 4u) | (db < 4u)) {      // only the lane(s) owning a target column
+                    p.x -= (da == 0u ? ga : 0.f) + (db == 0u ? gb : 0.f);
+                    p.y -= (da == 1u ? ga : 0.f) + (db == 1u ? gb : 0.f);
+                    p.z -= (da == 2u ? ga : 0.f) + (db == 2u ? gb : 0.f);
+                    p.w -= (da == 3u ? ga : 0.f) + (db == 3u ? gb : 0.f);
+                }
                 Io<T>::store4(dx + c0, p * t[j]);
             }
         }
     }
+    if (MODE == 0) finish_with_ticket(a);
 }
 
 // -------------------------------------------- streaming row (any C / alignment)
@@ -169,37 +221,40 @@ template <typename T, int MODE>
 __global__ void __launch_bounds__(256) row_stream_kernel(CeArgs a, float* sm_out, int64_t ld_sm) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= a.B) return;
-    const T* x = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
-    float m = -INFINITY;
-    for (int c = lane; c < a.C; c += 64) m = fmaxf(m, Io<T>::load1(x + c) * a.tab[c]);
-    m = wave_max(m);
-    float s = 0.f;
-    for (int c = lane; c < a.C; c += 64) s += expf(Io<T>::load1(x + c) * a.tab[c] - m);
-    s = wave_sum(s);
-    const float inv_s = 1.0f / s;
-    if (MODE == 1) {
-        float* o = sm_out + (int64_t)row * ld_sm;
-        for (int c = lane; c < a.C; c += 64) o[c] = expf(Io<T>::load1(x + c) * a.tab[c] - m) * inv_s;
-        return;
+    if (row < a.B) {                              // wave-uniform
+        const T* x = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
+        float m = -INFINITY;
+        for (int c = lane; c < a.C; c += 64) m = fmaxf(m, Io<T>::load1(x + c) * (a.tab[c] * kLog2e));
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < a.C; c += 64) s += fast_exp2(Io<T>::load1(x + c) * (a.tab[c] * kLog2e) - m);
+        s = wave_sum(s);
+        const float inv_s = 1.0f / s;
+        if (MODE == 1) {
+            float* o = sm_out + (int64_t)row * ld_sm;
+            for (int c = lane; c < a.C; c += 64) o[c] = fast_exp2(Io<T>::load1(x + c) * (a.tab[c] * kLog2e) - m) * inv_s;
+        } else {
+            const float lse = kLn2 * (m + fast_log2(s));
+            const RowCoef rc = row_coef(a, row);
+            float r = 0.f;
+            if (rc.ta >= 0) r += rc.wa * (lse - Io<T>::load1(x + rc.ta) * a.tab[rc.ta]);
+            if (rc.tb >= 0) r += rc.wb * (lse - Io<T>::load1(x + rc.tb) * a.tab[rc.tb]);
+            if (lane == 0) a.loss_row[row] = rc.rw * r;
+            if (a.dx != nullptr) {
+                T* dx = static_cast<T*>(a.dx) + (int64_t)row * a.lddx;
+                const float g = a.scale * rc.rw;
+                const float gs = g * (rc.wa + rc.wb) * inv_s, ga = g * rc.wa, gb = g * rc.wb;
+                for (int c = lane; c < a.C; c += 64) {
+                    const float tc = a.tab[c];
+                    float p = fast_exp2(Io<T>::load1(x + c) * (tc * kLog2e) - m) * gs;
+                    if (c == rc.ta) p -= ga;
+                    if (c == rc.tb) p -= gb;
+                    Io<T>::store1(dx + c, p * tc);
+                }
+            }
+        }
     }
-    const float lse = m + logf(s);
-    const RowCoef rc = row_coef(a, row);
-    float r = 0.f;
-    if (rc.ta >= 0) r += rc.wa * (lse - Io<T>::load1(x + rc.ta) * a.tab[rc.ta]);
-    if (rc.tb >= 0) r += rc.wb * (lse - Io<T>::load1(x + rc.tb) * a.tab[rc.tb]);
-    if (lane == 0) a.loss_row[row] = rc.rw * r;
-    if (a.dx == nullptr) return;
-    T* dx = static_cast<T*>(a.dx) + (int64_t)row * a.lddx;
-    const float g = a.scale * rc.rw;
-    const float gs = g * (rc.wa + rc.wb) * inv_s, ga = g * rc.wa, gb = g * rc.wb;
-    for (int c = lane; c < a.C; c += 64) {
-        const float tc = a.tab[c];
-        float p = expf(Io<T>::load1(x + c) * tc - m) * gs;
-        if (c == rc.ta) p -= ga;
-        if (c == rc.tb) p -= gb;
-        Io<T>::store1(dx + c, p * tc);
-    }
+    if (MODE == 0) finish_with_ticket(a);
 }
 
 // fixed-order sum of the per-row losses: one 256-thread block, deterministic
@@ -252,10 +307,10 @@ __global__ void __launch_bounds__(256) topk_hits_kernel(const T* x, int64_t ldx,
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) scale_by_scalar_kernel(T* x, int64_t n, const float* s) {
+__global__ void __launch_bounds__(256) scale_by_scalar_kernel(const T* x, int64_t n, const float* s, T* out) {
     const float f = *s;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        Io<T>::store1(x + i, Io<T>::load1(x + i) * f);
+        Io<T>::store1(out + i, Io<T>::load1(x + i) * f);
 }
 
 inline bool aligned(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -291,7 +346,7 @@ int iif_ce_fwd_bwd(const void* logits, int dtype, int64_t ld_logits, const float
                    const int64_t* targets_a, const int64_t* targets_b, float lam,
                    const float* row_weight, const float* class_weight, int64_t ignore_index,
                    float scale, int B, int C, float* loss_per_row, float* loss_out, void* dlogits,
-                   int64_t ld_dlogits, int32_t* d_status, void* stream) {
+                   int64_t ld_dlogits, int32_t* d_status, int32_t* d_ticket, void* stream) {
     if (B < 0 || C <= 0) return IIF_EINVAL;
     if (dtype != IIF_F32 && dtype != IIF_BF16) return IIF_EINVAL;
     hipStream_t st = as_stream(stream);
@@ -303,12 +358,14 @@ int iif_ce_fwd_bwd(const void* logits, int dtype, int64_t ld_logits, const float
     }
     if (!logits || !table || !targets_a || !loss_per_row) return IIF_EINVAL;
     if (ld_logits < C || (dlogits && ld_dlogits < C)) return IIF_EINVAL;
+    const bool one_launch = loss_out != nullptr && d_ticket != nullptr;
     CeArgs a{logits, ld_logits, table, targets_a, targets_b, lam, row_weight, class_weight,
-             ignore_index, scale, B, C, loss_per_row, dlogits, ld_dlogits, d_status};
+             ignore_index, scale, B, C, loss_per_row, dlogits, ld_dlogits, d_status,
+             one_launch ? loss_out : nullptr, one_launch ? d_ticket : nullptr};
     int rc = dtype == IIF_F32 ? launch_rows<float, 0>(a, nullptr, 0, st)
                               : launch_rows<unsigned short, 0>(a, nullptr, 0, st);
     if (rc != IIF_OK) return rc;
-    if (loss_out) {
+    if (loss_out && !one_launch) {
         hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, loss_per_row, B, scale, loss_out);
         IIF_LAUNCH_CHECK();
     }
@@ -369,17 +426,17 @@ int iif_topk_hits(const void* logits, int dtype, int64_t ld_logits, const float*
     return IIF_OK;
 }
 
-int iif_scale_by_device_scalar(void* x, int dtype, int64_t n, const float* d_scalar, void* stream) {
+int iif_scale_by_device_scalar(const void* x, int dtype, int64_t n, const float* d_scalar, void* out, void* stream) {
     if (n < 0 || !d_scalar) return IIF_EINVAL;
     if (n == 0) return IIF_OK;
-    if (!x) return IIF_EINVAL;
+    if (!x || !out) return IIF_EINVAL;
     const int blocks = (int)(cdiv64(n, 256) < 2048 ? cdiv64(n, 256) : 2048);
     if (dtype == IIF_F32)
         hipLaunchKernelGGL(scale_by_scalar_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream),
-                           (float*)x, n, d_scalar);
+                           (const float*)x, n, d_scalar, (float*)out);
     else if (dtype == IIF_BF16)
         hipLaunchKernelGGL(scale_by_scalar_kernel<unsigned short>, dim3(blocks), dim3(256), 0, as_stream(stream),
-                           (unsigned short*)x, n, d_scalar);
+                           (const unsigned short*)x, n, d_scalar, (unsigned short*)out);
     else
         return IIF_EINVAL;
     IIF_LAUNCH_CHECK();

@@ -44,7 +44,7 @@ def build_tables(cls_num_list, iif_norm=0):
     return tabs
 
 
-def _launch_ce(pred, table, ta, tb, lam, row_weight, class_weight, ignore_index, scale, want_grad):
+def _launch_ce(pred, table, ta, tb, lam, row_weight, class_weight, ignore_index, scale, want_grad, keep_rows=False):
     """One launch of the fused kernel.  Returns (loss, rows, dlogits-or-None)."""
     _lib.require_gpu(pred, table, ta, tb, row_weight, class_weight)
     if pred.dim() != 2:
@@ -55,8 +55,8 @@ def _launch_ce(pred, table, ta, tb, lam, row_weight, class_weight, ignore_index,
     if table.numel() != C:
         raise ValueError("IIF table has %d classes, logits have %d" % (table.numel(), C))
     dlogits = torch.empty((B, C), dtype=pred.dtype, device=pred.device) if want_grad else None
-    rows = torch.empty(B, dtype=torch.float32, device=pred.device)
-    loss = torch.zeros((), dtype=torch.float32, device=pred.device)
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)          # written by the kernel (0 for B == 0)
+    rows, ticket, status = _workspace(pred.device, B, keep_rows)
     ta = ta.to(torch.int64).contiguous()
     tb = None if tb is None else tb.to(torch.int64).contiguous()
     rw = None if row_weight is None else row_weight.to(torch.float32).contiguous()
@@ -65,9 +65,41 @@ def _launch_ce(pred, table, ta, tb, lam, row_weight, class_weight, ignore_index,
     rc = _lib.lib().iif_ce_fwd_bwd(
         _lib.ptr(pred), _lib.dtype_code(pred), pred.stride(0) if B else C, _lib.ptr(tab), _lib.ptr(ta),
         _lib.ptr(tb), float(lam), _lib.ptr(rw), _lib.ptr(cw), int(ignore_index), float(scale), B, C,
-        _lib.ptr(rows), _lib.ptr(loss), _lib.ptr(dlogits), C, 0, _lib.stream_ptr())
+        _lib.ptr(rows), _lib.ptr(loss), _lib.ptr(dlogits), C, _lib.ptr(status), _lib.ptr(ticket), _lib.stream_ptr())
     _lib.check(rc, "iif_ce_fwd_bwd")
     return loss, rows, dlogits
+
+
+_WS = {}
+
+
+def _workspace(device, B, own_rows):
+    """Per (device, stream) scratch of the fused launch: the per-row loss vector (grown on demand; a fresh tensor
+    when the caller hands the rows out, reduction='none'), the ticket word of the in-kernel loss reduce (zero
+    between launches) and the sticky label-status word (see ``check_label_status``)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = _WS[key] = {"rows": torch.empty(0, dtype=torch.float32, device=device),
+                         "ticket": torch.zeros(1, dtype=torch.int32, device=device),
+                         "status": torch.zeros(1, dtype=torch.int32, device=device)}
+    if own_rows:
+        rows = torch.empty(B, dtype=torch.float32, device=device)
+    else:
+        if ws["rows"].numel() < B:
+            ws["rows"] = torch.empty(max(B, 2 * ws["rows"].numel()), dtype=torch.float32, device=device)
+        rows = ws["rows"]
+    return rows, ws["ticket"], ws["status"]
+
+
+def check_label_status():
+    """Raise if any target seen by the fused loss since the last check was outside [0, C) and not the ignore
+    index (the reference asserts inside nll_loss; here such rows contribute zero and set a device flag).  One
+    host sync per call: use it where the loop synchronises anyway (classification/train.py:87-92)."""
+    for ws in _WS.values():
+        if int(ws["status"].item()) != 0:
+            ws["status"].zero_()
+            raise IndexError("IIF loss: a target label is outside [0, C) and is not the ignore index")
 
 
 class _FusedIIFCrossEntropy(torch.autograd.Function):
@@ -88,10 +120,11 @@ class _FusedIIFCrossEntropy(torch.autograd.Function):
         if dlogits is None:
             return (None,) * 9
         g = g_loss.to(torch.float32).contiguous()
+        out = torch.empty_like(dlogits)           # the saved gradient stays intact: backward may run twice
         rc = _lib.lib().iif_scale_by_device_scalar(_lib.ptr(dlogits), _lib.dtype_code(dlogits), dlogits.numel(),
-                                                   _lib.ptr(g), _lib.stream_ptr())
+                                                   _lib.ptr(g), _lib.ptr(out), _lib.stream_ptr())
         _lib.check(rc, "iif_scale_by_device_scalar")
-        return (dlogits,) + (None,) * 8
+        return (out,) + (None,) * 8
 
 
 def fused_iif_cross_entropy(pred, table, targets, targets_b=None, lam=1.0, row_weight=None, class_weight=None,
@@ -125,7 +158,7 @@ class _FusedIIFRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, table, ta, tb, lam, row_weight, class_weight, ignore_index):
         _, rows, dlogits = _launch_ce(pred, table, ta, tb, lam, row_weight, class_weight, ignore_index, 1.0,
-                                      ctx.needs_input_grad[0])
+                                      ctx.needs_input_grad[0], keep_rows=True)
         ctx.save_for_backward(dlogits)
         return rows
 
@@ -160,6 +193,17 @@ class IIFLoss(nn.Module):
         self.weight = weight
         tabs = build_tables(dataset.get_cls_num_list(), iif_norm)
         self.iif = {k: v.to(device, non_blocking=True) for k, v in tabs.items()}
+        # True only for the plain-CE criterion built by initialisers.get_criterion: 'mean' then divides by the sum
+        # of the targets' class weights (nn.CrossEntropyLoss semantics) instead of the batch size
+        self.weighted_mean = False
+
+    def mean_denominator(self, targets):
+        """Device scalar sum_i weight[t_i] (ignored / out-of-range targets count 0), or None for the plain 1/B."""
+        if not (self.weighted_mean and self.weight is not None and self.reduction == "mean"):
+            return None
+        w = self.weight.to(device=targets.device, dtype=torch.float32)
+        ok = (targets >= 0) & (targets < w.numel())
+        return (w[targets.clamp(0, w.numel() - 1)] * ok).sum()
 
     def _table(self, like):
         t = self.iif[self.variant]
@@ -176,6 +220,9 @@ class IIFLoss(nn.Module):
             w = self.weight
             if w is not None and w.device != pred.device:
                 w = w.to(pred.device)
+            den = self.mean_denominator(targets)
+            if den is not None:            # weighted mean: sum of the weighted rows over the sum of the weights
+                return fused_iif_cross_entropy(pred, table, targets, class_weight=w, reduction="sum") / den
             return fused_iif_cross_entropy(pred, table, targets, class_weight=w, reduction=red)
         return scale_logits(pred, table)
 
@@ -186,6 +233,8 @@ class IIFLoss(nn.Module):
         w = self.weight
         if w is not None and w.device != pred.device:
             w = w.to(pred.device)
+        if self.mean_denominator(y_a) is not None:          # two different denominators: two passes, as the reference
+            return lam * self(pred, y_a) + (1 - lam) * self(pred, y_b)
         return fused_iif_cross_entropy(pred, self._table(pred), y_a, targets_b=y_b, lam=lam, class_weight=w,
                                        reduction=red)
 

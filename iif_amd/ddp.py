@@ -20,16 +20,38 @@ import torch.distributed as dist
 
 
 class ArenaReducer(object):
-    def __init__(self, grad_arena, boundaries, bucket_bytes=32 << 20, process_group=None, tail_bytes=2 << 20):
+    """``mode``:
+      * ``"allreduce"`` (default): one ``all_reduce(SUM)`` per bucket;
+      * ``"rs_ag"``: ``reduce_scatter_tensor`` into this rank's 1/world shard of the bucket followed by
+        ``all_gather_into_tensor`` back into the arena (on the fully connected xGMI node the
+        7 peer shards of either phase travel over the 7 links concurrently instead of around one ring).  Bucket
+        bounds are multiples of 16 elements (arena tensors are 64-byte aligned), so every bucket divides by any
+        world size up to 16; the sum arrives in a different association than the ring's, fp32-rounding apart.
+    ``bucket_dtype=torch.bfloat16`` halves the bytes on the links by reducing a bf16 copy of each bucket (fp32
+    accumulation is lost: it is refused until ``probe_bf16`` has measured, on real gradients, that the averaged
+    gradient stays within a stated tolerance of the fp32 reduction)."""
+
+    def __init__(self, grad_arena, boundaries, bucket_bytes=32 << 20, process_group=None, tail_bytes=2 << 20,
+                 mode="allreduce", bucket_dtype=torch.float32):
         """grad_arena: flat fp32 tensor; boundaries: sorted arena offsets where a bucket
         may start (tensor starts, in elements).  The LAST bucket (the arena's head: stem and
         first blocks) can only start when backward has finished, so its reduction is exposed:
         it is kept below ``tail_bytes`` by one extra cut."""
+        if mode not in ("allreduce", "rs_ag"):
+            raise ValueError("unknown reducer mode %r" % (mode,))
         self.arena = grad_arena
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.mode = mode
+        self.bucket_dtype = torch.float32
+        self._bf16_cleared = False
         n = grad_arena.numel()
         cuts = sorted(set(int(b) for b in boundaries if 0 < int(b) < n))
+        if mode == "rs_ag":
+            if n % max(self.world, 1):
+                raise ValueError("rs_ag needs the arena length (%d) to divide by the world size (%d)" % (n, self.world))
+            cuts = [c for c in cuts if c % self.world == 0]
         # walk from the END of the arena (first gradients to complete) towards the start
         target = max(bucket_bytes // 4, 1)
         self.buckets = []          # (lo, hi) in completion order
@@ -49,8 +71,51 @@ class ArenaReducer(object):
         self.comm_stream = torch.cuda.Stream(device=grad_arena.device) if self.use_streams else None
         self._next = 0
         self._works = []
+        self._staging = {}         # bucket -> bf16 staging / shard buffers
         self.force = False         # exercise the bucket/stream machinery even with a single rank (tests)
         self.extra_streams = []    # other producer streams of gradients (the engine's wgrad stream)
+        self.launched = 0          # collectives enqueued since construction (bench / tests read it)
+        self.steps = 0
+        if bucket_dtype != torch.float32:
+            self.set_bucket_dtype(bucket_dtype)
+
+    # ---- configuration --------------------------------------------------------
+    def probe_bf16(self, tolerance=4e-3):
+        """Measure, on the gradients currently in the arena (call after one backward, before the reduction),
+        what reducing bf16 copies would do to the averaged gradient: per bucket, the relative L2 distance between
+        the bf16-bucket average and the fp32 average.  Clears ``set_bucket_dtype(bfloat16)`` when every bucket stays
+        within ``tolerance`` (bf16 has 8 mantissa bits: 2^-8 = 3.9e-3 is one rounding); returns the worst value.
+        Leaves the arena untouched."""
+        worst = 0.0
+        for lo, hi in self.buckets:
+            ref = self.arena[lo:hi].clone()
+            low = ref.to(torch.bfloat16)
+            if self.world > 1:
+                dist.all_reduce(ref, group=self.group)
+                dist.all_reduce(low, group=self.group)
+            err = (low.float() - ref).norm() / ref.norm().clamp_min(1e-30)
+            worst = max(worst, float(err))
+        self._bf16_cleared = worst <= tolerance
+        return worst
+
+    def set_bucket_dtype(self, dtype):
+        if dtype == torch.float32:
+            self.bucket_dtype = dtype
+            return
+        if dtype != torch.bfloat16:
+            raise ValueError("bucket dtype must be float32 or bfloat16")
+        if not self._bf16_cleared:
+            raise RuntimeError("bf16 gradient buckets are refused until probe_bf16() has shown that the averaged gradient "
+                               "stays within tolerance of the fp32 reduction on this model's gradients")
+        self.bucket_dtype = dtype
+
+    def describe(self):
+        """What the collective library is asked to do per step (goes into the bench JSON line)."""
+        esz = 2 if self.bucket_dtype == torch.bfloat16 else 4
+        return {"world": self.world, "mode": self.mode, "bucket_dtype": "bf16" if esz == 2 else "f32",
+                "buckets": len(self.buckets), "bucket_bytes": [int((hi - lo) * esz) for lo, hi in self.buckets],
+                "payload_bytes_per_step": int(self.arena.numel() * esz), "tail_bucket_bytes": int((self.buckets[-1][1] - self.buckets[-1][0]) * esz),
+                "collectives_launched": self.launched, "steps_reduced": self.steps}
 
     # ---- called by the engine -------------------------------------------------
     def begin(self):
@@ -65,43 +130,80 @@ class ArenaReducer(object):
             self._launch(self.buckets[self._next])
             self._next += 1
 
+    def _join(self):
+        if self.use_streams:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        else:
+            for w in self._works:
+                w()
+        self._works = []
+        self.steps += 1
+
     def finish(self):
         """Launch whatever is left and make the compute stream wait for every reduction."""
         if self.world == 1 and not self.force:
             return
         self.gradients_ready_from(0)
-        if self.use_streams:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
-        else:
-            for w in self._works:
-                w.wait()
-        self._works = []
+        self._join()
 
     def finish_tail(self, offset):
         """Frozen-backbone step: only arena[offset:] carries gradients; reduce exactly that slice."""
         if self.world == 1 and not self.force:
             return
-        self._launch((int(offset), self.arena.numel()))
+        offset = int(offset)
+        if self.mode == "rs_ag":
+            offset -= offset % self.world            # shard-divisible slice (a few frozen, zero gradients ride along)
+        self._launch((offset, self.arena.numel()))
         self._next = len(self.buckets)
-        if self.use_streams:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
-        else:
-            for w in self._works:
-                w.wait()
-        self._works = []
+        self._join()
 
     # ---- internals ------------------------------------------------------------
-    def _launch(self, bucket):
+    def _collective(self, bucket, sync):
+        """Enqueue the reduction of one bucket; returns a completion callable for the host-waited (CPU) path."""
         lo, hi = bucket
         view = self.arena[lo:hi]
+        low = self.bucket_dtype == torch.bfloat16
+        buf = view
+        if low:
+            buf = self._staging.get(("low", bucket))
+            if buf is None:
+                buf = self._staging[("low", bucket)] = torch.empty(hi - lo, dtype=torch.bfloat16, device=view.device)
+            buf.copy_(view)
+        waits = []
+        if self.mode == "rs_ag" and self.world > 1:
+            per = (hi - lo) // self.world
+            shard = self._staging.get(("shard", bucket, buf.dtype))
+            if shard is None:
+                shard = self._staging[("shard", bucket, buf.dtype)] = torch.empty(per, dtype=buf.dtype, device=view.device)
+            w1 = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=not sync)
+            if not sync:
+                w1.wait()                             # gloo: the gather reads what the scatter wrote
+            w2 = dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=not sync)
+            waits = [] if sync else [w2]
+            self.launched += 2
+        else:
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=not sync)
+            waits = [] if sync else [w]
+            self.launched += 1
+
+        def done():
+            for w in waits:
+                w.wait()
+            if low:
+                view.copy_(buf)
+        if sync and low:
+            view.copy_(buf)                           # same stream, after the collective
+        return done
+
+    def _launch(self, bucket):
         if self.use_streams:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             for s in self.extra_streams:
                 self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                self._collective(bucket, sync=True)
         else:
-            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._works.append(self._collective(bucket, sync=False))
 
     @property
     def grad_scale(self):
@@ -114,5 +216,15 @@ def broadcast_parameters(net, src=0, process_group=None):
     if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
         return
     dist.broadcast(net.param_arena, src, group=process_group)
+    sync_buffers(net, src, process_group)
+
+
+def sync_buffers(net, src=0, process_group=None):
+    """BN running statistics and counters of rank ``src`` on every rank.  DistributedDataParallel broadcasts the
+    buffers before every forward (``broadcast_buffers=True``, classification/train.py:232), so the reference
+    evaluates and checkpoints with rank 0's statistics; training-mode forwards never read them, so broadcasting
+    right before ``evaluate`` / a checkpoint is equivalent and costs nothing per step."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return
     dist.broadcast(net._rstat, src, group=process_group)
     dist.broadcast(net._nbt, src, group=process_group)

@@ -97,6 +97,9 @@ def synthetic_lt(name, seed=0, train=True, scale=1.0):
 # (classification/imbalanced_dataset.py:100-174); decoding an image needs PIL, which the build image lacks:
 # pass ``loader`` (path -> image) or install PIL.
 def _default_loader(path):
+    if path.endswith(".npy"):                    # pre-decoded HWC uint8 arrays need no image library
+        import numpy as np
+        return np.load(path)
     try:
         from PIL import Image
     except Exception as e:                       # pragma: no cover - depends on the deployment image
@@ -166,3 +169,73 @@ class LT_Dataset_Eval(Dataset):
         if self.transform is not None:
             sample = self.transform(sample)
         return sample, self.targets[index]
+
+
+# ---------------------------------------------------------------------------------------------------
+# Host-side tensor transforms for the list datasets (torchvision is not in this image).  Same geometry and
+# statistics as the reference's pipelines (imbalanced_dataset.py:189-233: RandomResizedCrop(224) + horizontal
+# flip for training, Resize(256) + CenterCrop(224) for evaluation, per-dataset mean / std); colour jitter and
+# the auto-augment policies are CPU augmentation outside the measured path (SURVEY 2a presets.py) and not rebuilt.
+LT_LISTS = {   # initialisers.py:83-100: (classes, train list, eval list) relative to the reference's working directory
+    "imagenet_lt": (1000, "../../../datasets/ImageNet-LT/ImageNet_LT_train.txt", "../../../datasets/ImageNet-LT/ImageNet_LT_test.txt"),
+    "inat18": (8142, "../../../datasets/train_val2018/iNaturalist18_train.txt", "../../../datasets/train_val2018/iNaturalist18_val.txt"),
+    "places_lt": (365, "../../../datasets/places365_standard/Places_LT_train.txt", "../../../datasets/places365_standard/Places_LT_test.txt"),
+}
+
+
+class TensorTransform(object):
+    def __init__(self, dset_name, train, size=224, seed=0):
+        inat = dset_name == "inat18"
+        self.mean = torch.tensor([0.466, 0.471, 0.380] if inat else [0.485, 0.456, 0.406]).view(3, 1, 1)
+        self.std = torch.tensor([0.195, 0.194, 0.192] if inat else [0.229, 0.224, 0.225]).view(3, 1, 1)
+        self.train, self.size = train, size
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def _to_chw(self, img):
+        import numpy as np
+        a = np.asarray(img)
+        if a.ndim == 2:
+            a = np.stack([a] * 3, -1)
+        t = torch.from_numpy(np.ascontiguousarray(a[..., :3])).permute(2, 0, 1).float()
+        return t / 255.0 if a.dtype == np.uint8 else t
+
+    def _resize(self, t, h, w):
+        return torch.nn.functional.interpolate(t[None], size=(h, w), mode="bilinear", align_corners=False, antialias=True)[0]
+
+    def __call__(self, img):
+        import math
+        t = self._to_chw(img)
+        _, h, w = t.shape
+        s = self.size
+        if self.train:                                   # RandomResizedCrop(scale 0.08-1, ratio 3/4-4/3), 10 tries, then flip
+            r = lambda: torch.rand((), generator=self.gen).item()      # noqa: E731
+            for _ in range(10):
+                area = h * w * (0.08 + 0.92 * r())
+                logr = math.log(3 / 4) + (math.log(4 / 3) - math.log(3 / 4)) * r()
+                cw, ch = int(round(math.sqrt(area * math.exp(logr)))), int(round(math.sqrt(area / math.exp(logr))))
+                if 0 < cw <= w and 0 < ch <= h:
+                    top, left = int(r() * (h - ch + 1)), int(r() * (w - cw + 1))
+                    break
+            else:
+                ch = cw = min(h, w); top, left = (h - ch) // 2, (w - cw) // 2
+            t = self._resize(t[:, top:top + ch, left:left + cw], s, s)
+            if r() < 0.5:
+                t = t.flip(-1)
+        else:                                            # Resize(256 * s / 224) on the short side + CenterCrop(s)
+            short = int(round(s * 256 / 224))
+            nh, nw = (short, max(int(round(w * short / h)), short)) if h <= w else (max(int(round(h * short / w)), short), short)
+            t = self._resize(t, nh, nw)
+            top, left = (nh - s) // 2, (nw - s) // 2
+            t = t[:, top:top + s, left:left + s]
+        return (t - self.mean) / self.std
+
+
+def get_dataset_lt(args, num_classes, train_txt, eval_txt, loader=None):
+    """imbalanced_dataset.py:177-259 without its samplers (built by the caller): the two list datasets, the
+    evaluation one remapped with the training class map."""
+    size = getattr(args, "image_size", 224)
+    train = LT_Dataset(args.data_path, train_txt, num_classes, transform=TensorTransform(args.dset_name, True, size, args.rand_number),
+                       loader=loader)
+    ev = LT_Dataset_Eval(args.data_path, eval_txt, train.class_map, num_classes, transform=TensorTransform(args.dset_name, False, size),
+                         loader=loader)
+    return train, ev

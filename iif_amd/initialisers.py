@@ -35,21 +35,33 @@ def get_criterion(args, dataset, model, num_classes):
         ones = torch.ones(1, num_classes, device=device)
         crit.iif = {k: ones for k in crit.iif}
         crit.is_plain_ce = True
+        # nn.CrossEntropyLoss(weight=w, reduction='mean') divides by the sum of the targets' weights
+        # (initialisers.py:43-46), unlike IIFLoss whose .mean() divides by the batch size (custom.py:32-33)
+        crit.weighted_mean = weight is not None and args.reduction == "mean"
         return crit
     raise NotImplementedError("criterion %r is outside the IIF hot path (SURVEY §2a: FocalLoss hard-codes CUDA tensors "
                               "and is used by no config)" % (args.classif,))
 
 
 def get_data(args):
-    """Synthetic stand-in for initialisers.py:51-112: returns
-    (dataset, num_classes, train_loader, test_loader, train_sampler)."""
+    """initialisers.py:51-112: returns (dataset, num_classes, train_loader, test_loader, train_sampler).
+    With ``--data-path`` the long-tailed sets are read from the reference's list files (``--train-txt`` /
+    ``--eval-txt`` default to the paths hard-coded at initialisers.py:83-100) through ``LT_Dataset`` /
+    ``LT_Dataset_Eval``; without it they are synthetic sets of the same shape (no dataset ships with the image)."""
     name = args.dset_name.lower()
-    if name.startswith("cifar"):
+    key = {"imagenet": "imagenet_lt", "imagenet_lt": "imagenet_lt", "places_lt": "places_lt", "inat18": "inat18"}.get(name)
+    if key is not None and getattr(args, "data_path", ""):
+        C, train_txt, eval_txt = imbalanced_dataset.LT_LISTS[key]
+        ds, ds_test = imbalanced_dataset.get_dataset_lt(args, C, getattr(args, "train_txt", None) or train_txt,
+                                                        getattr(args, "eval_txt", None) or eval_txt)
+        ds.num_classes = len(ds.cls_num_list)
+    elif name.startswith("cifar"):
         C = 100 if "100" in name else 10
         ds = imbalanced_dataset.synthetic_cifar_lt(C, args.imb_type, args.imb_factor, args.rand_number, True)
         ds_test = imbalanced_dataset.synthetic_cifar_lt(C, args.imb_type, args.imb_factor, args.rand_number, False)
     else:
-        key = {"imagenet": "imagenet_lt", "imagenet_lt": "imagenet_lt", "places_lt": "places_lt", "inat18": "inat18"}[name]
+        if key is None:
+            raise KeyError("unknown dataset %r" % (args.dset_name,))
         ds = imbalanced_dataset.synthetic_lt(key, args.rand_number, True, getattr(args, "synthetic_scale", 1.0))
         ds_test = imbalanced_dataset.synthetic_lt(key, args.rand_number, False)
     sampler = test_sampler = None
@@ -63,8 +75,9 @@ def get_data(args):
     elif getattr(args, "distributed", False):
         sampler = torch.utils.data.distributed.DistributedSampler(ds)
         test_sampler = torch.utils.data.distributed.DistributedSampler(ds_test, shuffle=False)
+    pin = torch.cuda.is_available()
     loader = torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
-                                         num_workers=args.workers, pin_memory=True, drop_last=True)
+                                         num_workers=args.workers, pin_memory=pin, drop_last=True)
     loader_test = torch.utils.data.DataLoader(ds_test, batch_size=args.batch_size, shuffle=False, sampler=test_sampler,
-                                              num_workers=args.workers, pin_memory=True)
+                                              num_workers=args.workers, pin_memory=pin)
     return ds, ds.num_classes, loader, loader_test, sampler

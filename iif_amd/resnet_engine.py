@@ -409,28 +409,42 @@ class NativeResNet(nn.Module):
 
     # --------------------------------------------------------------- forward
     def forward(self, x):
+        """Drop-in ``model(x)``: returns its OWN [N, num_classes] fp32 tensor (the plan's logits buffer is reused by
+        the next same-shaped call, so the module surface never hands out a view of it)."""
         _lib.require_gpu(x)
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected an NCHW image batch [N,3,H,W], got %s" % (tuple(x.shape),))
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list)
         if need_grad:
+            if not self.training:
+                raise RuntimeError("NativeResNet: an eval-mode forward under autograd is not supported (the native backward "
+                                   "is the training-mode one: batch statistics, transposed weights); wrap evaluation in "
+                                   "torch.no_grad() as classification/train.py:97 does, or call model.train()")
             return _NetFunction.apply(self, x, *self._param_list)
-        return self.run_forward(x, self.training)
+        return self.run_forward(x, self.training).clone()
 
     def run_forward(self, x, training):
-        """Native forward.  Returns fp32 logits [N, num_classes] (a view of the plan's buffer)."""
+        """Native forward.  Returns fp32 logits [N, num_classes] — a VIEW of the plan's buffer, valid until the next
+        forward of the same shape (``loss_and_backward`` consumes it in place; ``forward`` clones it)."""
         plan = self._plan(x.shape[0], x.shape[2], x.shape[3])
         plan.forward(x, training)
+        plan.generation += 1
         self._saved = plan if training else None
         return plan.logits[:, :self.num_classes]
 
-    def run_backward(self, dlogits=None, reducer=None):
+    def run_backward(self, dlogits=None, reducer=None, generation=None):
         """Native backward from d(loss)/d(logits); fills the gradient arena.
         ``dlogits`` None means the plan's own dlogits buffer was already filled
-        (fused loss path)."""
+        (fused loss path).  ``generation``: the plan generation the caller's forward produced; a mismatch means the
+        saved activations belong to a later forward (two forwards before one backward) and raises instead of
+        back-propagating the wrong batch."""
         plan = self._saved
         if plan is None:
             raise RuntimeError("run_backward() without a preceding training-mode forward")
+        if generation is not None and generation != (id(plan), plan.generation):
+            raise RuntimeError("NativeResNet keeps the activations of ONE forward: backward() was called for a forward whose "
+                               "activations a later forward has overwritten (gradient accumulation must run "
+                               "forward -> backward per micro-batch)")
         if dlogits is not None:
             plan.dlogits[:, :self.num_classes].copy_(dlogits)
         plan.backward(reducer)
@@ -505,11 +519,11 @@ class NativeResNet(nn.Module):
         self._head_only = True
         return self
 
-    def make_reducer(self, bucket_bytes=32 << 20, process_group=None):
+    def make_reducer(self, bucket_bytes=32 << 20, process_group=None, mode="allreduce"):
         """Bucketed, backward-overlapped all-reduce of the gradient arena (see iif_amd.ddp)."""
         from .ddp import ArenaReducer
         bounds = [o for (o, _, _) in self._offsets.values()]
-        return ArenaReducer(self._grad_arena, bounds, bucket_bytes, process_group)
+        return ArenaReducer(self._grad_arena, bounds, bucket_bytes, process_group, mode=mode)
 
     def block_offsets(self):
         """Arena offset of the first parameter of the stem, of every block (forward order) and of the head."""
@@ -535,10 +549,30 @@ class NativeResNet(nn.Module):
         rc = _lib.lib().iif_ce_fwd_bwd(
             _lib.ptr(plan.logits), _lib.IIF_F32, plan.logits.stride(0), _lib.ptr(table), _lib.ptr(targets),
             _lib.ptr(targets_b), float(lam), 0, _lib.ptr(cw), -100, scale, B, C, _lib.ptr(plan.loss_rows),
-            _lib.ptr(plan.loss), _lib.ptr(plan.dlogits), plan.dlogits.stride(0), 0, _lib.stream_ptr())
+            _lib.ptr(plan.loss), _lib.ptr(plan.dlogits), plan.dlogits.stride(0), _lib.ptr(plan.label_status),
+            _lib.ptr(plan.loss_ticket), _lib.stream_ptr())
         _lib.check(rc, "iif_ce_fwd_bwd")
+        den = criterion.mean_denominator(targets)
+        if den is not None:
+            if targets_b is not None:
+                raise NotImplementedError("mixup with the class-weighted plain-CE 'mean' criterion (two different denominators)")
+            # plain CE with class weights, 'mean': the launch above used 1/B; rescale loss and dlogits by B / sum w[t]
+            plan.loss_rescale.copy_((float(B) / den).reshape(1))
+            plan.loss.mul_(plan.loss_rescale[0])
+            _lib.check(_lib.lib().iif_scale_by_device_scalar(_lib.ptr(plan.dlogits), _lib.IIF_F32, plan.dlogits.numel(),
+                                                             _lib.ptr(plan.loss_rescale), _lib.ptr(plan.dlogits),
+                                                             _lib.stream_ptr()), "iif_scale_by_device_scalar")
         plan.backward(reducer)
         return plan.loss, logits
+
+    def check_labels(self):
+        """Raise if any target handed to ``loss_and_backward`` since the last check was outside [0, num_classes)
+        (the reference asserts on the device in nll_loss).  One host sync: call it where the training loop syncs
+        anyway (classification/train.py:87-92, the metric ``.item()`` calls)."""
+        for plan in self._plans.values():
+            if int(plan.label_status.item()) != 0:
+                plan.label_status.zero_()
+                raise IndexError("IIF loss: a target label is outside [0, %d) and is not the ignore index" % self.num_classes)
 
     @property
     def grad_arena(self):
@@ -556,15 +590,14 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, *params):
         ctx.net = net
-        out = net.run_forward(x, net.training)
-        if not net.training:       # eval-mode forward under grad: statistics are frozen, still differentiable
-            net._saved = net._plan(x.shape[0], x.shape[2], x.shape[3])
+        out = net.run_forward(x, True).clone()
+        ctx.generation = (id(net._saved), net._saved.generation)
         return out
 
     @staticmethod
     def backward(ctx, g):
         net = ctx.net
-        net.run_backward(g)
+        net.run_backward(g, generation=ctx.generation)
         return (None, None) + tuple(net._grad_views)
 
 
@@ -579,6 +612,7 @@ class _Plan(object):
     def __init__(self, net, n, h, w):
         self.net = net
         self.n, self.h, self.w = n, h, w
+        self.generation = 0      # bumped by every forward; autograd nodes remember theirs
         self.dt = net.compute_dtype
         self.dev = net._device
         dt, dev = self.dt, self.dev
@@ -649,6 +683,9 @@ class _Plan(object):
         self.dlogits = torch.zeros((n, head.out_padded), dtype=torch.float32, device=dev)
         self.dlogits_t = torch.zeros((n, head.out_padded), dtype=dt, device=dev)
         self.loss_rows = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.loss_rescale = torch.ones(1, dtype=torch.float32, device=dev)
+        self.loss_ticket = torch.zeros(1, dtype=torch.int32, device=dev)      # single-launch loss reduce (self-resetting)
+        self.label_status = torch.zeros(1, dtype=torch.int32, device=dev)     # sticky: 1 once a label was out of range
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         op, D = head.out_padded, head.in_features
         self.head_kind = ("linear" if isinstance(head, LinearParam) else
@@ -884,7 +921,7 @@ class _Plan(object):
                 torch.mul(head._s1d[:1], head._s1d[:1], out=self.head_s2)
                 _lib.check(_lib.lib().iif_scale_by_device_scalar(_lib.ptr(self.head_ex), _lib.dtype_code(self.head_ex),
                                                                  self.head_ex.numel(), _lib.ptr(self.head_s2),
-                                                                 _lib.stream_ptr()), "iif_scale_by_device_scalar")
+                                                                 _lib.ptr(self.head_ex), _lib.stream_ptr()), "iif_scale_by_device_scalar")
             else:
                 ops.rowmap_forward(self.pooled, 0, float(head.scale), self.head_ex, self.head_xnorm)
             feat = self.head_ex
@@ -1087,7 +1124,7 @@ class _Plan(object):
                 ops.dot_window_f32(self.dlogits, self.logits, n, head.out_features, 2.0, head._gs1d, alpha_div=head._s1d)
                 _lib.check(_lib.lib().iif_scale_by_device_scalar(_lib.ptr(self.head_dex), _lib.dtype_code(self.head_dex),
                                                                  self.head_dex.numel(), _lib.ptr(self.head_s2),
-                                                                 _lib.stream_ptr()), "iif_scale_by_device_scalar")
+                                                                 _lib.ptr(self.head_dex), _lib.stream_ptr()), "iif_scale_by_device_scalar")
                 ops.rowmap_backward(self.pooled, self.head_xnorm, self.head_dex, 0, 1.0, dp2)
             else:
                 ops.rowmap_backward(self.pooled, self.head_xnorm, self.head_dex, 0, float(head.scale), dp2)

@@ -48,7 +48,7 @@ def _load_mismatched(model, path):
     """Backbone weights from a checkpoint whose classifier has a different width
     (resnet_pytorch.py:383-397 swaps a 1000-way fc in and out; here the classifier
     entries are simply skipped)."""
-    sd = torch.load(path, map_location="cpu")
+    sd = torch.load(path, map_location="cpu", weights_only=False)    # the reference's checkpoint dict pickles its argparse Namespace
     sd = sd.get("model", sd)
     own = model.state_dict()
     keep = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}

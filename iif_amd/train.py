@@ -26,7 +26,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # distinct hardware queues f
 import torch   # noqa: E402
 
 from . import custom, initialisers, resnet_cifar, resnet_pytorch, utils
-from .ddp import broadcast_parameters
+from .ddp import broadcast_parameters, sync_buffers
 
 
 def lr_at(args, epoch, it, iters_per_epoch):
@@ -71,17 +71,32 @@ def train_one_epoch(model, criterion, data_loader, device, epoch, args, reducer=
         image = image.to(device, non_blocking=True)
         target = target.to(device, non_blocking=True)
         lr = lr_at(args, epoch, it, n_iters)
+        probe = reducer is not None and args.bf16_buckets and not getattr(reducer, "probed", False)
+        red = None if probe else reducer
         if mix is not None:
             image, ta, tb, lam = mix(image, target)
-            loss, output = model.loss_and_backward(image, ta, criterion, targets_b=tb, lam=lam, reducer=reducer)
+            loss, output = model.loss_and_backward(image, ta, criterion, targets_b=tb, lam=lam, reducer=red)
         else:
-            loss, output = model.loss_and_backward(image, target, criterion, reducer=reducer)
+            loss, output = model.loss_and_backward(image, target, criterion, reducer=red)
+        if probe:
+            # first step: gradients are still local; measure what bf16 buckets would do to their average, switch
+            # only if that stays within one bf16 rounding, then reduce this step (un-overlapped)
+            worst = reducer.probe_bf16()
+            reducer.probed = True
+            try:
+                reducer.set_bucket_dtype(torch.bfloat16)
+                print("bf16 gradient buckets enabled (probe: %.2e relative L2)" % worst)
+            except RuntimeError:
+                print("bf16 gradient buckets REFUSED (probe: %.2e relative L2 > tolerance); staying with fp32" % worst)
+            reducer.begin()
+            reducer.finish()
         model.sgd_step(lr, args.momentum, args.weight_decay, nesterov, grad_scale=scale)
         imgs_since += image.shape[0]
         if it % args.print_freq == 0 or it == n_iters - 1:
             acc1, acc5 = utils.accuracy(output, target, topk=(1, min(5, output.shape[1])))
             now = time.time()                                   # .item() below is the only host sync
             logger.update(loss=loss.item(), lr=lr)
+            model.check_labels()                                # out-of-range targets raise here (device assert in the reference)
             logger.meters["acc1"].update(acc1.item(), n=image.shape[0])
             logger.meters["acc5"].update(acc5.item(), n=image.shape[0])
             logger.meters["img/s"].update(imgs_since / max(now - t_last, 1e-9))
@@ -133,6 +148,11 @@ def main(args):
     print("Creating model")
     model = build_model(args, num_classes)
     criterion = initialisers.get_criterion(args, dataset, model, num_classes)
+    if args.sync_bn and args.distributed:
+        # train.py:190-191 converts to SyncBatchNorm (opt-in, off in every published recipe).  The native BN
+        # statistics are per-replica: refuse rather than silently train a different model.
+        raise NotImplementedError("--sync-bn: cross-replica batch statistics are not built into the native BN kernels "
+                                  "(per-replica statistics only, the reference's default); drop the flag")
     if args.opt.lower() not in ("sgd", "nesterov"):
         raise RuntimeError("Invalid optimizer {}. Only SGD and RMSprop are supported.".format(args.opt))
     if args.decoup:
@@ -140,7 +160,7 @@ def main(args):
     reducer = None
     if args.distributed:
         broadcast_parameters(model)
-        reducer = model.make_reducer()
+        reducer = model.make_reducer(mode=args.reduce_mode)
     if args.resume:
         # the reference's checkpoint dict (train.py:265-271): model / optimizer / lr_scheduler / epoch / args
         ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
@@ -160,6 +180,8 @@ def main(args):
         if args.distributed:
             train_sampler.set_epoch(epoch)
         train_one_epoch(model, criterion, data_loader, device, epoch, args, reducer)
+        if args.distributed:
+            sync_buffers(model)               # rank 0's BN statistics everywhere, as DDP's broadcast_buffers
         acc = evaluate(model, criterion, data_loader_test, device=device)
         best_acc = max(best_acc, acc)
         if args.output_dir:
@@ -177,7 +199,10 @@ def main(args):
 
 def get_args_parser(add_help=True):
     p = argparse.ArgumentParser(description="IIF classification training on MI355X", add_help=add_help)
-    p.add_argument("--data-path", default="", help="unused: datasets are synthetic")
+    p.add_argument("--data-path", default="", help="dataset root of the list files; empty = synthetic long-tailed sets")
+    p.add_argument("--train-txt", dest="train_txt", default=None, help="training list (default: the reference's path for --dset_name)")
+    p.add_argument("--eval-txt", dest="eval_txt", default=None, help="evaluation list (default: the reference's path)")
+    p.add_argument("--image-size", dest="image_size", default=224, type=int)
     p.add_argument("--dset_name", default="cifar100", help="cifar10|cifar100|imagenet_lt|places_lt|inat18 (synthetic)")
     p.add_argument("--rand_number", default=0, type=int)
     p.add_argument("--imb_type", default="exp", type=str)
@@ -223,6 +248,10 @@ def get_args_parser(add_help=True):
     p.add_argument("--record-result", dest="record_result", action="store_true")
     # MI355X-native additions
     p.add_argument("--compute-dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--reduce-mode", dest="reduce_mode", default="allreduce", choices=["allreduce", "rs_ag"],
+                   help="gradient buckets: one all_reduce each, or reduce_scatter + all_gather")
+    p.add_argument("--bf16-buckets", dest="bf16_buckets", action="store_true",
+                   help="reduce bf16 copies of the gradient buckets (refused unless the first step's probe stays in tolerance)")
     p.add_argument("--max-iters", default=0, type=int, help="stop each epoch after this many iterations (0 = all)")
     p.add_argument("--synthetic-scale", dest="synthetic_scale", default=1.0, type=float)
     return p

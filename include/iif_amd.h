@@ -74,13 +74,18 @@ int iif_build_table(const int64_t* counts_host, int C, int variant, int norm_p, 
  * reduction='none' value).  loss_out: float[1] or NULL.  dlogits may be NULL
  * (loss only).  d_status: int32[1] or NULL; set to 1 if any target is outside
  * [0,C) and != ignore_index (such rows contribute 0).
- * Deterministic: the row sum is a fixed-order tree, no float atomics. */
+ * d_ticket: int32[1] or NULL.  With a ticket word (ZERO on entry; the kernel leaves
+ * it zero again) the scalar loss is reduced by the last block of the SAME launch;
+ * without it a second, one-block launch sums loss_per_row.  A ticket word must not
+ * be shared by calls that can run concurrently (one per stream).
+ * Deterministic either way: the row sum is a fixed-order tree, no float atomics.
+ * The softmax runs in base 2 on v_exp_f32 / v_log_f32 (~1 ulp each). */
 int iif_ce_fwd_bwd(const void* logits, int dtype, int64_t ld_logits,
                    const float* table, const int64_t* targets_a, const int64_t* targets_b,
                    float lam, const float* row_weight, const float* class_weight,
                    int64_t ignore_index, float scale, int B, int C,
                    float* loss_per_row, float* loss_out,
-                   void* dlogits, int64_t ld_dlogits, int32_t* d_status, void* stream);
+                   void* dlogits, int64_t ld_dlogits, int32_t* d_status, int32_t* d_ticket, void* stream);
 
 /* out = logits * table.  Replaces classification/custom.py:37-39 (infer=True). */
 int iif_scale_logits(const void* logits, int dtype, int64_t ld_logits, const float* table,
@@ -100,9 +105,9 @@ int iif_topk_hits(const void* logits, int dtype, int64_t ld_logits, const float*
                   const int64_t* targets, int B, int C, const int32_t* k_host, int nk,
                   int32_t* hits, void* stream);
 
-/* x[i] *= *d_scalar (device scalar).  Used by the autograd bridge to apply the
- * upstream gradient of the scalar loss without a host sync. */
-int iif_scale_by_device_scalar(void* x, int dtype, int64_t n, const float* d_scalar, void* stream);
+/* out[i] = x[i] * *d_scalar (device scalar; out may alias x).  Used by the autograd
+ * bridge to apply the upstream gradient of the scalar loss without a host sync. */
+int iif_scale_by_device_scalar(const void* x, int dtype, int64_t n, const float* d_scalar, void* out, void* stream);
 
 /* out[b,:] = lam*x[b,:] + (1-lam)*x[perm[b],:], rows of n elements.
  * Replaces the image blend of classification/custom.py:112 (Mixup.__call__). */

@@ -24,7 +24,7 @@ class DS:
     def get_cls_num_list(self): return self.c
 
 
-for (B, C, dt) in ((256, 1000, torch.float32), (1024, 1204, torch.float32), (65536, 1000, torch.float32), (65536, 1000, torch.bfloat16),
+for (B, C, dt) in ((256, 1000, torch.float32), (1024, 1204, torch.float32), (2048, 1204, torch.float32), (65536, 1000, torch.float32), (65536, 1000, torch.bfloat16),
                    (16384, 8142, torch.bfloat16)):
     counts = [max(int(1280 * (5 / 1280) ** (i / (C - 1.0))), 1) for i in range(C)]
     crit = IIFLoss(DS(counts), variant="raw", device=dev)

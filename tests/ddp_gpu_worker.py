@@ -1,6 +1,10 @@
 """Worker of test_ddp_gpu.py: one data-parallel rank of the native engine.  Every rank sits on cuda:0
-(the test box has one GPU; RCCL refuses two ranks on one device, so the rehearsal uses gloo) and feeds
-the SAME batch, so that the averaged gradient equals the single-process gradient bit for bit."""
+(the test box has one GPU; RCCL refuses two ranks on one device, so the rehearsal uses gloo).
+
+``same``: every rank feeds the SAME batch, so the averaged gradient equals the single-process gradient bit for bit.
+``diff``: every rank feeds its OWN batch; ``emulate`` reproduces the data-parallel step in one process (backward on
+each rank's batch from the same weights, gradients summed in rank order, 1/world in the SGD launch), so a bucket
+reduced too early, a missed stream wait or a dropped slice shows up as a parameter difference."""
 import os
 import sys
 
@@ -8,43 +12,81 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+BATCH = 16
 
 
-def run(out_path, steps, with_reducer):
+def _setup(dev):
     from iif_amd import resnet_cifar
     from iif_amd.custom import IIFLoss
-    from iif_amd.ddp import broadcast_parameters
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
     torch.manual_seed(5)
     net = resnet_cifar.resnet20(num_classes=10, use_norm="None", device=dev, compute_dtype=torch.float32)
     net.train()
-    reducer = None
-    if with_reducer:
-        broadcast_parameters(net)
-        reducer = net.make_reducer(bucket_bytes=256 << 10)     # several buckets on a 0.27M-parameter net
-        assert len(reducer.buckets) >= 3
 
     class _D(object):
         def get_cls_num_list(self):
             return [500, 300, 200, 120, 80, 50, 30, 20, 10, 5]
-    crit = IIFLoss(_D(), variant="raw", reduction="mean", device=dev)
-    g = torch.Generator().manual_seed(77)
-    x = torch.randn(16, 3, 32, 32, generator=g).to(dev)
-    y = torch.randint(0, 10, (16,), generator=g).to(dev)
+    return net, IIFLoss(_D(), variant="raw", reduction="mean", device=dev)
+
+
+def _batch(dev, rank):
+    g = torch.Generator().manual_seed(77 + rank)
+    return torch.randn(BATCH, 3, 32, 32, generator=g).to(dev), torch.randint(0, 10, (BATCH,), generator=g).to(dev)
+
+
+def run(out_path, steps, with_reducer, data="same", mode="allreduce", bf16=False):
+    from iif_amd.ddp import broadcast_parameters
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    net, crit = _setup(dev)
+    reducer = None
+    rank = dist.get_rank() if with_reducer else 0
+    if with_reducer:
+        broadcast_parameters(net)
+        reducer = net.make_reducer(bucket_bytes=256 << 10, mode=mode)     # several buckets on a 0.27M-parameter net
+        assert len(reducer.buckets) >= 3
+    x, y = _batch(dev, rank if data == "diff" else 0)
     scale = reducer.grad_scale if reducer is not None else 1.0
-    losses = []
+    losses, info = [], {}
     for it in range(steps):
-        loss, _ = net.loss_and_backward(x, y, crit, reducer=reducer)
+        if bf16 and it == 0:
+            loss, _ = net.loss_and_backward(x, y, crit, reducer=None)
+            info["probe"] = reducer.probe_bf16()
+            reducer.set_bucket_dtype(torch.bfloat16)                       # raises if the probe refused
+            reducer.begin(); reducer.finish()
+        else:
+            loss, _ = net.loss_and_backward(x, y, crit, reducer=reducer)
         net.sgd_step(0.05, 0.9, 1e-4, grad_scale=scale)
         losses.append(float(loss.item()))
+    torch.cuda.synchronize()
+    if reducer is not None:
+        info["reducer"] = reducer.describe()
+    torch.save({"params": net.param_arena.detach().cpu(), "losses": losses, "info": info}, out_path)
+
+
+def emulate(out_path, steps, world):
+    """The data-parallel step of ``world`` ranks with rank-distinct batches, in one process."""
+    dev = torch.device("cuda", 0)
+    net, crit = _setup(dev)
+    batches = [_batch(dev, r) for r in range(world)]
+    losses = [[] for _ in range(world)]
+    for it in range(steps):
+        total = torch.zeros_like(net.grad_arena)
+        for r, (x, y) in enumerate(batches):
+            loss, _ = net.loss_and_backward(x, y, crit)
+            total += net.grad_arena                       # rank order: (g0 + g1) + ...
+            losses[r].append(float(loss.item()))
+        net.grad_arena.copy_(total)
+        net.sgd_step(0.05, 0.9, 1e-4, grad_scale=1.0 / world)
     torch.cuda.synchronize()
     torch.save({"params": net.param_arena.detach().cpu(), "losses": losses}, out_path)
 
 
 if __name__ == "__main__":
     out_dir, steps = sys.argv[1], int(sys.argv[2])
+    data = sys.argv[3] if len(sys.argv) > 3 else "same"
+    mode = sys.argv[4] if len(sys.argv) > 4 else "allreduce"
+    bf16 = len(sys.argv) > 5 and sys.argv[5] == "bf16"
     dist.init_process_group("gloo")
-    run(os.path.join(out_dir, "rank%d.pt" % dist.get_rank()), steps, True)
+    run(os.path.join(out_dir, "rank%d.pt" % dist.get_rank()), steps, True, data, mode, bf16)
     dist.barrier()
     dist.destroy_process_group()

@@ -118,3 +118,53 @@ def test_scheduler_state_matches_torch():
                 else torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[8, 14], gamma=0.1))
         sch2.load_state_dict(mine)                                       # the reference's resume path (train.py:241)
         assert sch2.last_epoch == 10
+
+
+def test_shot_acc_matches_per_class_scan():
+    """The bincount formulation against a direct per-class scan on random data (present classes only, empty splits -> 0)."""
+    from iif_amd.per_shot_acc import shot_acc
+    rng = np.random.RandomState(3)
+    for trial in range(5):
+        C = 30
+        train = rng.choice(C, size=4000, p=np.r_[np.full(5, 0.12), np.full(25, 0.016)])
+        labels = rng.choice(np.arange(2, C), size=500)                 # classes 0, 1 absent from the test labels
+        preds = np.where(rng.rand(500) < 0.6, labels, rng.choice(C, size=500))
+        many, med, low, per = shot_acc(preds, labels, train, many_shot_thr=100, low_shot_thr=60, acc_per_cls=True)
+        buckets = {"many": [], "med": [], "low": []}
+        want_per = []
+        for c in sorted(set(labels.tolist())):
+            sel = labels == c
+            acc = float((preds[sel] == c).mean())
+            want_per.append(acc)
+            n = int((train == c).sum())
+            buckets["many" if n > 100 else ("low" if n < 60 else "med")].append(acc)
+        want = [np.mean(v) if v else 0.0 for v in (buckets["many"], buckets["med"], buckets["low"])]
+        assert np.allclose([many, med, low], want, rtol=0, atol=1e-12)
+        assert np.allclose(per, want_per, rtol=0, atol=1e-12)
+    assert shot_acc(np.array([1, 1]), np.array([1, 1]), [1] * 500) == (1.0, 0, 0)
+
+
+def test_get_data_reads_list_files(tmp_path):
+    """``--data-path`` reaches LT_Dataset / LT_Dataset_Eval through get_data (initialisers.py:83-100,
+    imbalanced_dataset.py:177-259): class map by descending frequency, evaluation list remapped, tensors of the
+    reference's geometry."""
+    import types
+    from iif_amd import initialisers
+    rng = np.random.RandomState(0)
+    (tmp_path / "img").mkdir()
+    labels = [0] * 2 + [1] * 7 + [2] * 4
+    lines = []
+    for i, l in enumerate(labels):
+        np.save(tmp_path / "img" / ("%d.npy" % i), rng.randint(0, 255, size=(40 + i, 50, 3), dtype=np.uint8))
+        lines.append("img/%d.npy %d" % (i, l))
+    (tmp_path / "train.txt").write_text("\n".join(lines) + "\n")
+    (tmp_path / "eval.txt").write_text("\n".join(lines[:5]) + "\n")
+    args = types.SimpleNamespace(dset_name="places_lt", data_path=str(tmp_path), train_txt=str(tmp_path / "train.txt"),
+                                 eval_txt=str(tmp_path / "eval.txt"), image_size=32, rand_number=0, sampler="random",
+                                 distributed=False, batch_size=4, workers=0)
+    ds, C, loader, loader_test, sampler = initialisers.get_data(args)
+    assert ds.cls_num_list[:3] == [7, 4, 2] and ds.class_map[:3] == [2, 0, 1]
+    x, y = next(iter(loader))
+    assert tuple(x.shape) == (4, 3, 32, 32) and x.dtype == torch.float32 and y.dtype == torch.int64
+    xt, yt = next(iter(loader_test))
+    assert tuple(xt.shape) == (4, 3, 32, 32) and yt.tolist() == [2, 2, 0, 0]       # raw 0,0,1,1 through the training class map

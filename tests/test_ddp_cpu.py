@@ -23,7 +23,7 @@ def _worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from iif_amd import resnet_cifar
-        from iif_amd.ddp import ArenaReducer, broadcast_parameters
+        from iif_amd.ddp import ArenaReducer, broadcast_parameters, sync_buffers
         from iif_amd.utils import SmoothedValue
         torch.manual_seed(100 + rank)                       # different init per rank
         net = resnet_cifar.resnet20(num_classes=10, device="cpu", compute_dtype=torch.float32)
@@ -53,10 +53,55 @@ def _worker(rank, world, port, ret):
         assert torch.equal(g, expect)
         assert red.grad_scale == 1.0 / world
 
+        # reduce_scatter + all_gather buckets: same sums, every element exactly once
+        red2 = net.make_reducer(bucket_bytes=64 << 10, mode="rs_ag")
+        assert len(red2.buckets) >= 3 and all((hi - lo) % world == 0 for lo, hi in red2.buckets)
+        g.copy_(base * (rank + 1))
+        red2.begin()
+        red2.gradients_ready_from(offs["head"])
+        for bi in range(len(offs["blocks"]) - 1, -1, -1):
+            red2.gradients_ready_from(offs["blocks"][bi])
+        red2.finish()
+        assert torch.equal(g, expect)
+        d = red2.describe()
+        assert d["world"] == world and d["mode"] == "rs_ag" and d["collectives_launched"] == 2 * len(red2.buckets)
+        assert sum(d["bucket_bytes"]) == 4 * n and d["steps_reduced"] == 1
+        # frozen backbone: only the head's slice
+        g.copy_(base * (rank + 1))
+        red2.begin(); red2.finish_tail(offs["head"])
+        lo = offs["head"] - offs["head"] % world
+        assert torch.equal(g[lo:], expect[lo:]) and torch.equal(g[:lo], base[:lo] * (rank + 1))
+
+        # bf16 buckets: refused before the probe, cleared by it on well-scaled gradients, then within one rounding
+        red3 = net.make_reducer(bucket_bytes=64 << 10)
+        with pytest.raises(RuntimeError):
+            red3.set_bucket_dtype(torch.bfloat16)
+        gen = torch.Generator().manual_seed(7)
+        smooth = torch.randn(n, generator=gen) * 1e-3
+        g.copy_(smooth * (rank + 1))
+        worst = red3.probe_bf16()
+        assert worst <= 4e-3 and torch.equal(g, smooth * (rank + 1))          # the probe leaves the arena alone
+        red3.set_bucket_dtype(torch.bfloat16)
+        red3.begin(); red3.finish()
+        exact = smooth * sum(r + 1 for r in range(world))
+        assert ((g - exact).norm() / exact.norm()).item() <= 4e-3
+        assert red3.describe()["bucket_dtype"] == "bf16" and red3.describe()["payload_bytes_per_step"] == 2 * n
+        # gradients that bf16 cannot carry (spread over 30 binades inside one bucket is fine, but a bucket whose
+        # mass sits below bf16's resolution of its companion on another rank is not): the probe refuses
+        red4 = net.make_reducer(bucket_bytes=64 << 10)
+        g.copy_(torch.where(torch.arange(n) % 2 == 0, 1.0, 1.0 + 2.0 ** -10) * (1.0 if rank == 0 else -1.0) + (rank * 1e-3))
+        assert red4.probe_bf16() > 4e-3
+        with pytest.raises(RuntimeError):
+            red4.set_bucket_dtype(torch.bfloat16)
+
         m = SmoothedValue()
         m.update(10.0 * (rank + 1), n=4)
         m.synchronize_between_processes()
         assert m.count == 4 * world and abs(m.total - 4 * 10.0 * sum(r + 1 for r in range(world))) < 1e-9
+        # BN running statistics follow rank 0 (DDP broadcast_buffers)
+        net._rstat.fill_(float(rank + 3)); net._nbt.fill_(rank + 5)
+        sync_buffers(net)
+        assert float(net._rstat[0]) == 3.0 and int(net._nbt[0]) == 5
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

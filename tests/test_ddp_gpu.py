@@ -9,19 +9,57 @@ import torch
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def _launch(tmp_path, port, *worker_args):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(HERE, "ddp_gpu_worker.py"), str(tmp_path)] + [str(a) for a in worker_args]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [torch.load(tmp_path / ("rank%d.pt" % rk), weights_only=False) for rk in (0, 1)]
 
 
 def test_two_ranks_same_batch_equal_single_process_bit_for_bit(tmp_path):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(HERE, "ddp_gpu_worker.py"), str(tmp_path), "4"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    sys.path.insert(0, HERE)
     import ddp_gpu_worker
+    ranks = _launch(tmp_path, 29533, 4)
     ddp_gpu_worker.run(str(tmp_path / "single.pt"), 4, False)
-    single = torch.load(tmp_path / "single.pt")
-    for rk in (0, 1):
-        got = torch.load(tmp_path / ("rank%d.pt" % rk))
+    single = torch.load(tmp_path / "single.pt", weights_only=False)
+    for got in ranks:
         assert got["losses"] == single["losses"]
         assert torch.equal(got["params"], single["params"])       # (g + g) * 0.5 == g exactly
+
+
+@pytest.mark.parametrize("mode,port", [("allreduce", 29541), ("rs_ag", 29542)])
+def test_two_ranks_different_batches_match_emulated_data_parallel_step(tmp_path, mode, port):
+    """Rank-distinct batches: every bucket must carry BOTH ranks' final gradients (ordering against backward, the
+    weight-gradient stream, full coverage of the arena).  fp32 two-operand sums are order independent, so the
+    parameters after 4 steps equal the one-process emulation bit for bit, on both ranks."""
+    import ddp_gpu_worker
+    ranks = _launch(tmp_path, port, 4, "diff", mode)
+    ddp_gpu_worker.emulate(str(tmp_path / "emu.pt"), 4, 2)
+    emu = torch.load(tmp_path / "emu.pt", weights_only=False)
+    assert ranks[0]["losses"] != ranks[1]["losses"]               # the ranks really saw different data
+    for rk, got in enumerate(ranks):
+        assert got["losses"] == emu["losses"][rk]
+        assert torch.equal(got["params"], emu["params"]), (got["params"] - emu["params"]).abs().max()
+        d = got["info"]["reducer"]
+        assert d["world"] == 2 and d["mode"] == mode and d["steps_reduced"] == 4
+        assert d["collectives_launched"] == 4 * d["buckets"] * (2 if mode == "rs_ag" else 1)
+
+
+def test_bf16_buckets_keep_the_fp32_loss_curve(tmp_path):
+    """bf16 gradient buckets are only switched on after the probe on real gradients; the 6-step loss curve then stays
+    within 1e-3 relative of the fp32-bucket curve (bf16 rounding of the summed gradient, 2^-8 per element, before
+    momentum) and the parameters within 1e-3 of their norm."""
+    import ddp_gpu_worker
+    low = _launch(tmp_path, 29543, 6, "diff", "allreduce", "bf16")
+    ddp_gpu_worker.emulate(str(tmp_path / "emu.pt"), 6, 2)
+    emu = torch.load(tmp_path / "emu.pt", weights_only=False)
+    for rk, got in enumerate(low):
+        assert got["info"]["probe"] <= 4e-3 and got["info"]["reducer"]["bucket_dtype"] == "bf16"
+        for a, b in zip(got["losses"], emu["losses"][rk]):
+            assert abs(a - b) <= 1e-3 * abs(b), (got["losses"], emu["losses"][rk])
+        assert ((got["params"] - emu["params"]).norm() / emu["params"].norm()).item() <= 1e-3
+    assert torch.equal(low[0]["params"], low[1]["params"])        # replicas stay identical

@@ -145,7 +145,7 @@ def test_bf16_logits():
 
 
 # --------------------------------------------------------- C ABI, direct calls
-def _ce_raw(pred, table, ta, tb=None, lam=1.0, rw=None, cw=None, ignore=-100, scale=1.0, want_grad=True, ld=None):
+def _ce_raw(pred, table, ta, tb=None, lam=1.0, rw=None, cw=None, ignore=-100, scale=1.0, want_grad=True, ld=None, ticket=None):
     from iif_amd import _lib
     B, C = pred.shape
     dev = pred.device
@@ -155,7 +155,8 @@ def _ce_raw(pred, table, ta, tb=None, lam=1.0, rw=None, cw=None, ignore=-100, sc
     st = torch.zeros(1, dtype=torch.int32, device=dev)
     rc = _lib.lib().iif_ce_fwd_bwd(_lib.ptr(pred), _lib.dtype_code(pred), ld or pred.stride(0), _lib.ptr(table),
                                    _lib.ptr(ta), _lib.ptr(tb), lam, _lib.ptr(rw), _lib.ptr(cw), ignore, scale, B, C,
-                                   _lib.ptr(rows), _lib.ptr(loss), _lib.ptr(d), C, _lib.ptr(st), _lib.stream_ptr())
+                                   _lib.ptr(rows), _lib.ptr(loss), _lib.ptr(d), C, _lib.ptr(st), _lib.ptr(ticket),
+                                   _lib.stream_ptr())
     return rc, loss, rows, d, st
 
 
@@ -192,12 +193,66 @@ def test_cabi_argument_errors_and_empty_batch():
     t = torch.zeros(4, dtype=torch.int64, device=dev)
     rows = torch.zeros(4, device=dev)
     L = _lib.lib()
-    assert L.iif_ce_fwd_bwd(0, 0, 8, tab.data_ptr(), t.data_ptr(), 0, 1.0, 0, 0, -100, 1.0, 4, 8, rows.data_ptr(), 0, 0, 8, 0, 0) == -1
-    assert L.iif_ce_fwd_bwd(pred.data_ptr(), 7, 8, tab.data_ptr(), t.data_ptr(), 0, 1.0, 0, 0, -100, 1.0, 4, 8, rows.data_ptr(), 0, 0, 8, 0, 0) == -1
-    assert L.iif_ce_fwd_bwd(pred.data_ptr(), 0, 4, tab.data_ptr(), t.data_ptr(), 0, 1.0, 0, 0, -100, 1.0, 4, 8, rows.data_ptr(), 0, 0, 8, 0, 0) == -1
+    assert L.iif_ce_fwd_bwd(0, 0, 8, tab.data_ptr(), t.data_ptr(), 0, 1.0, 0, 0, -100, 1.0, 4, 8, rows.data_ptr(), 0, 0, 8, 0, 0, 0) == -1
+    assert L.iif_ce_fwd_bwd(pred.data_ptr(), 7, 8, tab.data_ptr(), t.data_ptr(), 0, 1.0, 0, 0, -100, 1.0, 4, 8, rows.data_ptr(), 0, 0, 8, 0, 0, 0) == -1
+    assert L.iif_ce_fwd_bwd(pred.data_ptr(), 0, 4, tab.data_ptr(), t.data_ptr(), 0, 1.0, 0, 0, -100, 1.0, 4, 8, rows.data_ptr(), 0, 0, 8, 0, 0, 0) == -1
     loss = torch.full((), 5.0, device=dev)
-    assert L.iif_ce_fwd_bwd(pred.data_ptr(), 0, 8, tab.data_ptr(), t.data_ptr(), 0, 1.0, 0, 0, -100, 1.0, 0, 8, rows.data_ptr(), loss.data_ptr(), 0, 8, 0, _lib.stream_ptr()) == 0
+    assert L.iif_ce_fwd_bwd(pred.data_ptr(), 0, 8, tab.data_ptr(), t.data_ptr(), 0, 1.0, 0, 0, -100, 1.0, 0, 8, rows.data_ptr(), loss.data_ptr(), 0, 8, 0, 0, _lib.stream_ptr()) == 0
     assert loss.item() == 0.0
+
+
+@pytest.mark.parametrize("B,C,dt", [(256, 1000, torch.float32), (1024, 1204, torch.float32), (5000, 1204, torch.bfloat16),
+                                    (33, 1001, torch.float32), (1, 8, torch.float32)])
+def test_single_launch_loss_reduce_matches_two_launch(B, C, dt):
+    """With a ticket word the scalar loss is reduced by the last block of the same launch: bit-identical to the
+    two-launch result (same fixed-order tree), run to run, and the ticket is left at zero for the next call."""
+    dev = _dev()
+    counts = lt_counts(C, 2000)
+    pred, tgt = sample(B, C, counts, B + C)
+    table = O.iif_tables(counts)["raw"].reshape(-1).to(dev)
+    p = pred.to(dev).to(dt)
+    rc, loss2, rows2, d2, _ = _ce_raw(p, table, tgt.to(dev), scale=1.0 / B)
+    assert rc == 0
+    ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+    for _ in range(3):
+        rc, loss1, rows1, d1, _ = _ce_raw(p, table, tgt.to(dev), scale=1.0 / B, ticket=ticket)
+        assert rc == 0 and ticket.item() == 0
+        assert torch.equal(rows1[:B], rows2[:B]) and torch.equal(d1, d2)
+        assert loss1.item() == loss2.item()
+    ref = O.iif_ce(p.float().cpu(), tgt, table.cpu().reshape(1, -1), None, "mean")
+    assert rel_err(loss1, ref) <= REL
+
+
+def test_autograd_backward_twice_and_scaled():
+    """The saved gradient is not modified by backward (retain_graph / two losses sharing the node / a loss scale)."""
+    from iif_amd.custom import IIFLoss
+    dev = _dev()
+    counts = lt_counts(100, 500)
+    pred, tgt = sample(32, 100, counts, 4)
+    crit = IIFLoss(DS(counts))
+    p = pred.to(dev).requires_grad_(True)
+    loss = crit(p, tgt.to(dev))
+    (loss * 0.25).backward(retain_graph=True)
+    g1 = p.grad.clone(); p.grad = None
+    (loss * 0.25).backward()
+    assert torch.equal(p.grad, g1)
+    _, ref_d, _ = O.iif_ce_closed_form(pred, tgt, O.iif_tables(counts)["raw"], None, "mean")
+    assert rel_err(p.grad, 0.25 * ref_d) <= REL
+
+
+def test_out_of_range_label_is_reported():
+    from iif_amd import custom
+    dev = _dev()
+    counts = lt_counts(10, 50)
+    pred, tgt = sample(8, 10, counts, 1)
+    crit = custom.IIFLoss(DS(counts))
+    crit(pred.to(dev), tgt.to(dev))
+    custom.check_label_status()                       # clean
+    bad = tgt.clone(); bad[3] = 10
+    crit(pred.to(dev), bad.to(dev))
+    with pytest.raises(IndexError):
+        custom.check_label_status()
+    custom.check_label_status()                       # flag was cleared
 
 
 def test_strided_rows_and_unaligned_pointers():
@@ -309,3 +364,27 @@ def test_large_shape_properties():
     shift = torch.randn(B, 1, device=dev) / t           # z shifts by a per-row constant
     loss2 = crit((pred.to(dev) + shift), tgt.to(dev))
     assert abs(loss2.item() - loss.item()) <= 1e-4 * abs(loss.item())
+
+
+def test_plain_ce_with_class_weights_divides_by_weight_sum():
+    """``--classif ce --deffered --reduction mean`` is nn.CrossEntropyLoss(weight=w) in the reference
+    (initialisers.py:43-46): the mean divides by the sum of the targets' weights, not by the batch size."""
+    import types
+    from iif_amd import initialisers
+    dev = _dev()
+    counts = lt_counts(100, 500)
+    pred, tgt = sample(64, 100, counts, 8)
+    args = types.SimpleNamespace(classif="ce", deffered=True, reduction="mean", iif="raw", iif_norm=0, device=dev)
+    crit = initialisers.get_criterion(args, DS(counts), None, 100)
+    assert crit.weighted_mean
+    w = torch.tensor(counts); w = (w.sum() / w).float()
+    ref_p = pred.clone().requires_grad_(True)
+    ref = torch.nn.CrossEntropyLoss(weight=w, reduction="mean")(ref_p, tgt)
+    ref.backward()
+    p = pred.to(dev).requires_grad_(True)
+    loss = crit(p, tgt.to(dev))
+    loss.backward()
+    assert rel_err(loss, ref) <= REL and rel_err(p.grad, ref_p.grad) <= REL
+    # the IIF criterion keeps the reference's own convention (custom.py:32-33: .mean() over the batch)
+    args.classif = "iif"
+    assert not initialisers.get_criterion(args, DS(counts), None, 100).weighted_mean
