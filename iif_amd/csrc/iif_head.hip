@@ -64,37 +64,47 @@ struct CeArgs {
     int32_t* ticket;       // zero on entry, zero again on exit
 };
 
-// Fixed-order sum of the per-row losses by the calling block (all of its threads).  Rows were written by other
-// blocks (other XCDs, other L2s): they are read with agent-scope atomic loads after the ticket's acquire.
-__device__ __forceinline__ void block_loss_sum(const CeArgs& a) {
+// Single-launch loss reduce.  workspace = int32 ticket (zero on entry / exit) followed by one float per block.
+// Every wave adds up the losses of the rows it walked (fixed order), the block combines its waves (fixed order) into
+// partial[blockIdx]; the last block to take a ticket sums the <= 2048 partials in a fixed tree.  Deterministic for a
+// given (B, C, dtype): the grid depends on nothing else.
+__device__ __forceinline__ void finish_with_ticket(const CeArgs& a, float wave_loss) {
+    if (a.ticket == nullptr) return;                // block-uniform
     __shared__ float sh[256];
+    __shared__ int last;
+    float* partial = reinterpret_cast<float*>(a.ticket + 1);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    if (lane == 0) sh[w] = wave_loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        for (int i = 0; i < wpb; ++i) acc += sh[i];
+        // No release fence here: an agent-scope fence writes back the whole XCD L2, which at this point is full of
+        // the gradient rows just stored (it cost 40 % of the kernel).  The partial goes out as an agent-scope atomic
+        // exchange (performed at the coherence point; a returning atomic has completed when its value is back), the
+        // ticket is taken only after that value has returned, and the last block reads the partials with
+        // agent-scope atomic loads: the same ordering without touching the ordinary stores.
+        const float prev = __hip_atomic_exchange(partial + blockIdx.x, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" : : "v"(prev) : "memory");
+        const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!last) return;
     float acc = 0.f;
-    for (int i = threadIdx.x; i < a.B; i += blockDim.x)
-        acc += __hip_atomic_load(a.loss_row + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x)
+        acc += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *a.loss_out = sh[0] * a.scale;
-}
-
-// Called by every thread of every block once its rows are stored.  Returns after the last block has reduced.
-__device__ __forceinline__ void finish_with_ticket(const CeArgs& a) {
-    if (a.ticket == nullptr) return;                // block-uniform
-    __shared__ int last;
-    __syncthreads();                                // all loss_row stores of this block issued
     if (threadIdx.x == 0) {
-        __threadfence();                            // release: rows visible at agent scope before the ticket
-        const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last = (t == (int)gridDim.x - 1);
+        *a.loss_out = sh[0] * a.scale;
+        __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    block_loss_sum(a);
-    if (threadIdx.x == 0) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Per-row scalars shared by the register and the streaming variants.
@@ -122,22 +132,18 @@ __device__ __forceinline__ RowCoef row_coef(const CeArgs& a, int row) {
 
 // ------------------------------------------------ register-resident row (C%4==0)
 // MODE 0: CE loss + gradient, MODE 1: softmax output (fp32)
-// A wave walks rows wave_id, wave_id + n_waves, ...: the IIF table chunk of the lane stays in registers for
-// all of them, and the next row's logits are already in flight while the current row is reduced.
+// A wave walks rows wave_id, wave_id + n_waves, ...  The IIF table sits in LDS (one copy per block, <= 8 KB) and the
+// next row's logits are already in flight while the current row is reduced and stored (6-8 waves per SIMD at
+// C = 1000 / 1204; a register-held table cost 110 VGPRs = half the occupancy).
 template <typename T, int NCH, int MODE>
 __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, int64_t ld_sm) {
+    __shared__ __attribute__((aligned(16))) float tab_s[NCH * 256];
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int nwaves = gridDim.x * wpb;
     int row = blockIdx.x * wpb + (threadIdx.x >> 6);
-    f32x4 t[NCH], t2[NCH], xn[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int c0 = (j * 64 + lane) * 4;
-        t[j] = c0 < a.C ? *reinterpret_cast<const f32x4*>(a.tab + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
-        t2[j] = t[j] * kLog2e;
-    }
-    if (row < a.B) {                              // wave-uniform
+    f32x4 xn[NCH];
+    if (row < a.B) {                              // wave-uniform: the first row is in flight while the table is staged
         const T* x0 = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -145,7 +151,11 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
             if (c0 < a.C) xn[j] = Io<T>::load4(x0 + c0);
         }
     }
+    for (int c = threadIdx.x; c < NCH * 256; c += blockDim.x) tab_s[c] = c < a.C ? a.tab[c] : 0.f;
+    __syncthreads();
+    float wave_loss = 0.f;
     for (; row < a.B; row += nwaves) {
+        asm volatile("" ::: "memory");            // keep the table reads in LDS: hoisted into registers they halve the occupancy
         const T* x = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
         f32x4 z[NCH];
         float m = -INFINITY;
@@ -153,13 +163,15 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
         for (int j = 0; j < NCH; ++j) {
             const int c0 = (j * 64 + lane) * 4;
             if (c0 < a.C) {
-                z[j] = xn[j] * t2[j];
+                z[j] = xn[j] * *reinterpret_cast<const f32x4*>(tab_s + c0);
                 m = fmaxf(m, fmaxf(fmaxf(z[j].x, z[j].y), fmaxf(z[j].z, z[j].w)));
             } else {
                 z[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             }
         }
-        if (row + nwaves < a.B) {                 // wave-uniform: next row's loads go out before the reductions
+        // The next row's loads go out BEFORE this row's stores: vmcnt retires in order, so a load issued after the
+        // stores could only be waited for together with them (write latency + read latency per row, 1.9 TB/s).
+        if (row + nwaves < a.B) {                 // wave-uniform
             const T* x1 = static_cast<const T*>(a.x) + (int64_t)(row + nwaves) * a.ldx;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
@@ -168,11 +180,12 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
             }
         }
         m = wave_max(m);
+        const float m2 = m * kLog2e;
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            z[j].x = fast_exp2(z[j].x - m); z[j].y = fast_exp2(z[j].y - m);
-            z[j].z = fast_exp2(z[j].z - m); z[j].w = fast_exp2(z[j].w - m);
+        for (int j = 0; j < NCH; ++j) {           // 2^(z*log2e - m*log2e): one fma + v_exp_f32 per element
+            z[j].x = fast_exp2(__builtin_fmaf(z[j].x, kLog2e, -m2)); z[j].y = fast_exp2(__builtin_fmaf(z[j].y, kLog2e, -m2));
+            z[j].z = fast_exp2(__builtin_fmaf(z[j].z, kLog2e, -m2)); z[j].w = fast_exp2(__builtin_fmaf(z[j].w, kLog2e, -m2));
             s += (z[j].x + z[j].y) + (z[j].z + z[j].w);
         }
         s = wave_sum(s);
@@ -186,12 +199,13 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
             }
             continue;
         }
-        const float lse = kLn2 * (m + fast_log2(s));
+        const float lse = m + kLn2 * fast_log2(s);
         const RowCoef rc = row_coef(a, row);
         float r = 0.f;
-        if (rc.ta >= 0) r += rc.wa * (lse - Io<T>::load1(x + rc.ta) * a.tab[rc.ta]);
-        if (rc.tb >= 0) r += rc.wb * (lse - Io<T>::load1(x + rc.tb) * a.tab[rc.tb]);
+        if (rc.ta >= 0) r += rc.wa * (lse - Io<T>::load1(x + rc.ta) * tab_s[rc.ta]);
+        if (rc.tb >= 0) r += rc.wb * (lse - Io<T>::load1(x + rc.tb) * tab_s[rc.tb]);
         if (lane == 0) a.loss_row[row] = rc.rw * r;
+        wave_loss += rc.rw * r;
         if (a.dx == nullptr) continue;
         T* dx = static_cast<T*>(a.dx) + (int64_t)row * a.lddx;
         const float g = a.scale * rc.rw;
@@ -209,11 +223,11 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
                     p.z -= (da == 2u ? ga : 0.f) + (db == 2u ? gb : 0.f);
                     p.w -= (da == 3u ? ga : 0.f) + (db == 3u ? gb : 0.f);
                 }
-                Io<T>::store4(dx + c0, p * t[j]);
+                Io<T>::store4(dx + c0, p * *reinterpret_cast<const f32x4*>(tab_s + c0));
             }
         }
     }
-    if (MODE == 0) finish_with_ticket(a);
+    if (MODE == 0) finish_with_ticket(a, wave_loss);
 }
 
 // -------------------------------------------- streaming row (any C / alignment)
@@ -221,6 +235,7 @@ template <typename T, int MODE>
 __global__ void __launch_bounds__(256) row_stream_kernel(CeArgs a, float* sm_out, int64_t ld_sm) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    float wave_loss = 0.f;
     if (row < a.B) {                              // wave-uniform
         const T* x = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
         float m = -INFINITY;
@@ -240,6 +255,7 @@ __global__ void __launch_bounds__(256) row_stream_kernel(CeArgs a, float* sm_out
             if (rc.ta >= 0) r += rc.wa * (lse - Io<T>::load1(x + rc.ta) * a.tab[rc.ta]);
             if (rc.tb >= 0) r += rc.wb * (lse - Io<T>::load1(x + rc.tb) * a.tab[rc.tb]);
             if (lane == 0) a.loss_row[row] = rc.rw * r;
+            wave_loss = rc.rw * r;
             if (a.dx != nullptr) {
                 T* dx = static_cast<T*>(a.dx) + (int64_t)row * a.lddx;
                 const float g = a.scale * rc.rw;
@@ -254,7 +270,7 @@ __global__ void __launch_bounds__(256) row_stream_kernel(CeArgs a, float* sm_out
             }
         }
     }
-    if (MODE == 0) finish_with_ticket(a);
+    if (MODE == 0) finish_with_ticket(a, wave_loss);
 }
 
 // fixed-order sum of the per-row losses: one 256-thread block, deterministic
@@ -315,12 +331,16 @@ __global__ void __launch_bounds__(256) scale_by_scalar_kernel(const T* x, int64_
 
 inline bool aligned(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+constexpr unsigned kMaxRowBlocks = 2048;      // = partial slots of the single-launch loss workspace
+
+// *inline_reduce (in/out): the caller wants the scalar loss reduced by this launch; cleared when the launch
+// configuration cannot do it (streaming kernel with more blocks than workspace slots).
 template <typename T, int MODE>
-int launch_rows(const CeArgs& a, float* sm_out, int64_t ld_sm, hipStream_t st) {
+int launch_rows(CeArgs a, float* sm_out, int64_t ld_sm, hipStream_t st, bool* inline_reduce = nullptr) {
     const int wpb = a.B <= 4096 ? 1 : 4;
     const dim3 grid((a.B + wpb - 1) / wpb), block(64 * wpb);
     // register-row kernel: at most 256 CUs x 8 blocks; beyond that a wave walks several rows
-    const dim3 pgrid(grid.x < 2048u ? grid.x : 2048u);
+    const dim3 pgrid(grid.x < kMaxRowBlocks ? grid.x : kMaxRowBlocks);
     bool vec = (a.C % 4 == 0) && (a.C <= 2048) && (a.ldx % 4 == 0) && aligned(a.x, Io<T>::kAlign) &&
                aligned(a.tab, 16);
     if (MODE == 0 && a.dx) vec = vec && (a.lddx % 4 == 0) && aligned(a.dx, Io<T>::kAlign);
@@ -330,8 +350,14 @@ int launch_rows(const CeArgs& a, float* sm_out, int64_t ld_sm, hipStream_t st) {
         if (nch <= 1) hipLaunchKernelGGL((row_reg_kernel<T, 1, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
         else if (nch <= 2) hipLaunchKernelGGL((row_reg_kernel<T, 2, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
         else if (nch <= 4) hipLaunchKernelGGL((row_reg_kernel<T, 4, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
+        else if (nch <= 5) hipLaunchKernelGGL((row_reg_kernel<T, 5, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);     // C = 1204 (LVIS head)
+        else if (nch <= 6) hipLaunchKernelGGL((row_reg_kernel<T, 6, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
         else hipLaunchKernelGGL((row_reg_kernel<T, 8, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
     } else {
+        if (grid.x > kMaxRowBlocks) {
+            a.ticket = nullptr;
+            if (inline_reduce) *inline_reduce = false;
+        }
         hipLaunchKernelGGL((row_stream_kernel<T, MODE>), grid, block, 0, st, a, sm_out, ld_sm);
     }
     IIF_LAUNCH_CHECK();
@@ -346,7 +372,7 @@ int iif_ce_fwd_bwd(const void* logits, int dtype, int64_t ld_logits, const float
                    const int64_t* targets_a, const int64_t* targets_b, float lam,
                    const float* row_weight, const float* class_weight, int64_t ignore_index,
                    float scale, int B, int C, float* loss_per_row, float* loss_out, void* dlogits,
-                   int64_t ld_dlogits, int32_t* d_status, int32_t* d_ticket, void* stream) {
+                   int64_t ld_dlogits, int32_t* d_status, void* d_workspace, void* stream) {
     if (B < 0 || C <= 0) return IIF_EINVAL;
     if (dtype != IIF_F32 && dtype != IIF_BF16) return IIF_EINVAL;
     hipStream_t st = as_stream(stream);
@@ -358,12 +384,12 @@ int iif_ce_fwd_bwd(const void* logits, int dtype, int64_t ld_logits, const float
     }
     if (!logits || !table || !targets_a || !loss_per_row) return IIF_EINVAL;
     if (ld_logits < C || (dlogits && ld_dlogits < C)) return IIF_EINVAL;
-    const bool one_launch = loss_out != nullptr && d_ticket != nullptr;
+    bool one_launch = loss_out != nullptr && d_workspace != nullptr;
     CeArgs a{logits, ld_logits, table, targets_a, targets_b, lam, row_weight, class_weight,
              ignore_index, scale, B, C, loss_per_row, dlogits, ld_dlogits, d_status,
-             one_launch ? loss_out : nullptr, one_launch ? d_ticket : nullptr};
-    int rc = dtype == IIF_F32 ? launch_rows<float, 0>(a, nullptr, 0, st)
-                              : launch_rows<unsigned short, 0>(a, nullptr, 0, st);
+             one_launch ? loss_out : nullptr, one_launch ? static_cast<int32_t*>(d_workspace) : nullptr};
+    int rc = dtype == IIF_F32 ? launch_rows<float, 0>(a, nullptr, 0, st, &one_launch)
+                              : launch_rows<unsigned short, 0>(a, nullptr, 0, st, &one_launch);
     if (rc != IIF_OK) return rc;
     if (loss_out && !one_launch) {
         hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, loss_per_row, B, scale, loss_out);

@@ -81,7 +81,7 @@ def _workspace(device, B, own_rows):
     ws = _WS.get(key)
     if ws is None:
         ws = _WS[key] = {"rows": torch.empty(0, dtype=torch.float32, device=device),
-                         "ticket": torch.zeros(1, dtype=torch.int32, device=device),
+                         "ticket": torch.zeros(1 + 2048, dtype=torch.int32, device=device),      # IIF_CE_WORKSPACE_BYTES
                          "status": torch.zeros(1, dtype=torch.int32, device=device)}
     if own_rows:
         rows = torch.empty(B, dtype=torch.float32, device=device)

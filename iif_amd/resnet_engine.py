@@ -684,7 +684,7 @@ class _Plan(object):
         self.dlogits_t = torch.zeros((n, head.out_padded), dtype=dt, device=dev)
         self.loss_rows = torch.zeros(n, dtype=torch.float32, device=dev)
         self.loss_rescale = torch.ones(1, dtype=torch.float32, device=dev)
-        self.loss_ticket = torch.zeros(1, dtype=torch.int32, device=dev)      # single-launch loss reduce (self-resetting)
+        self.loss_ticket = torch.zeros(1 + 2048, dtype=torch.int32, device=dev)      # IIF_CE_WORKSPACE_BYTES: ticket + block partials
         self.label_status = torch.zeros(1, dtype=torch.int32, device=dev)     # sticky: 1 once a label was out of range
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         op, D = head.out_padded, head.in_features

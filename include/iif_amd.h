@@ -74,18 +74,22 @@ int iif_build_table(const int64_t* counts_host, int C, int variant, int norm_p, 
  * reduction='none' value).  loss_out: float[1] or NULL.  dlogits may be NULL
  * (loss only).  d_status: int32[1] or NULL; set to 1 if any target is outside
  * [0,C) and != ignore_index (such rows contribute 0).
- * d_ticket: int32[1] or NULL.  With a ticket word (ZERO on entry; the kernel leaves
- * it zero again) the scalar loss is reduced by the last block of the SAME launch;
- * without it a second, one-block launch sums loss_per_row.  A ticket word must not
- * be shared by calls that can run concurrently (one per stream).
- * Deterministic either way: the row sum is a fixed-order tree, no float atomics.
+ * d_workspace: IIF_CE_WORKSPACE_BYTES of device memory or NULL.  Its first int32 is a
+ * ticket that must be ZERO on entry (zero it once; the kernel leaves it zero again),
+ * the rest holds one partial sum per block.  With a workspace the scalar loss comes
+ * out of the SAME launch (the last block to finish sums the per-block partials);
+ * without it a second, one-block launch sums loss_per_row.  A workspace must not be
+ * shared by calls that can run concurrently (one per stream).
+ * Deterministic either way (fixed-order trees, no float atomics); the two paths
+ * associate the sum differently and may differ in the last fp32 bits.
  * The softmax runs in base 2 on v_exp_f32 / v_log_f32 (~1 ulp each). */
 int iif_ce_fwd_bwd(const void* logits, int dtype, int64_t ld_logits,
                    const float* table, const int64_t* targets_a, const int64_t* targets_b,
                    float lam, const float* row_weight, const float* class_weight,
                    int64_t ignore_index, float scale, int B, int C,
                    float* loss_per_row, float* loss_out,
-                   void* dlogits, int64_t ld_dlogits, int32_t* d_status, int32_t* d_ticket, void* stream);
+                   void* dlogits, int64_t ld_dlogits, int32_t* d_status, void* d_workspace, void* stream);
+#define IIF_CE_WORKSPACE_BYTES (4 * (1 + 2048))
 
 /* out = logits * table.  Replaces classification/custom.py:37-39 (infer=True). */
 int iif_scale_logits(const void* logits, int dtype, int64_t ld_logits, const float* table,

@@ -235,9 +235,13 @@ def _state_checksum(sd):
     return np.array([float(v.double().sum()) for k, v in sd.items() if v.is_floating_point()])
 
 
-def _net_case(arch, num_classes, counts, B, hw, steps, lr):
+def _net_case(arch, num_classes, counts, B, hw, steps, lr, damp=None):
     cifar = arch in R.CIFAR_ARCHS
     sd = R.init_cifar(arch, num_classes, seed=7) if cifar else R.init_imagenet(arch, num_classes, seed=7)
+    if damp is not None:          # conditioned input: the last BN gain of every bottleneck scaled down (see g16_nets_conditioned)
+        for k in sd:
+            if k.startswith("layer") and k.endswith("bn3.weight"):
+                sd[k] = sd[k] * damp
     if cifar:
         model = getattr(resnet_cifar, arch)(num_classes=num_classes, use_norm="None")
     else:
@@ -276,6 +280,32 @@ def _net_case(arch, num_classes, counts, B, hw, steps, lr):
     final = model.state_dict()
     for k in final:
         close(my_sd[k], final[k], 2e-5, arch + " final " + k)
+    # The same steps by the same reference modules in float64 ("exact" arithmetic): how far the reference's OWN fp32
+    # run is from it is the noise floor that any other fp32 implementation is entitled to (random init on 2-8 images
+    # amplifies rounding: a ReLU or max-pool tie decided the other way moves whole gradients).
+    if cifar:
+        m64 = getattr(resnet_cifar, arch)(num_classes=num_classes, use_norm="None").double()
+    else:
+        m64 = getattr(resnet_pytorch, arch)(num_classes=num_classes, use_norm="None", pretrained="None").double()
+    m64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
+    m64.train()
+    opt64 = torch.optim.SGD(m64.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    sched64 = ref_utils.warmup_lr_scheduler(opt64, 1000, 1.0 / 1000)
+    losses64, gn64 = [], None
+    for it in range(steps):
+        lg = m64(x.double())
+        l64 = crit(lg, y)
+        opt64.zero_grad()
+        l64.backward()
+        if it == 0:
+            out["logits0_f64"] = lg.detach().numpy()
+            gn64 = [float(p.grad.norm()) for _, p in m64.named_parameters()]
+        opt64.step()
+        sched64.step()
+        losses64.append(float(l64))
+    out["losses_f64"] = np.array(losses64)
+    out["gradnorm0_f64"] = np.array(gn64)
+    out["final_checksum_f64"] = np.array([float(v.double().sum()) for k, v in m64.state_dict().items() if v.is_floating_point()])
     out["logits0"] = logits0.numpy()
     out["losses"] = np.array(losses)
     out["gradnorm_keys"] = np.array(list(gn0.keys()))
@@ -311,6 +341,24 @@ def g10_se():
     c1000 = COUNT_SETS["imagenet1000"]
     for k, v in _net_case("se_resnet50", 1000, c1000, 2, 64, 2, 0.1).items():
         out["se_resnet50_" + k] = v
+    return out
+
+
+# -------------------------------------------------------------------------- G16
+def g16_nets_conditioned():
+    """The ImageNet architectures on a WELL-CONDITIONED input: same seed-7 initialisation, but the last BN gain of every
+    bottleneck scaled by 0.1 (trained networks have small residual-branch gains; torchvision's zero_init_residual sets
+    them to 0) and 8 images.  At the plain random init of G7/G10 the reference's own fp32 run is 7e-2..3e-1 away from its
+    float64 run after one SGD step (profiles/r2_reference_fp32_noise.txt), so no 1e-4 statement can be made there; here
+    it stays within ~1e-5 over three steps, and the HIP path is held to the plain 1e-4 for the whole loss curve."""
+    out = {}
+    c1000 = COUNT_SETS["imagenet1000"]
+    c365 = COUNT_SETS["places365"]
+    for name, arch, C, counts in (("resnet50", "resnet50", 1000, c1000), ("resnext50", "resnext50_32x4d", 365, c365),
+                                  ("se_resnet50", "se_resnet50", 1000, c1000)):
+        for k, v in _net_case(arch, C, counts, 8, 64, 3, 0.1, damp=0.1).items():
+            out[name + "_" + k] = v
+        out[name + "_damp"] = np.array(0.1)
     return out
 
 
@@ -371,7 +419,7 @@ def g8_warmup():
 
 def main():
     sets = {"g1_class_counts": g1_class_counts, "g2_class_map": g2_class_map, "g3_tables": g3_tables,
-            "g4_loss": g4_loss, "g7_nets": g7_nets, "g8_warmup": g8_warmup, "g9_heads": g9_heads, "g10_se": g10_se}
+            "g4_loss": g4_loss, "g7_nets": g7_nets, "g8_warmup": g8_warmup, "g9_heads": g9_heads, "g10_se": g10_se, "g16_nets_conditioned": g16_nets_conditioned}
     only = sys.argv[1:]
     if only:
         sets = {k: v for k, v in sets.items() if k in only}

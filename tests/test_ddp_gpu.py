@@ -55,7 +55,7 @@ def test_bf16_buckets_keep_the_fp32_loss_curve(tmp_path):
     momentum) and the parameters within 1e-3 of their norm."""
     import ddp_gpu_worker
     low = _launch(tmp_path, 29543, 6, "diff", "allreduce", "bf16")
-    ddp_gpu_worker.emulate(str(tmp_path / "emu.pt"), 6, 2)
+    ddp_gpu_worker.emulate(str(tmp_path / "emu.pt"), 6, 2, lr=ddp_gpu_worker.BF16_LR)
     emu = torch.load(tmp_path / "emu.pt", weights_only=False)
     for rk, got in enumerate(low):
         assert got["info"]["probe"] <= 4e-3 and got["info"]["reducer"]["bucket_dtype"] == "bf16"

@@ -445,30 +445,49 @@ def test_full_size_step_replication_property(arch, C, rep, hw, dt):
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# HIP path straight against the REFERENCE's own numbers (tests/golden/g7_nets.npz, g10_se.npz: the reference's
-# resnet_cifar / resnet_pytorch modules, IIFLoss, torch.optim.SGD and warm-up run by tests/golden/make_golden.py on the
-# seed-7 state dict and the seed-99 batch).  No CPU oracle in the loop, no ReLU-decision replay, no damping.
-REF_NET_CASES = [("g7_nets", "resnet32", "resnet32", 100, 8, 32), ("g7_nets", "resnet50", "resnet50", 1000, 2, 64),
-                 ("g7_nets", "resnext50", "resnext50_32x4d", 365, 2, 64), ("g10_se", "se_resnet32", "se_resnet32", 100, 8, 32),
-                 ("g10_se", "se_resnet50", "se_resnet50", 1000, 2, 64)]
+# HIP path straight against the REFERENCE's own numbers (tests/golden/g7_nets.npz, g10_se.npz, g16_nets_conditioned.npz:
+# the reference's resnet_cifar / resnet_pytorch modules, IIFLoss, torch.optim.SGD and warm-up run by
+# tests/golden/make_golden.py on the seed-7 state dict and the seed-99 batch).  No CPU oracle in the loop, no
+# ReLU-decision replay.  Every fixture also holds the same reference modules run in float64: the distance between the
+# reference's fp32 and fp64 runs is the noise floor of the recipe.
+#   * CIFAR networks (random init, 8 images): noise ~1e-7 -> the whole loss curve is held to 1e-4.
+#   * ImageNet architectures, conditioned input (G16: last BN gain of every bottleneck x0.1, 8 images): noise <= 1e-5 ->
+#     the whole loss curve is held to 1e-4.
+#   * ImageNet architectures at plain random init on 2 images (G7/G10): the reference's own fp32 run is 7e-2..3e-1 from its
+#     fp64 run after ONE SGD step (profiles/r2_reference_fp32_noise.txt): only step 0 is a 1e-4 statement; the later
+#     losses are printed next to the reference's own noise, not asserted.
+REF_NET_CASES = [("g7_nets", "resnet32", "resnet32", 100, 8, 32, None), ("g10_se", "se_resnet32", "se_resnet32", 100, 8, 32, None),
+                 ("g16_nets_conditioned", "resnet50", "resnet50", 1000, 8, 64, 0.1),
+                 ("g16_nets_conditioned", "resnext50", "resnext50_32x4d", 365, 8, 64, 0.1),
+                 ("g16_nets_conditioned", "se_resnet50", "se_resnet50", 1000, 8, 64, 0.1),
+                 ("g7_nets", "resnet50", "resnet50", 1000, 2, 64, None), ("g7_nets", "resnext50", "resnext50_32x4d", 365, 2, 64, None),
+                 ("g10_se", "se_resnet50", "se_resnet50", 1000, 2, 64, None)]
 REF_COUNTS = {100: lambda: O.img_num_per_cls(100, 50000, "exp", 0.01),
               1000: lambda: [int(1280 * (5 / 1280) ** (i / 999.0)) for i in range(1000)],
               365: lambda: [int(4980 * (5 / 4980) ** (i / 364.0)) for i in range(365)]}
 
 
-@pytest.mark.parametrize("fixture,prefix,arch,C,B,hw", REF_NET_CASES, ids=[c[1] for c in REF_NET_CASES])
-def test_hip_step_against_reference_fixture(golden, fixture, prefix, arch, C, B, hw):
-    """fp32 HIP training steps on the reference's inputs vs the reference's outputs:
-    logits of step 0 and the loss of every step within 1e-4 relative (north_star); per-parameter gradient norms of
-    step 0 within 1e-3 (a ReLU pre-activation within ~1e-7 of zero may round to the other sign in two correct fp32
-    implementations, which moves individual gradients by ~1e-3 of their norm at random init on 2-8 images; see
-    DESIGN.md section 2); the weights after the last SGD step (warm-up lr, momentum 0.9, wd 1e-4) within 1e-4."""
+@pytest.mark.parametrize("fixture,prefix,arch,C,B,hw,damp", REF_NET_CASES,
+                         ids=[c[1] + ("_conditioned" if c[6] else "") for c in REF_NET_CASES])
+def test_hip_step_against_reference_fixture(golden, fixture, prefix, arch, C, B, hw, damp):
+    """fp32 HIP training steps on the reference's inputs vs the reference's outputs.
+    Always: logits and loss of step 0 within 1e-4 relative (north_star).  Well-conditioned cases (see above): every
+    later loss within 1e-4, the weights after the last step (per tensor: checksum within 2e-3 of the tensor's L1 norm,
+    plus three times the reference's own fp32-fp64 distance).  Gradient norms of step 0, per parameter: 1e-3 on the
+    well-conditioned cases, 2e-2 at random init on 2 images (a ReLU / max-pool tie that two correct fp32
+    implementations decide differently moves every gradient upstream: the reference's own fp32 run shows 6e-3 there)."""
     import numpy as np
     from iif_amd import resnet_cifar, resnet_pytorch
     from iif_amd.custom import IIFLoss
     g = golden(fixture)
     cifar = arch in R.CIFAR_ARCHS
+    conditioned = cifar or damp is not None
     sd = R.init_cifar(arch, C, seed=7) if cifar else R.init_imagenet(arch, C, seed=7)
+    if damp is not None:
+        assert float(g[prefix + "_damp"]) == damp
+        for k in sd:
+            if k.startswith("layer") and k.endswith("bn3.weight"):
+                sd[k] = sd[k] * damp
     chk = np.array([float(v.double().sum()) for k, v in sd.items() if v.is_floating_point()])
     assert np.allclose(chk, g[prefix + "_init_checksum"], rtol=0, atol=1e-9)          # the reference's initial weights
     gen = torch.Generator().manual_seed(99)
@@ -484,32 +503,45 @@ def test_hip_step_against_reference_fixture(golden, fixture, prefix, arch, C, B,
     net.train()
     crit = IIFLoss(DS(counts), variant="raw")
     xd, yd = x.to(DEV), y.to(DEV)
-    ref_losses = g[prefix + "_losses"]
+    ref_losses, ref_losses64 = g[prefix + "_losses"], g[prefix + "_losses_f64"]
     lr0 = float(g[prefix + "_lr0"])
-    worst_gn = 0.0
+    report = []
     for it in range(len(ref_losses)):
         net.zero_grad()
         logits = net(xd)
         loss = crit(logits, yd)
         loss.backward()
+        dev = abs(loss.item() - ref_losses[it]) / abs(ref_losses[it])
+        report.append((dev, abs(ref_losses[it] - ref_losses64[it]) / abs(ref_losses64[it])))
         if it == 0:
             assert relerr(logits, torch.from_numpy(g[prefix + "_logits0"])) <= 1e-4
-            ref_gn = dict(zip(g[prefix + "_gradnorm_keys"].tolist(), g[prefix + "_gradnorm0"].tolist()))
-            top = max(ref_gn.values())
-            for k, p in net.named_parameters():
-                e = abs(p.grad.double().norm().item() - ref_gn[k]) / max(ref_gn[k], 1e-6 * top)
-                worst_gn = max(worst_gn, e)
-                assert e <= 1e-3, (k, e)
-        assert abs(loss.item() - ref_losses[it]) <= 1e-4 * abs(ref_losses[it]), (it, loss.item(), ref_losses[it])
+            gn32 = g[prefix + "_gradnorm0"]
+            grads = dict(net.named_parameters())
+            tol = 1e-3 if conditioned else 2e-2
+            for k, a32 in zip(g[prefix + "_gradnorm_keys"].tolist(), gn32):
+                mine = grads[k].grad.double().norm().item()
+                assert abs(mine - a32) <= tol * max(a32, 1e-3 * gn32.max()), (k, mine, a32)
+        if it == 0 or conditioned:
+            assert dev <= 1e-4, (it, loss.item(), ref_losses[it], ref_losses64[it])
         net.sgd_step(lr0 * O.warmup_factor(it, 1000), 0.9, 1e-4)
+    print("%s%s: |hip - ref32| / |ref32| per step %s ; reference |fp32 - fp64| / |fp64| %s" % (
+        arch, "" if damp is None else " (conditioned)", ["%.1e" % r[0] for r in report], ["%.1e" % r[1] for r in report]))
+    if not conditioned:
+        return
     final = net.state_dict()
     fc = "linear.weight" if cifar else "fc.weight"
     assert relerr(final[fc][:4].float(), torch.from_numpy(g[prefix + "_final_fc"])) <= 1e-4
     assert relerr(final["bn1.running_mean"].float(), torch.from_numpy(g[prefix + "_final_bn1_rm"])) <= 1e-4
-    chk = np.array([float(v.double().sum()) for k, v in final.items() if v.is_floating_point()])
-    ref_chk = g[prefix + "_final_checksum"]
-    assert np.all(np.abs(chk - ref_chk) <= 1e-4 * np.maximum(np.abs(ref_chk), 1.0))
-    print("worst gradient-norm deviation %s: %.2e" % (arch, worst_gn))
+    fl = [(k, v) for k, v in final.items() if v.is_floating_point()]
+    chk = np.array([float(v.double().sum()) for _, v in fl])
+    l1 = np.array([float(v.double().abs().sum()) for _, v in fl])
+    c32, c64 = g[prefix + "_final_checksum"], g[prefix + "_final_checksum_f64"]
+    # 2e-3 of the L1 norm: weights move by ~1e-4 of themselves in these steps, so this only bites on the zero-initialised
+    # BN biases, which are pure accumulated gradients (per-step gradient agreement 1e-3, a single ReLU tie decided the
+    # other way shows up at 2e-4..8e-4 per tensor: scripts/dbg_se_precision.py, profiles/r2_relu_tie_evidence.txt)
+    bad = [(fl[i][0], chk[i], c32[i], c64[i]) for i in range(len(fl))
+           if abs(chk[i] - c32[i]) > 2e-3 * max(l1[i], 1e-3) + 3.0 * abs(c32[i] - c64[i])]
+    assert not bad, bad[:3]
 
 
 def test_module_surface_does_not_alias_and_refuses_stale_backward():
