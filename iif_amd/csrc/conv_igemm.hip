@@ -408,7 +408,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 // so the tap / channel-chunk displacement is a wave-uniform SCALAR (the buffer instruction's soffset) and
 // the per-lane voffset (pixel base + this lane's chunk) never changes: address generation costs ~3 VALU
 // instructions per row per step (a tap-validity bit test), instead of the general per-piece arithmetic.
-template <typename T, int BN, bool OUTF32, bool UTAP, int NW = 4>
+template <typename T, int BN, bool OUTF32, bool UTAP, int NW = 4, bool SHORTK = false>
 __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned src_bytes, unsigned wgt_bytes) {
     // NW waves, each 64 pixels x BN/2 channels: 128 x BN (4 waves) or 256 x 128 (8 waves).  The larger tile moves
     // 12 instead of 16 KB through the vector L1 per MFLOP: the stamps (scripts/conv_stamps.py) show the 4-wave
@@ -421,7 +421,14 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     constexpr int STAGE = (BM + BN) * 64;
     constexpr int LPS = 2 + NBI;        // DMA instructions per wave per stage
     constexpr unsigned OOB = UTAP ? 0x80000000u : 0xfffffff0u;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE];
+    // SHORTK (K <= 2 steps, the 64-channel layers of the 56x56 stage): both steps are fetched up front, nothing is ever
+    // refilled, so two stages are enough and the block fits 4 times per CU (LDS 34 KB = the epilogue's staging tile,
+    // <= 128 registers) instead of 3: one more tile's loads and stores in flight per CU for these purely
+    // bandwidth-bound launches.
+    constexpr int NST = SHORTK ? 2 : 3;
+    constexpr int STG_BYTES = BM * (BN * 2 + 16);            // conv_epilogue_staged parks the bf16 tile here
+    constexpr int SMEM_BYTES = NST * STAGE > STG_BYTES || sizeof(T) != 2 || OUTF32 ? NST * STAGE : STG_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -648,10 +655,15 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     };
     if (nk > 0) issue(S0{});
     if (nk > 1) { advance(); issue(S1{}); }
-    for (int k = 0; k < nk; k += 3) {
-        step(S0{}, S2{}, k);
-        if (k + 1 < nk) step(S1{}, S0{}, k + 1);
-        if (k + 2 < nk) step(S2{}, S1{}, k + 2);
+    if constexpr (SHORTK) {                       // nk <= 2 (host guarantees): step() never refills (k + 2 >= nk)
+        if (nk > 0) step(S0{}, S0{}, 0);          // nk == 0: a stride-2 parity class without taps (epilogue only)
+        if (nk > 1) step(S1{}, S0{}, 1);
+    } else {
+        for (int k = 0; k < nk; k += 3) {
+            step(S0{}, S2{}, k);
+            if (k + 1 < nk) step(S1{}, S0{}, k + 1);
+            if (k + 2 < nk) step(S2{}, S1{}, k + 2);
+        }
     }
 #ifdef IIF_CONV_STAMPS
     unsigned long long st_loop_end, st_end;
@@ -684,6 +696,11 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs a, unsigne
 template <typename T, int BN, bool OUTF32>
 __global__ void __launch_bounds__(256) conv_igemm_dma_utap_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     conv_igemm_dma_body<T, BN, OUTF32, true>(a, src_bytes, wgt_bytes);
+}
+// K <= 64 (two K steps): 4 blocks per CU (see SHORTK)
+template <int BN>
+__global__ void __launch_bounds__(256, 4) conv_igemm_dma_utap_k64_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+    conv_igemm_dma_body<unsigned short, BN, false, true, 4, true>(a, src_bytes, wgt_bytes);
 }
 
 
@@ -873,6 +890,288 @@ __global__ void __launch_bounds__(512) conv_igemm_dma_utap256_kernel(ConvArgs a,
     conv_igemm_dma_body<T, 128, OUTF32, true, 8>(a, src_bytes, wgt_bytes);
 }
 
+// ---------------------------------------------------------------- streaming 1x1 GEMM, weights resident in LDS
+// dst[M, N] = src[M, K] * wgt[N, K]^T for the bandwidth-bound 1x1 / stride-1 layers (56x56 and 28x28 stages: M = 0.2-0.8 M
+// pixels, K, N <= 256): forward and data gradient.  The tile kernels above spend most of a short-K tile outside the
+// multiply (prologue, one exposed load latency, epilogue) and re-read the activation tile once per 128-channel N tile;
+// in the step these launches ran at 2.3-3.1 TB/s.  Here:
+//   * persistent blocks (one per CU, 8 waves), the whole weight matrix stays in LDS (<= 64 KB), every activation row
+//     is read exactly once;
+//   * 4 COMPUTE waves, each owning 32 rows of the 128-row tile and ALL N channels: a wave multiplies only rows its own
+//     LDS-DMA fetched, so the K loop has no barrier at all, only counted vmcnt waits on a private ring of R K-slabs
+//     (16 rows x 64 B pieces) that runs continuously across tiles: the next tiles' rows are in flight during the
+//     epilogue of the current one;
+//   * 4 STORE waves drain the previous tile from an LDS staging buffer (16 B per lane, whole lines; residual add,
+//     ReLU-bit masks, forward BN statistics or upstream BN-backward sums as in conv_epilogue_staged) while the
+//     compute waves multiply the next one.  Two block-wide barriers per tile hand the staging buffer over.
+// Compute waves issue no vector-memory instruction besides their DMA, so the vmcnt arithmetic is exact; the store
+// waves' loads and stores live on their own counters.
+template <int BN, int KMAX>
+__global__ void __launch_bounds__(512) gemm1x1_stream_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+    constexpr int BM = 128, R = 6, CI = BN / 16;
+    constexpr int WBYTES = KMAX * BN * 2;                 // resident weights: K/32 slabs of [BN rows x 64 B]
+    constexpr int RING = 4 * R * 2048;                    // per compute wave: R slabs of its 32 rows x 64 B
+    constexpr int PITCH = BN * 2 + 16;
+    constexpr int CPR = BN / 8, RPP = 256 / CPR;
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[WBYTES + RING + BM * PITCH + 4 * 2 * BN * 4];
+    unsigned char* const wl = smem;
+    unsigned char* const ring = smem + WBYTES;
+    unsigned char* const stage = ring + RING;
+    float* const scratch = reinterpret_cast<float*>(stage + BM * PITCH);          // [4 store waves][2][BN]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = a.Cs / 32;
+    const int my_tiles = ((int)a.mtiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src), 0, src_bytes, 0x00020000);
+    const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wgt), 0, wgt_bytes, 0x00020000);
+    const int prow = lane >> 2;
+    const int chunk = (lane & 3) ^ swz(prow);
+
+    // ---- resident weights: slab ks, 16-row piece p -> wl + ks * BN * 64 + p * 1024; all 8 waves fetch
+    {
+        const int pieces = nk * (BN / 16);
+        for (int q = wave; q < pieces; q += 8) {
+            const int ks = q / (BN / 16), p = q - ks * (BN / 16);
+            const int n = p * 16 + prow;
+            const unsigned off = n < a.Cd ? ((unsigned)n * (unsigned)a.ldw + (unsigned)(ks * 32 + chunk * 8)) * 2u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)(wl + q * 1024), 16, off, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (my_tiles <= 0) return;
+
+    if (wave < 4) {
+        // ================================================================= compute waves
+        const int cw = wave;
+        unsigned char* const myring = ring + cw * R * 2048;
+        const int fr = lane & 15, fc = lane >> 4;
+        const int total = my_tiles * nk;
+        // issue state: slab gi = (tile ij, K slab iks)
+        int gi = 0, ij = 0, iks = 0;
+        unsigned vb[2];
+        auto tile_rows = [&](int j) {
+            const int m0 = ((int)blockIdx.x + j * (int)gridDim.x) * BM + cw * 32;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = m0 + i * 16 + prow;
+                vb[i] = m < a.M ? ((unsigned)m * (unsigned)a.spitch + (unsigned)(chunk * 8)) * 2u : OOB;
+            }
+        };
+        tile_rows(0);
+        auto issue_next = [&]() {
+            unsigned char* dstl = myring + (gi % R) * 2048;
+            const unsigned soff = (unsigned)iks * 64u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(dstl + i * 1024), 16, vb[i], soff, 0, 0);
+            ++gi;
+            if (++iks == nk) { iks = 0; ++ij; if (ij < my_tiles) tile_rows(ij); }
+        };
+        for (int q = 0; q < R - 1 && gi < total; ++q) issue_next();
+        // fragment offsets
+        int xo[2], wo[CI];
+#pragma unroll
+        for (int pj = 0; pj < 2; ++pj) { const int row = pj * 16 + fr; xo[pj] = row * 64 + ((fc ^ swz(row)) << 4); }
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) { const int row = ci * 16 + fr; wo[ci] = row * 64 + ((fc ^ swz(row)) << 4); }
+        int g = 0;
+#ifdef IIF_CONV_STAMPS
+        unsigned long long t_wait = 0, t_mfma = 0, t_ba = 0, t_stage = 0, t_bb = 0, t0s, t1s, t2s, t3s, t4s, t_begin;
+        IIF_STAMP(t_begin);
+#endif
+        for (int j = 0; j < my_tiles; ++j) {
+            f32x4 acc[CI][2];
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) { acc[ci][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ci][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int ks = 0; ks < nk; ++ks, ++g) {
+                // slabs g+1 .. g+R-2 may stay in flight (2 DMA instructions each); near the end fewer were issued
+#ifdef IIF_CONV_STAMPS
+                IIF_STAMP(t0s);
+#endif
+                if (gi >= g + R - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (R - 2)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef IIF_CONV_STAMPS
+                IIF_STAMP(t1s); t_wait += t1s - t0s;
+#endif
+                const unsigned char* xs = myring + (g % R) * 2048;
+                const unsigned char* ws = wl + ks * (BN * 64);
+                const u32x4 x0 = *reinterpret_cast<const u32x4*>(xs + xo[0]);
+                const u32x4 x1 = *reinterpret_cast<const u32x4*>(xs + xo[1]);
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) {
+                    const u32x4 wf = *reinterpret_cast<const u32x4*>(ws + wo[ci]);
+                    acc[ci][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, x0), acc[ci][0], 0, 0, 0);
+                    acc[ci][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, x1), acc[ci][1], 0, 0, 0);
+                }
+                // refill the slot read in the previous step (its fragments were consumed by that step's MFMAs)
+                if (gi < total) issue_next();
+#ifdef IIF_CONV_STAMPS
+                IIF_STAMP(t2s); t_mfma += t2s - t1s;
+#endif
+            }
+#ifdef IIF_CONV_STAMPS
+            IIF_STAMP(t2s);
+#endif
+            __builtin_amdgcn_s_barrier();                 // A: the store waves have drained tile j-1
+#ifdef IIF_CONV_STAMPS
+            IIF_STAMP(t3s); t_ba += t3s - t2s;
+#endif
+#pragma unroll
+            for (int pj = 0; pj < 2; ++pj)
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) {
+                    const int row = cw * 32 + pj * 16 + fr, ch = ci * 16 + fc * 4;
+                    u32x2 w;
+                    w.x = pack_bf16x2(acc[ci][pj].x, acc[ci][pj].y);
+                    w.y = pack_bf16x2(acc[ci][pj].z, acc[ci][pj].w);
+                    *reinterpret_cast<u32x2*>(stage + row * PITCH + ch * 2) = w;
+                }
+#ifdef IIF_CONV_STAMPS
+            IIF_STAMP(t4s); t_stage += t4s - t3s;
+#endif
+            __builtin_amdgcn_s_barrier();                 // B: tile j is staged
+#ifdef IIF_CONV_STAMPS
+            IIF_STAMP(t0s); t_bb += t0s - t4s;
+#endif
+        }
+        __builtin_amdgcn_s_barrier();                     // C: the store waves' last per-wave sums are in scratch
+#ifdef IIF_CONV_STAMPS
+        IIF_STAMP(t1s);
+        if (g_stamps && blockIdx.x < 256 && lane == 0 && cw == 0) {
+            unsigned long long* o = g_stamps + ((int64_t)blockIdx.x * 4 + 0) * 8;
+            o[0] = t_wait; o[1] = t_mfma; o[2] = t_ba; o[3] = t_stage; o[4] = t_bb; o[5] = t1s - t_begin; o[6] = (unsigned long long)my_tiles; o[7] = t_begin;
+        }
+#endif
+        return;
+    }
+
+    // ===================================================================== store waves
+    const int ts = tid - 256, sw = wave - 4;
+    const int chk = ts % CPR, r0 = ts / CPR;
+    const int n = chk * 8;
+    const bool stats = a.bn_partial != nullptr;
+    float bmean[8], bistd[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bmean[q] = 0.f; bistd[q] = 0.f; }
+    if (a.bw_x && n < a.Cd) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[n + q]; bistd[q] = a.bw_stats[a.Cd + n + q]; }
+    }
+    // combine the 4 store waves' sums of tile `mt` (already in scratch) into its partial row
+    auto emit_partial = [&](int mt) {
+        if (ts < BN && ts < a.Cd) {
+            float s2 = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s2 += scratch[(w * 2 + 0) * BN + ts]; q2 += scratch[(w * 2 + 1) * BN + ts]; }
+            float* p = a.bn_partial + (int64_t)(a.bn_row0 + mt) * 2 * a.dpitch + ts;
+            p[0] = s2; p[a.dpitch] = q2;
+        }
+    };
+#ifdef IIF_CONV_STAMPS
+    unsigned long long u_bar = 0, u_drain = 0, u_red = 0, u0, u1, u2, u3, u_begin;
+    IIF_STAMP(u_begin);
+#endif
+    for (int j = 0; j < my_tiles; ++j) {
+#ifdef IIF_CONV_STAMPS
+        IIF_STAMP(u0);
+#endif
+        __builtin_amdgcn_s_barrier();                     // A
+        if (stats && j > 0) emit_partial((int)blockIdx.x + (j - 1) * (int)gridDim.x);   // idle window: the compute waves stage tile j
+        __builtin_amdgcn_s_barrier();                     // B
+#ifdef IIF_CONV_STAMPS
+        IIF_STAMP(u1); u_bar += u1 - u0;
+#endif
+        const int mt = (int)blockIdx.x + j * (int)gridDim.x;
+        const int m0 = mt * BM;
+        float bs[8], bq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bs[q] = 0.f; bq[q] = 0.f; }
+        if (n < a.Cd) {
+#pragma unroll 4
+            for (int row = r0; row < BM; row += RPP) {
+                const int m = m0 + row;
+                if (m >= a.M) break;
+                u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * PITCH + chk * 16);
+                const int64_t o = ((int64_t)m * a.dpitch + n) * 2;
+                if (a.res) {
+                    const u32x4 rr = *reinterpret_cast<const u32x4*>(a.res + o);
+                    const unsigned rb = a.res_bits ? a.res_bits[o >> 4] : 0xffu;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16_bits_to_f32(v[q] & 0xffffu) + ((rb >> (2 * q)) & 1u ? bf16_bits_to_f32(rr[q] & 0xffffu) : 0.f);
+                        const float hi = __uint_as_float(v[q] & 0xffff0000u) + ((rb >> (2 * q + 1)) & 1u ? __uint_as_float(rr[q] & 0xffff0000u) : 0.f);
+                        v[q] = pack_bf16x2(lo, hi);
+                    }
+                }
+                *reinterpret_cast<u32x4*>(a.dst + o) = v;
+                if (a.bw_x) {
+                    const u32x4 xv = *reinterpret_cast<const u32x4*>(a.bw_x + o);
+                    const unsigned mb = a.bw_bits ? a.bw_bits[o >> 4] : 0xffu;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float glo = (mb >> (2 * q)) & 1u ? bf16_bits_to_f32(v[q] & 0xffffu) : 0.f;
+                        const float ghi = (mb >> (2 * q + 1)) & 1u ? __uint_as_float(v[q] & 0xffff0000u) : 0.f;
+                        const float xlo = (bf16_bits_to_f32(xv[q] & 0xffffu) - bmean[2 * q]) * bistd[2 * q];
+                        const float xhi = (__uint_as_float(xv[q] & 0xffff0000u) - bmean[2 * q + 1]) * bistd[2 * q + 1];
+                        bs[2 * q] += glo; bq[2 * q] += glo * xlo;
+                        bs[2 * q + 1] += ghi; bq[2 * q + 1] += ghi * xhi;
+                    }
+                } else if (stats) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16_bits_to_f32(v[q] & 0xffffu), hi = __uint_as_float(v[q] & 0xffff0000u);
+                        bs[2 * q] += lo; bq[2 * q] = fmaf(lo, lo, bq[2 * q]);
+                        bs[2 * q + 1] += hi; bq[2 * q + 1] = fmaf(hi, hi, bq[2 * q + 1]);
+                    }
+                }
+            }
+        }
+#ifdef IIF_CONV_STAMPS
+        IIF_STAMP(u2); u_drain += u2 - u1;
+#endif
+        if (stats) {
+            // lanes of a wave that share the chunk, then one row of sums per store wave (combined after the next barrier)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int o = CPR; o < 64; o <<= 1) { bs[q] += __shfl_xor(bs[q], o, 64); bq[q] += __shfl_xor(bq[q], o, 64); }
+            }
+            if (lane < CPR) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    scratch[(sw * 2 + 0) * BN + lane * 8 + q] = bs[q];
+                    scratch[(sw * 2 + 1) * BN + lane * 8 + q] = bq[q];
+                }
+            }
+        }
+    }
+#ifdef IIF_CONV_STAMPS
+    IIF_STAMP(u3);
+    if (g_stamps && blockIdx.x < 256 && lane == 0 && sw == 0) {
+        unsigned long long* o = g_stamps + ((int64_t)blockIdx.x * 4 + 1) * 8;
+        o[0] = u_bar; o[1] = u_drain; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = u3 - u_begin; o[6] = (unsigned long long)my_tiles; o[7] = u_begin;
+    }
+#endif
+    __builtin_amdgcn_s_barrier();                         // C
+    if (stats) emit_partial((int)blockIdx.x + (my_tiles - 1) * (int)gridDim.x);
+}
+
+inline bool use_stream1x1(const ConvArgs& a, bool utap, int esz, bool outf32, int* bn, int* kmax) {
+    const char* off = getenv("IIF_CONV_NO_STREAM1X1");                        // read per call: A/B runs toggle it
+    if (off || !utap || esz != 2 || outf32 || a.groups > 1 || a.scatter || a.in_shift != 0 || a.sshift != 0) return false;
+    if (a.R != 1 || a.S != 1 || a.pad != 0 || a.ntaps != 1 || a.bias) return false;
+    if (a.Hs != a.Hd || a.Ws != a.Wd || (a.Cs % 32) || a.spitch != a.Cs || a.dpitch != a.Cd) return false;
+    if (a.Cd == 256 && a.Cs <= 64) { *bn = 256; *kmax = 64; }
+    else if (a.Cd == 128 && a.Cs <= 256) { *bn = 128; *kmax = 256; }
+    else if (a.Cd == 64 && a.Cs <= 256) { *bn = 64; *kmax = 256; }
+    else return false;
+    const char* force = getenv("IIF_CONV_STREAM1X1_FORCE");                   // tests: small grids too (read per call)
+    return force || (a.M + 127) / 128 >= 1024;                                // >= 4 tiles per persistent block
+}
+
 // 256-pixel tiles: bf16 uniform-tap launches wide enough for the 128-channel tile whose 256-row grid still fills
 // the chip (2 blocks per CU resident).  IIF_CONV_BM=128|256 forces a choice (experiments).
 inline bool use_bm256(const ConvArgs& a, bool utap, int esz) {
@@ -927,6 +1226,24 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
         IIF_LAUNCH_CHECK();
         return IIF_OK;
     }
+    int sbn = 0, skmax = 0;
+    if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_stream1x1(a, utap, (int)sizeof(T), OUTF32, &sbn, &skmax)) {
+        a.mtiles = (a.M + 127) / 128;
+        a.ntiles = 1;
+        if (const int rc = claim_partial_rows(a)) return rc;
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+            return n > 0 ? n : 256;
+        }();
+        const unsigned grid = (unsigned)(a.mtiles < cus ? a.mtiles : cus);
+        const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
+        if (sbn == 256) hipLaunchKernelGGL((gemm1x1_stream_kernel<256, 64>), dim3(grid), dim3(512), 0, st, a, sb, wb);
+        else if (sbn == 128) hipLaunchKernelGGL((gemm1x1_stream_kernel<128, 256>), dim3(grid), dim3(512), 0, st, a, sb, wb);
+        else hipLaunchKernelGGL((gemm1x1_stream_kernel<64, 256>), dim3(grid), dim3(512), 0, st, a, sb, wb);
+        IIF_LAUNCH_CHECK();
+        return IIF_OK;
+    }
     if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_bm256(a, utap, (int)sizeof(T))) {
         a.mtiles = (a.M + 255) / 256;
         a.ntiles = (a.Cd + 127) / 128;
@@ -955,6 +1272,16 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
     if (dma) {
         const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
         if (utap) {
+            const bool shortk = sizeof(T) == 2 && !OUTF32 && a.ntaps * (a.Cs / ET<T>::KE) <= 2 && (a.Cd & 7) == 0 && !a.bias &&
+                                getenv("IIF_CONV_NO_SHORTK") == nullptr;
+            if constexpr (sizeof(T) == 2 && !OUTF32) {
+                if (shortk) {
+                    if (narrow) hipLaunchKernelGGL((conv_igemm_dma_utap_k64_kernel<64>), grid, blk, 0, st, a, sb, wb);
+                    else hipLaunchKernelGGL((conv_igemm_dma_utap_k64_kernel<128>), grid, blk, 0, st, a, sb, wb);
+                    IIF_LAUNCH_CHECK();
+                    return IIF_OK;
+                }
+            }
             if (narrow) hipLaunchKernelGGL((conv_igemm_dma_utap_kernel<T, 64, OUTF32>), grid, blk, 0, st, a, sb, wb);
             else hipLaunchKernelGGL((conv_igemm_dma_utap_kernel<T, 128, OUTF32>), grid, blk, 0, st, a, sb, wb);
         } else {

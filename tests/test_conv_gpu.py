@@ -392,3 +392,89 @@ def test_stem_s2d_weight_gradient_all_taps_per_block(n, h, w):
     for splits in (0, 1, 5):
         dw = ops.conv_wgrad(x.to(DEV), dy.to(DEV), 4, 4, 1, 2, workspace=ws, splits=splits)
         assert (dw.double().cpu() - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-6), (n, h, w, splits)
+
+
+# ------------------------------------------------------------------------------------------- streaming 1x1 kernel
+STREAM_CASES = [  # N, Cin, H, W, Cout : the three instantiations, ragged last tile, fewer tiles than blocks, many tiles per block
+    (3, 64, 20, 23, 256), (2, 256, 17, 19, 64), (2, 256, 24, 24, 128), (1, 64, 9, 7, 64), (2, 32, 40, 40, 256),
+    (5, 128, 12, 12, 64), (40, 64, 56, 56, 256), (37, 256, 56, 56, 64),
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES)
+def test_stream1x1_forward_stats_and_dgrad_epilogues(case, monkeypatch):
+    """gemm1x1_stream_kernel (persistent, weights resident in LDS, compute / store wave groups) forced onto small
+    grids: forward + fused BN statistics, data gradient with a ReLU-masked residual, data gradient with the upstream
+    BN-backward sums — each against torch and BIT-IDENTICAL in the stored tensor to the tile kernels it replaces."""
+    from iif_amd import ops
+    n, cin, h, w, cout = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout)
+    m = n * h * w
+    x = torch.randn(m, cin, generator=g).to(dt)
+    wt = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(dt)
+    xd = x.view(n, h, w, cin).to(DEV)
+    wd = wt.to(DEV)
+    ref = x.float() @ wt.float().t()
+
+    def run(force):
+        if force:
+            monkeypatch.setenv("IIF_CONV_STREAM1X1_FORCE", "1")
+            monkeypatch.delenv("IIF_CONV_NO_STREAM1X1", raising=False)
+        else:
+            monkeypatch.delenv("IIF_CONV_STREAM1X1_FORCE", raising=False)
+            monkeypatch.setenv("IIF_CONV_NO_STREAM1X1", "1")
+        out = torch.full((n, h, w, cout), float("nan"), dtype=dt, device=DEV)
+        partial = torch.full((((m + 127) // 128) * 2 * cout,), float("nan"), device=DEV)
+        nt = ops.conv_forward_bnstats(xd, wd, 1, 1, 1, 0, out, partial)
+        return out, partial, nt
+    out_s, part_s, nt_s = run(True)
+    out_t, part_t, nt_t = run(False)
+    assert nt_s == (m + 127) // 128
+    assert (out_s.float().cpu().view(m, cout) - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    assert torch.equal(out_s, out_t)                                  # same fp32 accumulation order per element
+    sums_s = part_s[:nt_s * 2 * cout].view(nt_s, 2, cout).sum(0)
+    stored = out_s.float().view(m, cout)
+    assert not torch.isnan(sums_s).any()
+    assert (sums_s[0] - stored.sum(0)).abs().max().item() <= 2e-6 * max(1.0, stored.sum(0).abs().max().item()) * 8
+    assert (sums_s[1] - (stored * stored).sum(0)).abs().max().item() <= 2e-5 * (stored * stored).sum(0).abs().max().item()
+    if nt_t == nt_s:
+        assert (part_s[:nt_s * 2 * cout] - part_t[:nt_s * 2 * cout]).abs().max().item() <= 1e-4 * part_t[:nt_s * 2 * cout].abs().max().item()
+
+    # data gradient dX[m, cin] = dY[m, cout] @ W, with the masked residual, then with the upstream BN-backward sums
+    dy = torch.randn(m, cout, generator=g).to(dt)
+    res = torch.randn(m, cin, generator=g).to(dt)
+    pre = torch.randn(m, cin, generator=g).to(dt)
+    upx = torch.randn(m, cin, generator=g).to(dt)
+    st_id = torch.zeros(4, cin); st_id[2] = 1.0
+    y = torch.empty(m, cin, dtype=dt, device=DEV)
+    bits = torch.empty(m * cin // 8, dtype=torch.uint8, device=DEV)
+    ops.bn_apply(pre.to(DEV), st_id.to(DEV), y, relu=True, relu_bits=bits)
+    wtt = torch.zeros(cin, (cout + 15) // 16 * 16, dtype=dt, device=DEV)
+    ops.weight_transpose(wt.float().to(DEV), cout, cin, 1, wtt)
+    dyd = dy.view(n, h, w, cout).to(DEV)
+    refdx = dy.float() @ wt.float() + res.float() * (pre.float() > 0)
+    stats = torch.zeros(4, cin)
+    stats[0] = torch.randn(cin, generator=g) * 0.1
+    stats[1] = torch.rand(cin, generator=g) + 0.5
+    got = {}
+    for force in (True, False):
+        if force:
+            monkeypatch.setenv("IIF_CONV_STREAM1X1_FORCE", "1"); monkeypatch.delenv("IIF_CONV_NO_STREAM1X1", raising=False)
+        else:
+            monkeypatch.delenv("IIF_CONV_STREAM1X1_FORCE", raising=False); monkeypatch.setenv("IIF_CONV_NO_STREAM1X1", "1")
+        dx = ops.conv_dgrad(dyd, wtt, 1, 1, 1, 0, (h, w), res=res.view(n, h, w, cin).to(DEV), res_bits=bits)
+        out2 = torch.full((n, h, w, cin), float("nan"), dtype=dt, device=DEV)
+        partial = torch.full(((m + 127) // 128 + 8, 2, cin), float("nan"), device=DEV)
+        nt = ops.conv_dgrad_bnbwd(dyd, wtt, 1, 1, 1, 0, (h, w), out2, upx.view(n, h, w, cin).to(DEV), bits, stats.to(DEV),
+                                  partial.view(-1))
+        got[force] = (dx, out2, partial[:nt].sum(0).cpu(), nt)
+    dx_s, out2_s, ps, nt = got[True]
+    assert (dx_s.float().cpu().view(m, cin) - refdx).abs().max().item() <= 2.0 ** -7 * refdx.abs().max().item()
+    assert torch.equal(dx_s, got[False][0]) and torch.equal(out2_s, got[False][1])
+    gq = out2_s.float().cpu().view(m, cin) * (pre.float() > 0)
+    xhat = (upx.float() - stats[0]) * stats[1]
+    s1, s2 = gq.sum(0), (gq * xhat).sum(0)
+    assert not torch.isnan(ps).any() and nt == (m + 127) // 128
+    assert (ps[0] - s1).abs().max().item() <= 2e-6 * max(1.0, s1.abs().max().item()) * 8
+    assert (ps[1] - s2).abs().max().item() <= 2e-6 * max(1.0, s2.abs().max().item()) * 8
