@@ -421,10 +421,13 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     constexpr int STAGE = (BM + BN) * 64;
     constexpr int LPS = 2 + NBI;        // DMA instructions per wave per stage
     constexpr unsigned OOB = UTAP ? 0x80000000u : 0xfffffff0u;
-    // SHORTK (K <= 2 steps, the 64-channel layers of the 56x56 stage): both steps are fetched up front, nothing is ever
-    // refilled, so two stages are enough and the block fits 4 times per CU (LDS 34 KB = the epilogue's staging tile,
-    // <= 128 registers) instead of 3: one more tile's loads and stores in flight per CU for these purely
-    // bandwidth-bound launches.
+    // SHORTK: two LDS stages instead of three, so the block fits 4 times per CU (LDS 34 KB = the epilogue's staging
+    // tile, <= 128 registers) instead of 3: one more tile's loads and stores in flight per CU.  With K <= 2 steps
+    // (the 64-channel layers of the 56x56 stage) nothing is ever refilled; longer K loops pay a second barrier per step
+    // (the stage that was just read is the one refilled).  Used for K <= 2304 (everything the halo / 256-row kernels do
+    // not take): measured +18..21 % on the 64-channel 1x1 layers alone (scripts/bm_stream1x1.py), -15 % on 28x28
+    // 128->512, -10 % on 14x14 256->1024, -8 % on the 56x56 3x3 layers, nothing slower by more than 1 %; forward + data
+    // gradient launches of a ResNet50 step 11.01 -> 10.60 ms serialised.
     constexpr int NST = SHORTK ? 2 : 3;
     constexpr int STG_BYTES = BM * (BN * 2 + 16);            // conv_epilogue_staged parks the bf16 tile here
     constexpr int SMEM_BYTES = NST * STAGE > STG_BYTES || sizeof(T) != 2 || OUTF32 ? NST * STAGE : STG_BYTES;
@@ -632,7 +635,14 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
         IIF_STAMP(t2);
 #endif
         // the refill DMA is issued behind the fragment reads, so its issue time covers their LDS latency
-        if (k + 2 < nk) { advance(); issue(refill_c); }
+        if (k + 2 < nk) {
+            if constexpr (SHORTK) {
+                // two stages: the stage just read is the one refilled, so every wave must hold its fragments first
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            advance(); issue(refill_c);
+        }
 #ifdef IIF_CONV_STAMPS
         IIF_STAMP(t3);
         st_wait += t1 - t0; st_lds += t2 - t1; st_dma += t3 - t2; st_prev = t3;
@@ -655,9 +665,11 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     };
     if (nk > 0) issue(S0{});
     if (nk > 1) { advance(); issue(S1{}); }
-    if constexpr (SHORTK) {                       // nk <= 2 (host guarantees): step() never refills (k + 2 >= nk)
-        if (nk > 0) step(S0{}, S0{}, 0);          // nk == 0: a stride-2 parity class without taps (epilogue only)
-        if (nk > 1) step(S1{}, S0{}, 1);
+    if constexpr (SHORTK) {                       // two stages: step k reads stage k & 1 and refills it with step k + 2
+        for (int k = 0; k < nk; k += 2) {
+            step(S0{}, S0{}, k);
+            if (k + 1 < nk) step(S1{}, S1{}, k + 1);
+        }
     } else {
         for (int k = 0; k < nk; k += 3) {
             step(S0{}, S2{}, k);
@@ -1169,7 +1181,12 @@ inline bool use_stream1x1(const ConvArgs& a, bool utap, int esz, bool outf32, in
     else if (a.Cd == 64 && a.Cs <= 256) { *bn = 64; *kmax = 256; }
     else return false;
     const char* force = getenv("IIF_CONV_STREAM1X1_FORCE");                   // tests: small grids too (read per call)
-    return force || (a.M + 127) / 128 >= 1024;                                // >= 4 tiles per persistent block
+    if (force) return true;
+    // Measured alone (scripts/bm_stream1x1.py, bs 256): forward 64->256 0.150 -> 0.134 ms, 256->128 0.140 -> 0.117,
+    // 256->64 0.105 -> 0.099 against the 4-blocks-per-CU tile kernel; the data gradients with the upstream BN-backward
+    // sums are SLOWER here (their epilogue loads sit in 4 store waves only: 0.216 -> 0.397 ms), so they stay on the
+    // tile kernels.
+    return !a.transposed && !a.bw_x && (a.M + 127) / 128 >= 1024;             // >= 4 tiles per persistent block
 }
 
 // 256-pixel tiles: bf16 uniform-tap launches wide enough for the 128-channel tile whose 256-row grid still fills
@@ -1256,7 +1273,8 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
         return IIF_OK;
     }
     a.mtiles = (a.M + 127) / 128;
-    const bool narrow = a.Cd <= 64;
+    const char* f64 = getenv("IIF_CONV_FORCE_BN64");       // experiment: 128x64 tiles (4 blocks per CU) for wider outputs too
+    const bool narrow = a.Cd <= 64 || (f64 && a.ntaps * a.Cs <= atoi(f64));
     const int bn = narrow ? 64 : 128;
     a.ntiles = (a.Cd + bn - 1) / bn;
     const int64_t blocks = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
@@ -1272,7 +1290,8 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
     if (dma) {
         const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
         if (utap) {
-            const bool shortk = sizeof(T) == 2 && !OUTF32 && a.ntaps * (a.Cs / ET<T>::KE) <= 2 && (a.Cd & 7) == 0 && !a.bias &&
+            const char* k2 = getenv("IIF_CONV_TWOSTAGE_K");          // two-stage / 4-blocks-per-CU variant up to this K
+            const bool shortk = sizeof(T) == 2 && !OUTF32 && a.ntaps * a.Cs <= (k2 ? atoi(k2) : 2304) && (a.Cd & 7) == 0 && !a.bias &&
                                 getenv("IIF_CONV_NO_SHORTK") == nullptr;
             if constexpr (sizeof(T) == 2 && !OUTF32) {
                 if (shortk) {
