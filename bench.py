@@ -256,6 +256,10 @@ def main():
     ap.add_argument("--event-every", type=int, default=4, help="bracket the conv launches of every n-th timed step")
     ap.add_argument("--trace-loss", action="store_true", help="record the loss of every step (one tiny copy per step)")
     ap.add_argument("--force-reducer", action="store_true", help="drive the bucketed all-reduce path even with one rank")
+    ap.add_argument("--reduce-mode", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="gradient buckets: one all_reduce each, or reduce_scatter + all_gather (iif_amd.ddp)")
+    ap.add_argument("--bf16-buckets", action="store_true",
+                    help="reduce bf16 copies of the gradient buckets (only if the probe on the first gradients stays in tolerance)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo only to rehearse N ranks on one GPU")
     ap.add_argument("--device-index", type=int, default=None, help="put every rank on this GPU (rehearsal only)")
@@ -293,9 +297,22 @@ def main():
     net.train()
     broadcast_parameters(net)
     crit = IIFLoss(_Counts(counts), variant="raw", reduction="mean", device=dev)
-    reducer = net.make_reducer() if (world > 1 or args.force_reducer) else None
+    reducer = net.make_reducer(mode=args.reduce_mode) if (world > 1 or args.force_reducer) else None
     if reducer is not None and args.force_reducer:
         reducer.force = True
+    tail_events = []
+    if reducer is not None:
+        # exposed tail: how long the compute stream sits in reducer.finish() waiting for the last buckets
+        _finish = reducer.finish
+
+        def timed_finish():
+            if not measuring[0]:
+                return _finish()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); _finish(); e1.record()
+            tail_events.append((e0, e1))
+        reducer.finish = timed_finish
+    measuring = [False]
     g = torch.Generator().manual_seed(1234 + rank)
     B = args.batch
     x = torch.randn(B, 3, args.image, args.image, generator=g).to(dev)
@@ -318,8 +335,21 @@ def main():
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
     note("model built (%d params), starting %d warm-up steps" % (sum(p.numel() for p in net.parameters()), args.warmup))
+    bf16_probe = None
     for it in range(args.warmup):
-        step(it)
+        if it == 0 and reducer is not None and args.bf16_buckets:
+            # gradients of the first step stay local: measure what bf16 buckets would do to their average, switch only if
+            # that stays within one bf16 rounding, then reduce this step un-overlapped (as iif_amd.train does)
+            net.loss_and_backward(x, y, crit, reducer=None)
+            bf16_probe = reducer.probe_bf16()
+            try:
+                reducer.set_bucket_dtype(torch.bfloat16)
+            except RuntimeError:
+                note("bf16 buckets refused by the probe (%.2e): staying with fp32" % bf16_probe)
+            reducer.begin(); reducer.finish()
+            net.sgd_step(1e-4, 0.9, 1e-4, grad_scale=scale)
+        else:
+            step(it)
         if it == 0:
             torch.cuda.synchronize()
             note("first step done")
@@ -331,6 +361,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    measuring[0] = True
     t0 = time.perf_counter()
     for it in range(args.steps):
         if timer is not None:
@@ -367,6 +398,14 @@ def main():
                                    "bs=%d/GPU, SGD momentum 0.9 wd 1e-4 with warm-up, random init" % (args.model, args.image, args.image, C, counts[0], B),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4)},
         }
+        if reducer is not None:
+            # what the collective library was asked to do (proof that `world` ranks reduced, and how)
+            rd = reducer.describe()
+            rd["backend"] = args.backend + (" (RCCL over xGMI)" if args.backend == "nccl" else "")
+            rd["exposed_tail_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in tail_events) / max(len(tail_events), 1), 4)
+            if bf16_probe is not None:
+                rd["bf16_probe_rel_l2"] = bf16_probe
+            out["reducer"] = rd
         nsamp = max(timer.sampled_steps, 1) if timer is not None else 1
         if timer is not None and args.per_shape:
             for sh, (cnt, ms, fl) in sorted(timer.per_shape().items(), key=lambda kv: -kv[1][1]):

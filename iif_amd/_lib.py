@@ -34,6 +34,8 @@ SIGNATURES = {
     "iif_conv_wgrad": [_P, _P, _P, _P, _P, _L, _I, _P],
     "iif_conv_igemm_bnstats": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "iif_bn_finalize_stats": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _P],
+    "iif_bn_finalize_stats_fused": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _P, _P],
+    "iif_bn_backward_partials_fused": [_P, _P, _P, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P, _P],
     "iif_bn_workspace_bytes": [_L, _I],
     "iif_bn_forward_stats": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _P],
     "iif_bn_apply": [_P, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P],

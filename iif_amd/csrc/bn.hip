@@ -335,6 +335,94 @@ __global__ void __launch_bounds__(256) bn_partial_reduce_kernel(const float* par
     }
 }
 
+// Both stages in ONE launch.  Stage 1 as bn_partial_reduce_kernel (slice blockIdx.y, 32 channels blockIdx.x); the slice
+// sums are published with agent-scope atomic exchanges (performed at the coherence point; a returning atomic has
+// completed when its value is back), then the block takes a ticket of its channel group; the block that draws the last
+// ticket reads all slices back with agent-scope atomic loads, sums them in slice order (double) and finalises its 32
+// channels.  No fence: an agent-scope release would write back the whole L2 (measured on the IIF loss kernel: 40 % of
+// its time), the ordinary stores of this kernel need no ordering at all.  tickets: int32[>= gridDim.x], zero on entry,
+// zero again on exit.  MODE 0: forward statistics (+ running statistics), MODE 1: backward sums -> dgamma, dbeta, coef.
+template <int MODE>
+__global__ void __launch_bounds__(256) bn_reduce_finalize_kernel(const float* partial, int nblk, int C, int rows_per_slice,
+                                                                 float* slices_out, int* tickets, double count,
+                                                                 const float* gamma, const float* beta_or_stats, float eps,
+                                                                 float momentum, float* o0, float* o1, float* o2) {
+    __shared__ double sh[512];
+    __shared__ int last;
+    const int cl = threadIdx.x & 31, ln = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int r0 = blockIdx.y * rows_per_slice;
+    int r1 = r0 + rows_per_slice; if (r1 > nblk) r1 = nblk;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        int r = r0 + ln;
+        for (; r + 24 < r1; r += 32) {                  // 4 rows in flight per lane, sums in row order
+            const float a0 = partial[(int64_t)r * 2 * C + c], b0 = partial[(int64_t)r * 2 * C + C + c];
+            const float a1 = partial[(int64_t)(r + 8) * 2 * C + c], b1 = partial[(int64_t)(r + 8) * 2 * C + C + c];
+            const float a2 = partial[(int64_t)(r + 16) * 2 * C + c], b2 = partial[(int64_t)(r + 16) * 2 * C + C + c];
+            const float a3 = partial[(int64_t)(r + 24) * 2 * C + c], b3 = partial[(int64_t)(r + 24) * 2 * C + C + c];
+            a += a0; a += a1; a += a2; a += a3;
+            b += b0; b += b1; b += b2; b += b3;
+        }
+        for (; r < r1; r += 8) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
+    }
+    sh[ln * 32 + cl] = a; sh[256 + ln * 32 + cl] = b;
+    __syncthreads();
+    if (ln == 0) {                                      // threads 0..31: one wave
+        float keep = 0.f;
+        if (c < C) {
+            double s = 0.0, q = 0.0;
+            for (int j = 0; j < 8; ++j) { s += sh[j * 32 + cl]; q += sh[256 + j * 32 + cl]; }
+            float* o = slices_out + (int64_t)blockIdx.y * 2 * C + c;
+            keep = __hip_atomic_exchange(o, (float)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            keep += __hip_atomic_exchange(o + C, (float)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : : "v"(keep) : "memory");       // every lane's exchanges have returned
+        if (threadIdx.x == 0) {
+            const int t = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (t == (int)gridDim.y - 1);
+        }
+    }
+    __syncthreads();
+    if (!last) return;
+    // ---- the last block of this channel group: slices in order, 8 lanes x 32 channels
+    const int ns = (int)gridDim.y;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int j = ln; j < ns; j += 8) {
+            s += (double)__hip_atomic_load(slices_out + (int64_t)j * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q += (double)__hip_atomic_load(slices_out + (int64_t)j * 2 * C + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    __syncthreads();
+    sh[ln * 32 + cl] = s; sh[256 + ln * 32 + cl] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ln != 0 || c >= C) return;
+    s = 0.0; q = 0.0;
+    for (int j = 0; j < 8; ++j) { s += sh[j * 32 + cl]; q += sh[256 + j * 32 + cl]; }
+    if (MODE == 0) {                                    // o0 = stats[4][C], o1 / o2 = running mean / var (nullable)
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float ga = gamma[c], be = beta_or_stats[c];
+        const float k = ga * invstd;
+        o0[c] = (float)mean; o0[C + c] = invstd; o0[2 * C + c] = k; o0[3 * C + c] = be - (float)mean * k;
+        if (o1) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            o1[c] = (1.f - momentum) * o1[c] + momentum * (float)mean;
+            o2[c] = (1.f - momentum) * o2[c] + momentum * (float)unbiased;
+        }
+    } else {                                            // o0 = dgamma, o1 = dbeta, o2 = coef[3][C]
+        const float ga = gamma[c], invstd = beta_or_stats[C + c];
+        o0[c] = (float)q;
+        o1[c] = (float)s;
+        o2[c] = ga * invstd;
+        o2[C + c] = (float)(s / count);
+        o2[2 * C + c] = (float)(q / count) * invstd;
+    }
+}
+
 // partial rows above which the sums are pre-reduced into 64 slices by a separate launch
 inline int two_stage_rows() {
     static const int v = getenv("IIF_BN_TWO_STAGE_ROWS") ? atoi(getenv("IIF_BN_TWO_STAGE_ROWS")) : 512;
@@ -396,7 +484,7 @@ int bn_apply_t(const T* x, const float* stats, const T* r, const float* stats2, 
 template <typename T>
 int bn_backward_t(const T* gy, const T* ymask, const unsigned char* bits, const T* x, const float* stats, const float* gamma,
                   int64_t M, int C, float* dgamma, float* dbeta, T* dx, T* gm, float* ws, int64_t ws_bytes, hipStream_t st,
-                  const float* ext_partial = nullptr, int n_ext = 0, bool recompute = false) {
+                  const float* ext_partial = nullptr, int n_ext = 0, bool recompute = false, int* tickets = nullptr) {
     constexpr int V = VT<T>::V;
     Geo g = make_geo(M, C, V, 512);
     const int64_t need = ((int64_t)g.nblk * 2 * C + 3 * C) * 4;
@@ -404,10 +492,19 @@ int bn_backward_t(const T* gy, const T* ymask, const unsigned char* bits, const 
     float* coef = ws + (int64_t)g.nblk * 2 * C;
     const dim3 rgrid(g.nblk, g.colblocks), blk(256);
     const float* fin_src = ws;
+    bool finalized = false;
     if (ext_partial) {
         fin_src = ext_partial;
         g.nblk = n_ext;
-        if (n_ext > two_stage_rows()) {          // many tile rows: 64 slices first (fixed order), as in the forward path
+        if (n_ext > two_stage_rows() && tickets) {   // both stages in one launch (see bn_reduce_finalize_kernel)
+            const int slices = 64, rps = (n_ext + slices - 1) / slices;
+            if ((int64_t)(slices * 2 * C + 3 * C) * 4 > ws_bytes || (C + 31) / 32 > 64) return IIF_EINVAL;
+            coef = ws + (int64_t)slices * 2 * C;
+            hipLaunchKernelGGL(bn_reduce_finalize_kernel<1>, dim3((C + 31) / 32, slices), blk, 0, st, ext_partial, n_ext, C, rps, ws,
+                               tickets, (double)M, gamma, stats, 0.f, 0.f, dgamma, dbeta, coef);
+            IIF_LAUNCH_CHECK();
+            finalized = true;
+        } else if (n_ext > two_stage_rows()) {   // many tile rows: 64 slices first (fixed order), as in the forward path
             const int slices = 64, rps = (n_ext + slices - 1) / slices;
             if ((int64_t)(slices * 2 * C + 3 * C) * 4 > ws_bytes) return IIF_EINVAL;
             hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 31) / 32, slices), blk, 0, st, ext_partial, n_ext, C, rps, ws);
@@ -422,7 +519,7 @@ int bn_backward_t(const T* gy, const T* ymask, const unsigned char* bits, const 
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
         IIF_LAUNCH_CHECK();
     }
-    {
+    if (!finalized) {
         const int cb = finalize_cb(g.nblk);
         const dim3 fgrid((C + cb - 1) / cb);
         if (cb == 4) hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, fgrid, blk, 0, st, fin_src, g.nblk, C, (double)M, gamma, stats, dgamma, dbeta, coef);
@@ -486,6 +583,20 @@ int iif_bn_finalize_stats(const float* partial, int n_partials, int64_t m, int c
                               stats, st);
 }
 
+int iif_bn_finalize_stats_fused(const float* partial, int n_partials, int64_t m, int c, const float* gamma, const float* beta,
+                                float eps, float momentum, float* running_mean, float* running_var, float* stats,
+                                float* scratch, int64_t scratch_floats, int32_t* tickets, void* stream) {
+    if (!partial || !gamma || !beta || !stats || n_partials <= 0 || m <= 0 || c <= 0) return IIF_EINVAL;
+    if (!tickets || n_partials <= two_stage_rows() || !scratch || scratch_floats < (int64_t)64 * 2 * c || (c + 31) / 32 > 64)
+        return iif_bn_finalize_stats(partial, n_partials, m, c, gamma, beta, eps, momentum, running_mean, running_var, stats,
+                                     scratch, scratch_floats, stream);
+    const int slices = 64, rps = (n_partials + slices - 1) / slices;
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel<0>, dim3((c + 31) / 32, slices), dim3(256), 0, as_stream(stream), partial,
+                       n_partials, c, rps, scratch, tickets, (double)m, gamma, beta, eps, momentum, stats, running_mean, running_var);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
 int iif_bn_apply(const void* x, int dtype, int64_t m, int c, const float* stats, const void* residual,
                  const float* residual_stats, int relu, void* y, uint8_t* relu_bits, void* stream) {
     if (!x || !stats || !y || m <= 0 || c <= 0) return IIF_EINVAL;
@@ -544,16 +655,24 @@ int iif_bn_backward_relu_recompute(const void* gy, const void* x, int dtype, int
     return IIF_EINVAL;
 }
 
-int iif_bn_backward_partials(const void* gy, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,
-                             const float* stats, const float* gamma, const float* partial, int n_partials, float* dgamma,
-                             float* dbeta, void* dx, void* workspace, int64_t workspace_bytes, void* stream) {
+int iif_bn_backward_partials_fused(const void* gy, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,
+                                   const float* stats, const float* gamma, const float* partial, int n_partials, float* dgamma,
+                                   float* dbeta, void* dx, void* workspace, int64_t workspace_bytes, int32_t* tickets,
+                                   void* stream) {
     if (!gy || !x || !stats || !gamma || !partial || n_partials <= 0 || !dgamma || !dbeta || !dx || !workspace || m <= 0 || c <= 0)
         return IIF_EINVAL;
     if (m > 0x7fffff00LL || bad_align(gy) || bad_align(x) || bad_align(dx)) return IIF_EUNSUPPORTED;
     if (dtype != IIF_BF16 || c % 8) return IIF_EUNSUPPORTED;
     return bn_backward_t<unsigned short>((const unsigned short*)gy, nullptr, relu_bits, (const unsigned short*)x, stats, gamma, m, c,
                                          dgamma, dbeta, (unsigned short*)dx, nullptr, (float*)workspace, workspace_bytes,
-                                         as_stream(stream), partial, n_partials);
+                                         as_stream(stream), partial, n_partials, false, (c + 31) / 32 <= 64 ? tickets : nullptr);
+}
+
+int iif_bn_backward_partials(const void* gy, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,
+                             const float* stats, const float* gamma, const float* partial, int n_partials, float* dgamma,
+                             float* dbeta, void* dx, void* workspace, int64_t workspace_bytes, void* stream) {
+    return iif_bn_backward_partials_fused(gy, relu_bits, x, dtype, m, c, stats, gamma, partial, n_partials, dgamma, dbeta, dx,
+                                          workspace, workspace_bytes, nullptr, stream);
 }
 
 }  // extern "C"

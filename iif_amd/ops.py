@@ -47,7 +47,14 @@ def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial, groups=1):
 
 
 def bn_finalize_stats(partial, n_partials, m, c, gamma, beta, running_mean, running_var, stats, eps=1e-5, momentum=0.1,
-                      scratch=None):
+                      scratch=None, tickets=None):
+    """``tickets`` (zeroed int32[64], one per stream): both reduction stages in one launch (iif_bn_finalize_stats_fused)."""
+    if tickets is not None:
+        check(lib().iif_bn_finalize_stats_fused(ptr(partial), n_partials, m, c, ptr(gamma), ptr(beta), eps, momentum,
+                                                ptr(running_mean), ptr(running_var), ptr(stats), ptr(scratch),
+                                                0 if scratch is None else scratch.numel(), ptr(tickets), stream_ptr()),
+              "iif_bn_finalize_stats_fused")
+        return stats
     check(lib().iif_bn_finalize_stats(ptr(partial), n_partials, m, c, ptr(gamma), ptr(beta), eps, momentum,
                                       ptr(running_mean), ptr(running_var), ptr(stats), ptr(scratch),
                                       0 if scratch is None else scratch.numel(), stream_ptr()),
@@ -347,9 +354,9 @@ def conv_dgrad_bnbwd(dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits, up_st
     return nt.value
 
 
-def bn_backward_partials(gy, relu_bits, x2d, stats, gamma, partial, n_partials, dgamma, dbeta, dx, ws):
+def bn_backward_partials(gy, relu_bits, x2d, stats, gamma, partial, n_partials, dgamma, dbeta, dx, ws, tickets=None):
     m, c = x2d.shape
-    check(lib().iif_bn_backward_partials(ptr(gy), ptr(relu_bits), ptr(x2d), dtype_code(x2d), m, c, ptr(stats), ptr(gamma),
-                                         ptr(partial), n_partials, ptr(dgamma), ptr(dbeta), ptr(dx), ptr(ws), ws.numel(),
-                                         stream_ptr()), "iif_bn_backward_partials")
+    check(lib().iif_bn_backward_partials_fused(ptr(gy), ptr(relu_bits), ptr(x2d), dtype_code(x2d), m, c, ptr(stats), ptr(gamma),
+                                               ptr(partial), n_partials, ptr(dgamma), ptr(dbeta), ptr(dx), ptr(ws), ws.numel(),
+                                               ptr(tickets), stream_ptr()), "iif_bn_backward_partials_fused")
     return dx

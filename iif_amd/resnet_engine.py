@@ -716,6 +716,9 @@ class _Plan(object):
         cmax = max(u.conv.cout for u in self.units)
         mmax = max(u.n * u.ho * u.wo for u in self.units)
         self.bn_ws = ops.bn_workspace(mmax, cmax, dev)
+        # ticket words of the single-launch two-stage BN reductions (self-resetting; one set per stream that finalises)
+        self.bn_tickets = torch.zeros(64, dtype=torch.int32, device=dev) if not os.environ.get("IIF_BN_NO_FUSED_FINALIZE") else None
+        self.bn_tickets_side = torch.zeros(64, dtype=torch.int32, device=dev) if self.bn_tickets is not None else None
         self.bn_partial = torch.empty(max(((u.n * u.ho * u.wo + 127) // 128) * 2 * u.conv.cout for u in self.units),
                                       dtype=torch.float32, device=dev)
         self.bn_scratch = torch.empty(128 * cmax, dtype=torch.float32, device=dev)
@@ -843,7 +846,8 @@ class _Plan(object):
             partial, scratch = (self.bn_partial_side, self.bn_scratch_side) if side else (self.bn_partial, self.bn_scratch)
             nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, partial, groups=u.groups)
             ops.bn_finalize_stats(partial, nt, m, cv.cout, u.bn.weight, u.bn.bias, u.bn.running_mean,
-                                  u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM, scratch=scratch)
+                                  u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM, scratch=scratch,
+                                  tickets=self.bn_tickets_side if side else self.bn_tickets)
             return x2
         ops.conv_forward(u.src, u.w, k, k, st, pd, out=u.x, groups=u.groups, out_hw=(u.ho, u.wo))
         if training:
@@ -1050,7 +1054,7 @@ class _Plan(object):
             # the data gradient that wrote gy already reduced (sum g, sum g*xhat) per tile: no reduction pass
             dx = self._gbuf((dxkey, m, cv.cout, par), (m, cv.cout)) if keep_gy else g2
             ops.bn_backward_partials(g2, bits, u.x.view(m, cv.cout), u.stats, bn.weight, self.bw_partial, ready[1],
-                                     bn._dgamma, bn._dbeta, dx, ws)
+                                     bn._dgamma, bn._dbeta, dx, ws, tickets=self.bn_tickets)
         elif gmasked is not None or keep_gy:
             # dx goes to its own buffer; gy is either overwritten by its masked copy (gmasked) or left as is
             dx = self._gbuf((dxkey, m, cv.cout, par), (m, cv.cout))

@@ -209,6 +209,14 @@ int iif_bn_finalize_stats(const float* partial, int n_partials, int64_t m, int c
                           const float* beta, float eps, float momentum, float* running_mean,
                           float* running_var, float* stats, float* scratch, int64_t scratch_floats,
                           void* stream);
+/* iif_bn_finalize_stats with both reduction stages in ONE launch when there are > 512 partial rows: the 64 slice sums
+ * are published with agent-scope atomics and the last block of every 32-channel group (a ticket per group) finishes
+ * the statistics.  tickets: int32[64], ZERO on entry (zero it once; the kernel leaves it zero), not shared by calls
+ * that can run concurrently; NULL = the two-launch path.  Same arithmetic (fixed-order fp64 sums). */
+int iif_bn_finalize_stats_fused(const float* partial, int n_partials, int64_t m, int c, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean,
+                                float* running_var, float* stats, float* scratch, int64_t scratch_floats,
+                                int32_t* tickets, void* stream);
 int iif_bn_backward(const void* gy, const void* y_mask, const uint8_t* relu_bits, const void* x,
                     int dtype, int64_t m, int c, const float* stats, const float* gamma, float* dgamma,
                     float* dbeta, void* dx, void* gmasked, void* workspace, int64_t workspace_bytes,
@@ -406,6 +414,11 @@ int iif_bn_backward_partials(const void* gy, const uint8_t* relu_bits, const voi
                              const float* stats, const float* gamma, const float* partial, int n_partials,
                              float* dgamma, float* dbeta, void* dx, void* workspace, int64_t workspace_bytes,
                              void* stream);
+/* the same with the slice reduction and the finalisation of > 512 partial rows in one launch (tickets as above) */
+int iif_bn_backward_partials_fused(const void* gy, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,
+                                   const float* stats, const float* gamma, const float* partial, int n_partials,
+                                   float* dgamma, float* dbeta, void* dx, void* workspace, int64_t workspace_bytes,
+                                   int32_t* tickets, void* stream);
 
 /* Stem without a stored activation (resnet_pytorch.py:284-287: bn1 -> relu -> maxpool):
  *   iif_maxpool_bn_forward           max pool over relu(a*x + b) of the RAW convolution output x (stats: scale at [2c],

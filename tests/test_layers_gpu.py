@@ -309,3 +309,46 @@ def test_weight_transpose_batched_matches_per_tensor():
             ref = torch.empty(ci, ldwt, dtype=dt, device=DEV)
             ops.weight_transpose(arena[oi:oi + co * ldw].view(co, ldw), co, ci, rs, ref)
             assert torch.equal(out[oo:oo + ci * ldwt].view(ci, ldwt), ref), (co, ci, rs)
+
+
+@pytest.mark.parametrize("nt,c", [(700, 64), (6272, 256), (1568, 512), (3000, 40), (513, 2048)])
+def test_bn_reduce_and_finalize_in_one_launch_is_bit_identical(nt, c):
+    """iif_bn_finalize_stats_fused / iif_bn_backward_partials_fused (slice sums published with agent-scope atomics,
+    last block of every 32-channel group finalises) against the two-launch path: same fixed-order sums, bit for bit,
+    and the ticket words are left at zero for the next call."""
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(nt + c)
+    m = nt * 128
+    partial = torch.randn(nt, 2, c, generator=g).abs_().mul_(100.0)
+    partial[:, 1] += partial[:, 0] ** 2 / 128            # keep the variance positive
+    partial = partial.to(DEV)
+    gamma, beta = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV)
+    tickets = torch.zeros(64, dtype=torch.int32, device=DEV)
+    out = []
+    for tk in (None, tickets, tickets):
+        stats = torch.full((4, c), float("nan"), device=DEV)
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        ops.bn_finalize_stats(partial.view(-1), nt, m, c, gamma, beta, rm, rv, stats, scratch=torch.empty(128 * c, device=DEV), tickets=tk)
+        out.append((stats, rm, rv))
+    assert tickets.abs().sum().item() == 0
+    for a_, b_ in zip(out[0], out[1]):
+        assert torch.equal(a_, b_)
+    for a_, b_ in zip(out[1], out[2]):
+        assert torch.equal(a_, b_)
+    # backward flavour through bn_backward_partials (bf16 tensors, c % 8 == 0)
+    if c % 8 == 0:
+        mm = 256
+        gy = torch.randn(mm, c, generator=g).to(torch.bfloat16).to(DEV)
+        x = torch.randn(mm, c, generator=g).to(torch.bfloat16).to(DEV)
+        bits = torch.randint(0, 255, (mm * c // 8,), dtype=torch.uint8, generator=g).to(DEV)
+        st = torch.rand(4, c, device=DEV) + 0.5
+        res = []
+        for tk in (None, tickets):
+            dg, db = torch.full((c,), float("nan"), device=DEV), torch.full((c,), float("nan"), device=DEV)
+            dx = torch.empty_like(x)
+            ws = ops.bn_workspace(mm, c, DEV)
+            ops.bn_backward_partials(gy, bits, x, st, gamma, partial.view(-1), nt, dg, db, dx, ws, tickets=tk)
+            res.append((dg, db, dx))
+        assert tickets.abs().sum().item() == 0
+        for a_, b_ in zip(res[0], res[1]):
+            assert torch.equal(a_, b_)
