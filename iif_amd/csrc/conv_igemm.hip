@@ -913,24 +913,25 @@ __global__ void __launch_bounds__(512) conv_igemm_dma_utap256_kernel(ConvArgs a,
 //     LDS-DMA fetched, so the K loop has no barrier at all, only counted vmcnt waits on a private ring of R K-slabs
 //     (16 rows x 64 B pieces) that runs continuously across tiles: the next tiles' rows are in flight during the
 //     epilogue of the current one;
-//   * 4 STORE waves drain the previous tile from an LDS staging buffer (16 B per lane, whole lines; residual add,
+//   * 8 STORE waves drain the previous tile from an LDS staging buffer (16 B per lane, whole lines; residual add,
 //     ReLU-bit masks, forward BN statistics or upstream BN-backward sums as in conv_epilogue_staged) while the
 //     compute waves multiply the next one.  Two block-wide barriers per tile hand the staging buffer over.
 // Compute waves issue no vector-memory instruction besides their DMA, so the vmcnt arithmetic is exact; the store
 // waves' loads and stores live on their own counters.
+constexpr int STREAM_SW = 8;
 template <int BN, int KMAX>
-__global__ void __launch_bounds__(512) gemm1x1_stream_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
-    constexpr int BM = 128, R = 6, CI = BN / 16;
+__global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+    constexpr int BM = 128, R = 5, CI = BN / 16, SW = STREAM_SW;      // SW store waves next to the 4 compute waves
     constexpr int WBYTES = KMAX * BN * 2;                 // resident weights: K/32 slabs of [BN rows x 64 B]
     constexpr int RING = 4 * R * 2048;                    // per compute wave: R slabs of its 32 rows x 64 B
     constexpr int PITCH = BN * 2 + 16;
-    constexpr int CPR = BN / 8, RPP = 256 / CPR;
+    constexpr int CPR = BN / 8, RPP = 64 * SW / CPR;
     constexpr unsigned OOB = 0x80000000u;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[WBYTES + RING + BM * PITCH + 4 * 2 * BN * 4];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[WBYTES + RING + BM * PITCH + SW * 2 * BN * 4];
     unsigned char* const wl = smem;
     unsigned char* const ring = smem + WBYTES;
     unsigned char* const stage = ring + RING;
-    float* const scratch = reinterpret_cast<float*>(stage + BM * PITCH);          // [4 store waves][2][BN]
+    float* const scratch = reinterpret_cast<float*>(stage + BM * PITCH);          // [SW store waves][2][BN]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -944,7 +945,7 @@ __global__ void __launch_bounds__(512) gemm1x1_stream_kernel(ConvArgs a, unsigne
     // ---- resident weights: slab ks, 16-row piece p -> wl + ks * BN * 64 + p * 1024; all 8 waves fetch
     {
         const int pieces = nk * (BN / 16);
-        for (int q = wave; q < pieces; q += 8) {
+        for (int q = wave; q < pieces; q += 4 + SW) {
             const int ks = q / (BN / 16), p = q - ks * (BN / 16);
             const int n = p * 16 + prow;
             const unsigned off = n < a.Cd ? ((unsigned)n * (unsigned)a.ldw + (unsigned)(ks * 32 + chunk * 8)) * 2u : OOB;
@@ -1061,7 +1062,7 @@ __global__ void __launch_bounds__(512) gemm1x1_stream_kernel(ConvArgs a, unsigne
     }
 
     // ===================================================================== store waves
-    const int ts = tid - 256, sw = wave - 4;
+    const int ts = tid - 256, sw = wave - 4;             // store-thread index 0 .. 64*SW-1
     const int chk = ts % CPR, r0 = ts / CPR;
     const int n = chk * 8;
     const bool stats = a.bn_partial != nullptr;
@@ -1072,12 +1073,12 @@ __global__ void __launch_bounds__(512) gemm1x1_stream_kernel(ConvArgs a, unsigne
 #pragma unroll
         for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[n + q]; bistd[q] = a.bw_stats[a.Cd + n + q]; }
     }
-    // combine the 4 store waves' sums of tile `mt` (already in scratch) into its partial row
+    // combine the store waves' sums of tile `mt` (already in scratch) into its partial row
     auto emit_partial = [&](int mt) {
         if (ts < BN && ts < a.Cd) {
             float s2 = 0.f, q2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { s2 += scratch[(w * 2 + 0) * BN + ts]; q2 += scratch[(w * 2 + 1) * BN + ts]; }
+            for (int w = 0; w < SW; ++w) { s2 += scratch[(w * 2 + 0) * BN + ts]; q2 += scratch[(w * 2 + 1) * BN + ts]; }
             float* p = a.bn_partial + (int64_t)(a.bn_row0 + mt) * 2 * a.dpitch + ts;
             p[0] = s2; p[a.dpitch] = q2;
         }
@@ -1102,12 +1103,13 @@ __global__ void __launch_bounds__(512) gemm1x1_stream_kernel(ConvArgs a, unsigne
 #pragma unroll
         for (int q = 0; q < 8; ++q) { bs[q] = 0.f; bq[q] = 0.f; }
         if (n < a.Cd) {
+            const int rows_here = a.M - m0 < BM ? a.M - m0 : BM;          // only the last tile is short
+            const unsigned char* sp = stage + r0 * PITCH + chk * 16;
+            int64_t o = ((int64_t)(m0 + r0) * a.dpitch + n) * 2;
+            const int64_t ostep = (int64_t)RPP * a.dpitch * 2;
 #pragma unroll 4
-            for (int row = r0; row < BM; row += RPP) {
-                const int m = m0 + row;
-                if (m >= a.M) break;
-                u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * PITCH + chk * 16);
-                const int64_t o = ((int64_t)m * a.dpitch + n) * 2;
+            for (int row = r0; row < rows_here; row += RPP, sp += RPP * PITCH, o += ostep) {
+                u32x4 v = *reinterpret_cast<const u32x4*>(sp);
                 if (a.res) {
                     const u32x4 rr = *reinterpret_cast<const u32x4*>(a.res + o);
                     const unsigned rb = a.res_bits ? a.res_bits[o >> 4] : 0xffu;
@@ -1178,14 +1180,14 @@ inline bool use_stream1x1(const ConvArgs& a, bool utap, int esz, bool outf32, in
     if (a.Hs != a.Hd || a.Ws != a.Wd || (a.Cs % 32) || a.spitch != a.Cs || a.dpitch != a.Cd) return false;
     if (a.Cd == 256 && a.Cs <= 64) { *bn = 256; *kmax = 64; }
     else if (a.Cd == 128 && a.Cs <= 256) { *bn = 128; *kmax = 256; }
-    else if (a.Cd == 64 && a.Cs <= 256) { *bn = 64; *kmax = 256; }
+    else if (a.Cd == 64 && a.Cs <= 256 && (a.Cs >= 128 || getenv("IIF_CONV_STREAM1X1_FORCE"))) { *bn = 64; *kmax = 256; }   // 64->64: the tile kernel wins (0.038 vs 0.060 ms)
     else return false;
     const char* force = getenv("IIF_CONV_STREAM1X1_FORCE");                   // tests: small grids too (read per call)
     if (force) return true;
-    // Measured alone (scripts/bm_stream1x1.py, bs 256): forward 64->256 0.150 -> 0.134 ms, 256->128 0.140 -> 0.117,
-    // 256->64 0.105 -> 0.099 against the 4-blocks-per-CU tile kernel; the data gradients with the upstream BN-backward
-    // sums are SLOWER here (their epilogue loads sit in 4 store waves only: 0.216 -> 0.397 ms), so they stay on the
-    // tile kernels.
+    // Measured alone (scripts/bm_stream1x1.py, bs 256, 8 store waves): forward 64->256 0.152 -> 0.113 ms (4.5 TB/s),
+    // 256->128 0.136 -> 0.121, 256->64 0.105 -> 0.100, 28x28 64->256 0.033 -> 0.029 against the 4-blocks-per-CU tile
+    // kernel; the data gradients with the upstream BN-backward sums are level or slower here (their epilogue loads
+    // wait inside the store waves: 64->256 0.220 -> 0.243 ms), so they stay on the tile kernels.
     return !a.transposed && !a.bw_x && (a.M + 127) / 128 >= 1024;             // >= 4 tiles per persistent block
 }
 
@@ -1255,9 +1257,9 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
         }();
         const unsigned grid = (unsigned)(a.mtiles < cus ? a.mtiles : cus);
         const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
-        if (sbn == 256) hipLaunchKernelGGL((gemm1x1_stream_kernel<256, 64>), dim3(grid), dim3(512), 0, st, a, sb, wb);
-        else if (sbn == 128) hipLaunchKernelGGL((gemm1x1_stream_kernel<128, 256>), dim3(grid), dim3(512), 0, st, a, sb, wb);
-        else hipLaunchKernelGGL((gemm1x1_stream_kernel<64, 256>), dim3(grid), dim3(512), 0, st, a, sb, wb);
+        if (sbn == 256) hipLaunchKernelGGL((gemm1x1_stream_kernel<256, 64>), dim3(grid), dim3(64 * (4 + STREAM_SW)), 0, st, a, sb, wb);
+        else if (sbn == 128) hipLaunchKernelGGL((gemm1x1_stream_kernel<128, 256>), dim3(grid), dim3(64 * (4 + STREAM_SW)), 0, st, a, sb, wb);
+        else hipLaunchKernelGGL((gemm1x1_stream_kernel<64, 256>), dim3(grid), dim3(64 * (4 + STREAM_SW)), 0, st, a, sb, wb);
         IIF_LAUNCH_CHECK();
         return IIF_OK;
     }

@@ -1098,6 +1098,15 @@ class _Plan(object):
         if reducer is not None:
             reducer.begin()
             reducer.extra_streams = [self.wg_stream] if self.wg_stream is not None else []
+        if self.wg_stream is not None:
+            # fork the side streams off the compute stream before anything is recorded on them: under hipGraph capture
+            # every event of the step then belongs to the capture (the first fence used to be recorded on a stream that
+            # had not joined it yet), and all of them are joined again at the end of backward
+            ev = torch.cuda.Event()
+            ev.record()
+            self.wg_stream.wait_event(ev)
+            if self.ds_stream is not None:
+                self.ds_stream.wait_event(ev)
         # ---- head: dlogits (fp32, pad columns are zero) -> head grads -> pooled grad -> final activation grad
         op, D = head.out_padded, head.in_features
         if self.dt == torch.float32:
@@ -1134,6 +1143,10 @@ class _Plan(object):
                 ops.rowmap_backward(self.pooled, self.head_xnorm, self.head_dex, 0, float(head.scale), dp2)
         fh, fw, fc = self.final.shape[1], self.final.shape[2], self.final.shape[3]
         if net._head_only:              # frozen backbone: the classifier's gradients are all that is needed
+            if self.wg_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.wg_stream)
+                if self.ds_stream is not None:
+                    torch.cuda.current_stream().wait_stream(self.ds_stream)
             if reducer is not None:
                 reducer.finish_tail(offs["head"])
             return
@@ -1236,6 +1249,8 @@ class _Plan(object):
             self._unit_backward(u, g, u.y, need_dgrad=False)
         if self.wg_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wg_stream)
+            if self.ds_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.ds_stream)
             self._wg_events.clear()
         if reducer is not None:
             reducer.finish()
