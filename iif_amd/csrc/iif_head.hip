@@ -14,6 +14,8 @@
 // patched by the one lane that owns the target column instead of being compared in every lane.
 // The scalar loss comes out of the SAME launch when the caller passes a ticket word: the last block to finish
 // (atomic ticket, agent-scope fence) sums the per-row losses in a fixed order — deterministic, no second launch.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -151,7 +153,22 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
             if (c0 < a.C) xn[j] = Io<T>::load4(x0 + c0);
         }
     }
-    for (int c = threadIdx.x; c < NCH * 256; c += blockDim.x) tab_s[c] = c < a.C ? a.tab[c] : 0.f;
+    // table -> LDS in 16-byte pieces, all loads of a thread issued before the first LDS write (a scalar loop cost a
+    // single-wave block 20 dependent round trips to L2: 22 us at [1024, 1204])
+    {
+        constexpr int V4 = NCH * 64;                       // float4 pieces of the padded table
+        f32x4 tv[(V4 + 63) / 64];
+#pragma unroll
+        for (int q = 0; q < (V4 + 63) / 64; ++q) {
+            const int i = threadIdx.x + q * blockDim.x;
+            tv[q] = (i < V4 && i * 4 < a.C) ? *reinterpret_cast<const f32x4*>(a.tab + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < (V4 + 63) / 64; ++q) {
+            const int i = threadIdx.x + q * blockDim.x;
+            if (i < V4) *reinterpret_cast<f32x4*>(tab_s + i * 4) = tv[q];
+        }
+    }
     __syncthreads();
     float wave_loss = 0.f;
     for (; row < a.B; row += nwaves) {
@@ -337,10 +354,14 @@ constexpr unsigned kMaxRowBlocks = 2048;      // = partial slots of the single-l
 // configuration cannot do it (streaming kernel with more blocks than workspace slots).
 template <typename T, int MODE>
 int launch_rows(CeArgs a, float* sm_out, int64_t ld_sm, hipStream_t st, bool* inline_reduce = nullptr) {
-    const int wpb = a.B <= 4096 ? 1 : 4;
+    static const char* wpb_env = getenv("IIF_HEAD_WPB");
+    // waves per block: every block stages the table once and takes one ticket, so small batches use fewer, fatter blocks
+    const int wpb = wpb_env ? atoi(wpb_env) : 4;          // measured 1 / 2 / 4: [1024, 1204] 23.2 / 13.3 / 9.5 us, [256, 1000] 9.1 / 7.6 / 6.6 us
     const dim3 grid((a.B + wpb - 1) / wpb), block(64 * wpb);
     // register-row kernel: at most 256 CUs x 8 blocks; beyond that a wave walks several rows
-    const dim3 pgrid(grid.x < kMaxRowBlocks ? grid.x : kMaxRowBlocks);
+    static const char* mb_env = getenv("IIF_HEAD_MAXBLOCKS");
+    const unsigned maxb = mb_env ? (unsigned)atoi(mb_env) : 1024u;     // 256 / 512 / 1024 / 2048 blocks: [8192, 1204] 25.9 / 23.6 / 26.5 / 35.3 us, [65536, 1000] bf16 0.213 / 0.129 / 0.085 / 0.090 ms
+    const dim3 pgrid(grid.x < maxb ? grid.x : maxb);
     bool vec = (a.C % 4 == 0) && (a.C <= 2048) && (a.ldx % 4 == 0) && aligned(a.x, Io<T>::kAlign) &&
                aligned(a.tab, 16);
     if (MODE == 0 && a.dx) vec = vec && (a.lddx % 4 == 0) && aligned(a.dx, Io<T>::kAlign);
