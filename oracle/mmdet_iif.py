@@ -1,12 +1,12 @@
 """CPU restatement of the mmdet ``IIFLoss`` plugin arithmetic.
 
-TEST INFRASTRUCTURE — see ``oracle/__init__.py``.  The mmdet half of the
-reference is not importable here (mmcv / mmdet absent), so this file is a
-restatement pinned by cross-checks, not by running the reference:
-  * with weight=None, avg_factor=None, class_weight=None, loss_weight=1 it
-    must equal ``oracle.iif_oracle.iif_ce(reduction='mean')`` (golden G4);
-  * the CE known answers of instance_segmentation/tests/test_metrics/
-    test_losses.py:8-32 (table of ones).
+TEST INFRASTRUCTURE — see ``oracle/__init__.py``.  Parity PINNED: every function below is checked against
+vectors produced by executing the reference's own files (tests/golden/make_golden_mmdet.py runs
+mmdet/models/losses/{utils,accuracy,cross_entropy_loss,iif_loss,fasa_iif_loss}.py, models/utils/normed_predictor.py
+and roi_heads/bbox_heads/fasa_bbox_head.py under placeholder mmcv / registry modules; fixtures g11..g15), by
+tests/test_mmdet_golden.py on the CPU.  Additional cross-checks: with weight=None, avg_factor=None,
+class_weight=None, loss_weight=1 the loss equals ``oracle.iif_oracle.iif_ce(reduction='mean')`` (golden G4), and the
+CE known answers of instance_segmentation/tests/test_metrics/test_losses.py:8-32 (table of ones).
 Citations are relative to /root/reference/instance_segmentation/.
 """
 import csv

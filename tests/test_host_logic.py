@@ -89,3 +89,51 @@ def test_model_zoo_parameter_counts():
     assert count(resnet_pytorch.resnext101_32x4d(num_classes=365, device="cpu")) == 42876589
     m = resnet_cifar.resnet32(num_classes=10, use_norm="lr_cosine", device="cpu")
     assert m.linear.scale.item() == 5.0
+
+
+def test_mmdet_registration_against_a_registry(monkeypatch):
+    """BASELINE config 5 plugs the native classes into mmdet through its registries (models/builder.py:7-14,
+    models/utils/builder.py:6, mmcv.cnn.CONV_LAYERS).  mmdet is not installed here, so the registration code runs
+    against stand-in registries with mmcv's ``register_module(name=, force=, module=)`` / ``get`` protocol: the
+    reference's names resolve to the native classes, replacing entries already there."""
+    import sys
+    import types
+
+    class Registry(object):
+        def __init__(self):
+            self.module_dict = {}
+
+        def register_module(self, name=None, force=False, module=None):
+            if name in self.module_dict and not force:
+                raise KeyError(name + " is already registered")
+            self.module_dict[name] = module
+            return module
+
+        def get(self, key):
+            return self.module_dict.get(key)
+
+    losses, linear, conv = Registry(), Registry(), Registry()
+    losses.module_dict["IIFLoss"] = object            # the fork's own class is already there: force=True must replace it
+    mods = {"mmdet": types.ModuleType("mmdet"), "mmdet.models": types.ModuleType("mmdet.models"),
+            "mmdet.models.builder": types.ModuleType("mmdet.models.builder"),
+            "mmdet.models.utils": types.ModuleType("mmdet.models.utils"),
+            "mmdet.models.utils.builder": types.ModuleType("mmdet.models.utils.builder"),
+            "mmcv": types.ModuleType("mmcv"), "mmcv.cnn": types.ModuleType("mmcv.cnn")}
+    mods["mmdet.models.builder"].LOSSES = losses
+    mods["mmdet.models.utils.builder"].LINEAR_LAYERS = linear
+    mods["mmcv.cnn"].CONV_LAYERS = conv
+    for k, v in mods.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    from iif_amd import mmdet_fasa, mmdet_iif_loss, mmdet_normed_predictor
+    assert mmdet_iif_loss.register_into_mmdet() and mmdet_fasa.register_into_mmdet() and mmdet_normed_predictor.register_into_mmdet()
+    assert losses.get("IIFLoss") is mmdet_iif_loss.IIFLoss and losses.get("FasaIIFLoss") is mmdet_fasa.FasaIIFLoss
+    assert linear.get("NormedLinear") is mmdet_normed_predictor.NormedLinear
+    assert linear.get("IIFNormedLinear") is mmdet_normed_predictor.IIFNormedLinear
+    assert conv.get("NormedConv2d") is mmdet_normed_predictor.NormedConv2d
+    # build_loss(cfg) = registry.get(type)(**kwargs)  (mmcv build_from_cfg); the config of configs/activations/iif/*.py
+    import os
+    from tests.conftest import GOLDEN
+    cfg = dict(type="IIFLoss", variant="raw", num_classes=1203, path=os.path.join(GOLDEN, "lvis_files/idf_1204.csv"), device="cpu")
+    crit = losses.get(cfg.pop("type"))(**cfg)
+    assert crit.get_cls_channels(1203) == 1204 and tuple(crit.iif_weights.shape) == (1, 1204)
+    assert crit.custom_cls_channels and crit.custom_activation and crit.custom_accuracy
