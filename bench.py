@@ -197,6 +197,14 @@ def cpu_baseline(counts, sample_bs, steps, device=None):
     cores = max(1, min(cores, int(os.environ.get("IIF_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     sd = R.init_imagenet("resnet50", len(counts), seed=0)
+    # Conditioned initialisation for the loss comparison: the last BN gain of every bottleneck x0.1 (trained networks have
+    # small residual gains; torchvision's zero_init_residual sets them to 0).  At the plain random init the REFERENCE's own
+    # fp32 run is 7e-3..3e-1 of the loss away from its float64 run after one SGD step (profiles/r2_reference_fp32_noise.txt),
+    # so a 1e-4 loss-curve statement is only meaningful on a recipe where fp32 itself is reproducible (here: <= 1e-5,
+    # tests/golden/g16_nets_conditioned.npz).  The CPU throughput does not depend on the weight values.
+    for k in sd:
+        if k.startswith("layer") and k.endswith("bn3.weight"):
+            sd[k] = sd[k] * 0.1
     g = torch.Generator().manual_seed(0)
     x = torch.randn(sample_bs, 3, 224, 224, generator=g)
     prior = torch.tensor(counts, dtype=torch.float64)
@@ -231,9 +239,10 @@ def cpu_baseline(counts, sample_bs, steps, device=None):
             out["loss_max_rel_delta_" + name] = float("%.3g" % max(deltas))
             del net
         out["loss_steps_compared"] = steps + 1
-        out["loss_note"] = ("same weights, batch and SGD steps (lr 1e-4) through the HIP path; random-init raw-IIF training is chaotic: the "
-                            "CPU oracle run with 8 vs 3 threads differs by 4.8e-2 over the same 9 steps (DESIGN.md section 6), so only the "
-                            "first step isolates arithmetic; controlled-condition curves are asserted to 1e-4 in tests/test_resnet_gpu.py")
+        out["loss_note"] = ("same weights, batch and SGD steps (lr 1e-4) through the HIP path, on the conditioned initialisation (last BN gain of "
+                            "every bottleneck x0.1) where fp32 itself is reproducible; at plain random init the reference's own fp32 run is "
+                            "7e-3..3e-1 from its float64 run after one step (profiles/r2_reference_fp32_noise.txt); the same curves against "
+                            "the reference's stored numbers are asserted to 1e-4 in tests/test_resnet_gpu.py::test_hip_step_against_reference_fixture")
         out["cpu_losses"] = [round(v, 4) for v in losses]
     return out
 

@@ -744,6 +744,9 @@ class _Plan(object):
             pr = os.environ.get("IIF_WGRAD_STREAM_PRIORITY")
             self.wg_stream = torch.cuda.Stream(device=dev) if pr is None else torch.cuda.Stream(device=dev, priority=int(pr))
         self._wg_events = {}
+        # blocks the weight-gradient stream may lag behind the compute stream: dx buffers rotate over `wg_lag` slots,
+        # block-input gradients over wg_lag + 1, and block b waits for the weight gradients of the blocks >= b + wg_lag
+        self.wg_lag = max(2, int(os.environ.get("IIF_WGRAD_LAG", "2")))
         # backward of the convolutional shortcut (BN backward + dgrad + wgrad of 4 blocks) on a third stream
         self.ds_stream = None
         if self.wg_stream is not None and ds_units and dt == torch.bfloat16 and not os.environ.get("IIF_NO_BWD_SIDE"):
@@ -1014,7 +1017,7 @@ class _Plan(object):
         ev = torch.cuda.Event()
         ev.record(self.wg_stream)
         self._wg_events[tag] = ev
-        old = self._wg_events.pop(tag + 1, None)
+        old = self._wg_events.pop(tag + self.wg_lag - 1, None)
         if old is not None:
             torch.cuda.current_stream().wait_event(old)
 
@@ -1162,9 +1165,9 @@ class _Plan(object):
             inp = b["inp"]
             # g is the gradient w.r.t. the block output (pre-mask).  After this call g holds the masked
             # gradient (the residual-branch gradient) and dx of the last conv has been consumed.
-            par = bi & 1
+            par = bi % self.wg_lag
             self._wgrad_fence(bi)
-            gin = self._gbuf(("gin", tuple(inp.shape), bi % 3), inp.shape)
+            gin = self._gbuf(("gin", tuple(inp.shape), bi % (self.wg_lag + 1)), inp.shape)
             dkey = ("d", tuple(last.src.shape), len(units) - 1, par)
             # The block's ReLU gates g on both paths.  With a convolutional shortcut or a plain identity no masked
             # copy of g is written: the shortcut's BN backward and the identity add read g through the ReLU bits.
