@@ -546,16 +546,21 @@ class NativeResNet(nn.Module):
         table = criterion._table(plan.logits)
         scale = 1.0 / B if criterion.reduction == "mean" else 1.0
         cw = criterion.weight
+        den = criterion.mean_denominator(targets)
+        if den is not None and targets_b is not None:
+            # plain CE with class weights, 'mean', under mixup: lam * L_a / sum w[y_a] + (1 - lam) * L_b / sum w[y_b]
+            # (custom.py:116-117 on nn.CrossEntropyLoss(weight=w)).  Two denominators fold into the kernel's (lam, scale)
+            # pair; they are read back once per step (this rare recipe pays one host sync).
+            ka = float(lam) / float(den.item())
+            kb = (1.0 - float(lam)) / float(criterion.mean_denominator(targets_b).item())
+            scale, lam, den = ka + kb, ka / (ka + kb), None
         rc = _lib.lib().iif_ce_fwd_bwd(
             _lib.ptr(plan.logits), _lib.IIF_F32, plan.logits.stride(0), _lib.ptr(table), _lib.ptr(targets),
             _lib.ptr(targets_b), float(lam), 0, _lib.ptr(cw), -100, scale, B, C, _lib.ptr(plan.loss_rows),
             _lib.ptr(plan.loss), _lib.ptr(plan.dlogits), plan.dlogits.stride(0), _lib.ptr(plan.label_status),
             _lib.ptr(plan.loss_ticket), _lib.stream_ptr())
         _lib.check(rc, "iif_ce_fwd_bwd")
-        den = criterion.mean_denominator(targets)
         if den is not None:
-            if targets_b is not None:
-                raise NotImplementedError("mixup with the class-weighted plain-CE 'mean' criterion (two different denominators)")
             # plain CE with class weights, 'mean': the launch above used 1/B; rescale loss and dlogits by B / sum w[t]
             plan.loss_rescale.copy_((float(B) / den).reshape(1))
             plan.loss.mul_(plan.loss_rescale[0])

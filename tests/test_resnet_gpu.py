@@ -567,3 +567,29 @@ def test_module_surface_does_not_alias_and_refuses_stale_backward():
         net(xa.to(DEV))
     with torch.no_grad():
         net(xa.to(DEV))
+
+
+@pytest.mark.parametrize("mix", [False, True])
+def test_fused_step_plain_ce_with_class_weights_weighted_mean(mix):
+    """``--classif ce --deffered --reduction mean`` through loss_and_backward: the loss and d(loss)/d(logits) of
+    nn.CrossEntropyLoss(weight=w) (initialisers.py:43-46), also under mixup (custom.py:116-117: each term divided by
+    the weight sum of ITS targets)."""
+    import types
+    from iif_amd import initialisers
+    C, B = 10, 12
+    counts = [500, 300, 200, 120, 80, 50, 30, 20, 10, 5]
+    net, _ = _build("resnet20", C, torch.float32)
+    net.train()
+    args = types.SimpleNamespace(classif="ce", deffered=True, reduction="mean", iif="raw", iif_norm=0, device=DEV)
+    crit = initialisers.get_criterion(args, DS(counts), net, C)
+    x, ya = _data(B, 32, counts, seed=3)
+    _, yb = _data(B, 32, counts, seed=4)
+    lam = 0.3
+    loss, logits = net.loss_and_backward(x.to(DEV), ya.to(DEV), crit, targets_b=yb.to(DEV) if mix else None, lam=lam)
+    lg = logits.detach().float().cpu().clone().requires_grad_(True)
+    w = torch.tensor(counts); w = (w.sum() / w).float()
+    ref_crit = torch.nn.CrossEntropyLoss(weight=w, reduction="mean")
+    ref = lam * ref_crit(lg, ya) + (1 - lam) * ref_crit(lg, yb) if mix else ref_crit(lg, ya)
+    ref.backward()
+    assert relerr(loss, ref) <= 1e-4
+    assert relerr(net._saved.dlogits[:, :C], lg.grad) <= 1e-4
