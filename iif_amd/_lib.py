@@ -36,6 +36,10 @@ SIGNATURES = {
     "iif_bn_finalize_stats": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _P],
     "iif_bn_finalize_stats_fused": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _P, _P],
     "iif_bn_backward_partials_fused": [_P, _P, _P, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P, _P],
+    "iif_bn_partial_sums": [_P, _I, _I, _P, _P],
+    "iif_bn_stats_sums": [_P, _I, _L, _I, _P, _P, _L, _P],
+    "iif_bn_backward_sums": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _L, _P],
+    "iif_bn_backward_apply_sums": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _c.c_double, _P, _P, _P, _P, _P, _P],
     "iif_bn_workspace_bytes": [_L, _I],
     "iif_bn_forward_stats": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _P],
     "iif_bn_apply": [_P, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P],

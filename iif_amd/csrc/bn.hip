@@ -540,6 +540,76 @@ int bn_backward_t(const T* gy, const T* ymask, const unsigned char* bits, const 
     return IIF_OK;
 }
 
+// ---------------------------------------------------------------- cross-replica statistics (SyncBatchNorm)
+// The reduction and the normalisation are separate entry points, so the host can all-reduce the per-channel sums of all
+// ranks in between (classification/train.py:190-191 converts to nn.SyncBatchNorm: statistics over the global batch).
+//   forward : sums[0][c] = sum x, sums[1][c] = sum x^2 of THIS rank -> all-reduce -> iif_bn_finalize_stats(sums, 1 row,
+//             m * world): the same finalisation as the single-rank path, on a single "partial row".
+//   backward: local (sum g, sum g*xhat) -> dgamma / dbeta stay LOCAL sums (the gradient all-reduce averages them like
+//             every other parameter gradient), the subtraction terms mean(g), mean(g*xhat) use the all-reduced sums and
+//             the global count.
+inline int launch_column_sums(const float* partial, int n, int C, float* sums, hipStream_t st) {
+    hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 31) / 32, 1), dim3(256), 0, st, partial, n, C, n, sums);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_coef_kernel(const float* local, const float* total, int C, double count, const float* gamma,
+                                                          const float* stats, float* dgamma, float* dbeta, float* coef) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = stats[C + c];
+    dbeta[c] = local[c];
+    dgamma[c] = local[C + c];
+    coef[c] = gamma[c] * invstd;
+    coef[C + c] = (float)((double)total[c] / count);
+    coef[2 * C + c] = (float)((double)total[C + c] / count) * invstd;
+}
+
+template <typename T>
+int bn_stats_sums_t(const T* x, int64_t M, int C, float* sums, float* ws, int64_t ws_bytes, hipStream_t st) {
+    constexpr int V = VT<T>::V;
+    Geo g = make_geo(M, C, V, 512);
+    if ((int64_t)g.nblk * 2 * C * 4 > ws_bytes) return IIF_EINVAL;
+    hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(g.nblk, g.colblocks), dim3(256), 0, st, x, g, ws);
+    IIF_LAUNCH_CHECK();
+    return launch_column_sums(ws, g.nblk, C, sums, st);
+}
+
+template <typename T>
+int bn_backward_sums_t(const T* gy, const T* ymask, const unsigned char* bits, const T* x, const float* stats, int64_t M, int C,
+                       float* sums, float* ws, int64_t ws_bytes, hipStream_t st) {
+    constexpr int V = VT<T>::V;
+    Geo g = make_geo(M, C, V, 512);
+    if ((int64_t)g.nblk * 2 * C * 4 > ws_bytes) return IIF_EINVAL;
+    const dim3 rgrid(g.nblk, g.colblocks), blk(256);
+    if (bits) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
+    else if (ymask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), rgrid, blk, 0, st, gy, ymask, bits, x, stats, g, ws);
+    IIF_LAUNCH_CHECK();
+    return launch_column_sums(ws, g.nblk, C, sums, st);
+}
+
+template <typename T>
+int bn_backward_apply_sums_t(const T* gy, const T* ymask, const unsigned char* bits, const T* x, const float* stats, const float* gamma,
+                             const float* local, const float* total, double count, int64_t M, int C, float* dgamma, float* dbeta,
+                             T* dx, T* gm, float* coef, hipStream_t st) {
+    constexpr int V = VT<T>::V;
+    const dim3 blk(256);
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), blk, 0, st, local, total, C, count, gamma, stats, dgamma, dbeta, coef);
+    IIF_LAUNCH_CHECK();
+    const int cv = C / V;
+    const int64_t tv = M * cv;
+    const dim3 agrid(stream_blocks(tv));
+#define IIF_BAPPLY(MK, GO) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MK, GO>), agrid, blk, 0, st, gy, ymask, bits, x, stats, coef, dx, gm, tv, cv, C)
+    if (bits) { if (gm) IIF_BAPPLY(2, true); else IIF_BAPPLY(2, false); }
+    else if (ymask) { if (gm) IIF_BAPPLY(1, true); else IIF_BAPPLY(1, false); }
+    else { if (gm) IIF_BAPPLY(0, true); else IIF_BAPPLY(0, false); }
+#undef IIF_BAPPLY
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
 inline bool bad_align(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 
 }  // namespace
@@ -666,6 +736,43 @@ int iif_bn_backward_partials_fused(const void* gy, const uint8_t* relu_bits, con
     return bn_backward_t<unsigned short>((const unsigned short*)gy, nullptr, relu_bits, (const unsigned short*)x, stats, gamma, m, c,
                                          dgamma, dbeta, (unsigned short*)dx, nullptr, (float*)workspace, workspace_bytes,
                                          as_stream(stream), partial, n_partials, false, (c + 31) / 32 <= 64 ? tickets : nullptr);
+}
+
+int iif_bn_partial_sums(const float* partial, int n_partials, int c, float* sums, void* stream) {
+    if (!partial || !sums || n_partials <= 0 || c <= 0) return IIF_EINVAL;
+    return launch_column_sums(partial, n_partials, c, sums, as_stream(stream));
+}
+
+int iif_bn_stats_sums(const void* x, int dtype, int64_t m, int c, float* sums, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!x || !sums || !workspace || m <= 0 || c <= 0) return IIF_EINVAL;
+    if (m > 0x7fffff00LL || bad_align(x)) return IIF_EUNSUPPORTED;
+    if (dtype == IIF_F32) return c % 4 ? IIF_EUNSUPPORTED : bn_stats_sums_t<float>((const float*)x, m, c, sums, (float*)workspace, workspace_bytes, as_stream(stream));
+    if (dtype == IIF_BF16) return c % 8 ? IIF_EUNSUPPORTED : bn_stats_sums_t<unsigned short>((const unsigned short*)x, m, c, sums, (float*)workspace, workspace_bytes, as_stream(stream));
+    return IIF_EINVAL;
+}
+
+int iif_bn_backward_sums(const void* gy, const void* y_mask, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,
+                         const float* stats, float* sums, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!gy || !x || !stats || !sums || !workspace || m <= 0 || c <= 0) return IIF_EINVAL;
+    if (m > 0x7fffff00LL || bad_align(gy) || bad_align(x) || bad_align(y_mask)) return IIF_EUNSUPPORTED;
+    if (dtype == IIF_F32) return c % 4 ? IIF_EUNSUPPORTED : bn_backward_sums_t<float>((const float*)gy, (const float*)y_mask, relu_bits, (const float*)x, stats, m, c, sums, (float*)workspace, workspace_bytes, as_stream(stream));
+    if (dtype == IIF_BF16) return c % 8 ? IIF_EUNSUPPORTED : bn_backward_sums_t<unsigned short>((const unsigned short*)gy, (const unsigned short*)y_mask, relu_bits, (const unsigned short*)x, stats, m, c, sums, (float*)workspace, workspace_bytes, as_stream(stream));
+    return IIF_EINVAL;
+}
+
+int iif_bn_backward_apply_sums(const void* gy, const void* y_mask, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,
+                               const float* stats, const float* gamma, const float* local_sums, const float* total_sums,
+                               double total_count, float* dgamma, float* dbeta, void* dx, void* gmasked, float* coef_scratch,
+                               void* stream) {
+    if (!gy || !x || !stats || !gamma || !local_sums || !total_sums || !dgamma || !dbeta || !dx || !coef_scratch || m <= 0 || c <= 0 ||
+        total_count <= 0.0)
+        return IIF_EINVAL;
+    if (m > 0x7fffff00LL || bad_align(gy) || bad_align(x) || bad_align(dx) || bad_align(y_mask) || bad_align(gmasked)) return IIF_EUNSUPPORTED;
+    if (dtype == IIF_F32)
+        return c % 4 ? IIF_EUNSUPPORTED : bn_backward_apply_sums_t<float>((const float*)gy, (const float*)y_mask, relu_bits, (const float*)x, stats, gamma, local_sums, total_sums, total_count, m, c, dgamma, dbeta, (float*)dx, (float*)gmasked, coef_scratch, as_stream(stream));
+    if (dtype == IIF_BF16)
+        return c % 8 ? IIF_EUNSUPPORTED : bn_backward_apply_sums_t<unsigned short>((const unsigned short*)gy, (const unsigned short*)y_mask, relu_bits, (const unsigned short*)x, stats, gamma, local_sums, total_sums, total_count, m, c, dgamma, dbeta, (unsigned short*)dx, (unsigned short*)gmasked, coef_scratch, as_stream(stream));
+    return IIF_EINVAL;
 }
 
 int iif_bn_backward_partials(const void* gy, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,

@@ -127,6 +127,35 @@ def bn_backward(gy, y_mask, x2d, stats, gamma, dgamma, dbeta, dx, ws, gmasked=No
     return dx
 
 
+# ----------------------------------------------------- cross-replica BN pieces
+def bn_partial_sums(partial, n_partials, c, sums):
+    """sums [2, c] = column sums of the partial rows [n, 2, c] (per-rank half of a SyncBatchNorm reduction)."""
+    check(lib().iif_bn_partial_sums(ptr(partial), n_partials, c, ptr(sums), stream_ptr()), "iif_bn_partial_sums")
+    return sums
+
+
+def bn_stats_sums(x2d, sums, ws):
+    m, c = x2d.shape
+    check(lib().iif_bn_stats_sums(ptr(x2d), dtype_code(x2d), m, c, ptr(sums), ptr(ws), ws.numel(), stream_ptr()), "iif_bn_stats_sums")
+    return sums
+
+
+def bn_backward_sums(gy, y_mask, x2d, stats, sums, ws, relu_bits=None):
+    m, c = x2d.shape
+    check(lib().iif_bn_backward_sums(ptr(gy), ptr(y_mask), ptr(relu_bits), ptr(x2d), dtype_code(x2d), m, c, ptr(stats), ptr(sums),
+                                     ptr(ws), ws.numel(), stream_ptr()), "iif_bn_backward_sums")
+    return sums
+
+
+def bn_backward_apply_sums(gy, y_mask, x2d, stats, gamma, local_sums, total_sums, total_count, dgamma, dbeta, dx, coef, gmasked=None,
+                           relu_bits=None):
+    m, c = x2d.shape
+    check(lib().iif_bn_backward_apply_sums(ptr(gy), ptr(y_mask), ptr(relu_bits), ptr(x2d), dtype_code(x2d), m, c, ptr(stats), ptr(gamma),
+                                           ptr(local_sums), ptr(total_sums), float(total_count), ptr(dgamma), ptr(dbeta), ptr(dx),
+                                           ptr(gmasked), ptr(coef), stream_ptr()), "iif_bn_backward_apply_sums")
+    return dx
+
+
 # --------------------------------------------------------------------- pooling
 def maxpool_forward(x, k, stride, pad):
     n, h, w, c = x.shape

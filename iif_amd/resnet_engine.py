@@ -170,6 +170,7 @@ class NativeResNet(nn.Module):
         self._plans = {}
         self._saved = None
         self._head_only = False
+        self._sync_bn = None            # (process group, world size) once enable_sync_bn() was called
         if style == "imagenet":
             self.conv1 = ConvParam(3, 64, 7, 2, 3); self.bn1 = BNParam(64)
             exp = 4 if block == "bottleneck" else 1
@@ -519,6 +520,19 @@ class NativeResNet(nn.Module):
         self._head_only = True
         return self
 
+    def enable_sync_bn(self, process_group=None):
+        """Batch statistics over all ranks (``--sync-bn``, classification/train.py:190-191: nn.SyncBatchNorm).  Forward:
+        per-rank (sum, sum of squares) all-reduced before the finalisation; backward: the mean terms of the BN gradient from
+        all-reduced sums, dgamma / dbeta local (averaged by the gradient all-reduce like every other gradient).  One small
+        blocking collective per BN layer and direction, as in the reference.  Plans built before the call are dropped."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("enable_sync_bn() needs an initialised process group")
+        self._sync_bn = (process_group, dist.get_world_size(process_group))
+        self._plans = {}
+        self._saved = None
+        return self
+
     def make_reducer(self, bucket_bytes=32 << 20, process_group=None, mode="allreduce"):
         """Bucketed, backward-overlapped all-reduce of the gradient arena (see iif_amd.ddp)."""
         from .ddp import ArenaReducer
@@ -644,7 +658,7 @@ class _Plan(object):
             u.w = torch.empty((c1.cout, 16 * S2D_CPAD), dtype=dt, device=dev)
             u.dwp = torch.empty((c1.cout, 16 * S2D_CPAD), dtype=torch.float32, device=dev)
         self.stem = u
-        self.pool_fused = net.style == "imagenet" and not os.environ.get("IIF_NO_POOL_FUSE")
+        self.pool_fused = net.style == "imagenet" and not os.environ.get("IIF_NO_POOL_FUSE") and net._sync_bn is None
         if net.style == "imagenet":
             self.pool_hw = ((ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1)
             self.pool_out = E(n, self.pool_hw[0], self.pool_hw[1], c1.cout)
@@ -843,21 +857,51 @@ class _Plan(object):
         if need_transposed:
             ops.weight_transpose(self.head_wsrc, head.out_padded, head.in_features, 1, self.head_wt)
 
+    # ------------------------------------------------- cross-replica statistics
+    def _sync_sums(self, c, side=False, which=0):
+        key = ("syncsums", c, bool(side), which)
+        t = self._grad_pool.get(key)
+        if t is None:
+            t = self._grad_pool[key] = torch.empty((2, c), dtype=torch.float32, device=self.dev)
+        return t
+
+    def _sync_coef(self, c, side=False):
+        key = ("synccoef32", c, bool(side))
+        t = self._grad_pool.get(key)
+        if t is None:
+            t = self._grad_pool[key] = torch.empty((3, c), dtype=torch.float32, device=self.dev)
+        return t
+
+    def _sync_finalize(self, u, sums, m, sync):
+        """SyncBatchNorm forward (classification/train.py:190-191): this rank's (sum x, sum x^2) -> all-reduce -> the
+        ordinary finalisation on one "partial row" with the global count."""
+        group, world = sync
+        torch.distributed.all_reduce(sums, group=group)
+        ops.bn_finalize_stats(sums, 1, m * world, u.conv.cout, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var,
+                              u.stats, BN_EPS, BN_MOMENTUM)
+
     # ---------------------------------------------------------------- forward
     def _conv_bn(self, u, training, side=False):
         cv = u.conv
         k, st, pd = u.geom
         m = u.n * u.ho * u.wo
         x2 = u.x.view(m, cv.cout)
+        sync = self.net._sync_bn if training else None
         if training and self.dt == torch.bfloat16 and cv.cout % 8 == 0 and _dma_ok(u.src):
             # statistics come out of the convolution's epilogue: no extra pass over x
             partial, scratch = (self.bn_partial_side, self.bn_scratch_side) if side else (self.bn_partial, self.bn_scratch)
             nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, partial, groups=u.groups)
+            if sync is not None:
+                self._sync_finalize(u, ops.bn_partial_sums(partial, nt, cv.cout, self._sync_sums(cv.cout, side)), m, sync)
+                return x2
             ops.bn_finalize_stats(partial, nt, m, cv.cout, u.bn.weight, u.bn.bias, u.bn.running_mean,
                                   u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM, scratch=scratch,
                                   tickets=self.bn_tickets_side if side else self.bn_tickets)
             return x2
         ops.conv_forward(u.src, u.w, k, k, st, pd, out=u.x, groups=u.groups, out_hw=(u.ho, u.wo))
+        if sync is not None:
+            self._sync_finalize(u, ops.bn_stats_sums(x2, self._sync_sums(cv.cout, side), self.bn_ws), m, sync)
+            return x2
         if training:
             ops.bn_forward_stats(x2, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var, u.stats, self.bn_ws,
                                  BN_EPS, BN_MOMENTUM)
@@ -1058,7 +1102,26 @@ class _Plan(object):
         ready = None
         if ws is self.bn_ws:                     # (the shortcut branch on its own stream never consumes fused sums)
             ready, self._bw_ready = self._bw_ready, None
-        if ready is not None and ready[0] is u and gmasked is None:
+        sync = self.net._sync_bn
+        if sync is not None:
+            # SyncBatchNorm backward: local (sum g, sum g*xhat) -> dgamma / dbeta; all-reduced sums + global count -> dx
+            group, world = sync
+            side = ws is not self.bn_ws
+            local = self._sync_sums(cv.cout, side, 1)
+            if ready is not None and ready[0] is u and gmasked is None:
+                ops.bn_partial_sums(self.bw_partial, ready[1], cv.cout, local)
+            else:
+                ops.bn_backward_sums(g2, None if (mask is None or bits is not None) else mask.view(m, cv.cout), u.x.view(m, cv.cout), u.stats,
+                                     local, ws, relu_bits=bits)
+            total = self._sync_sums(cv.cout, side, 2)
+            total.copy_(local)
+            torch.distributed.all_reduce(total, group=group)
+            dx = self._gbuf((dxkey, m, cv.cout, par), (m, cv.cout)) if (gmasked is not None or keep_gy) else g2
+            coef = self._sync_coef(cv.cout, side)
+            ops.bn_backward_apply_sums(g2, None if (mask is None or bits is not None) else mask.view(m, cv.cout), u.x.view(m, cv.cout),
+                                       u.stats, bn.weight, local, total, float(m) * world, bn._dgamma, bn._dbeta, dx, coef,
+                                       gmasked=None if gmasked is None else gmasked.view(m, cv.cout), relu_bits=bits)
+        elif ready is not None and ready[0] is u and gmasked is None:
             # the data gradient that wrote gy already reduced (sum g, sum g*xhat) per tile: no reduction pass
             dx = self._gbuf((dxkey, m, cv.cout, par), (m, cv.cout)) if keep_gy else g2
             ops.bn_backward_partials(g2, bits, u.x.view(m, cv.cout), u.stats, bn.weight, self.bw_partial, ready[1],

@@ -149,10 +149,7 @@ def main(args):
     model = build_model(args, num_classes)
     criterion = initialisers.get_criterion(args, dataset, model, num_classes)
     if args.sync_bn and args.distributed:
-        # train.py:190-191 converts to SyncBatchNorm (opt-in, off in every published recipe).  The native BN
-        # statistics are per-replica: refuse rather than silently train a different model.
-        raise NotImplementedError("--sync-bn: cross-replica batch statistics are not built into the native BN kernels "
-                                  "(per-replica statistics only, the reference's default); drop the flag")
+        model.enable_sync_bn()                # train.py:190-191: batch statistics over all ranks
     if args.opt.lower() not in ("sgd", "nesterov"):
         raise RuntimeError("Invalid optimizer {}. Only SGD and RMSprop are supported.".format(args.opt))
     if args.decoup:

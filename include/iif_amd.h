@@ -414,6 +414,24 @@ int iif_bn_backward_partials(const void* gy, const uint8_t* relu_bits, const voi
                              const float* stats, const float* gamma, const float* partial, int n_partials,
                              float* dgamma, float* dbeta, void* dx, void* workspace, int64_t workspace_bytes,
                              void* stream);
+/* Cross-replica batch statistics (nn.SyncBatchNorm, classification/train.py:190-191): reduction and normalisation as
+ * separate calls so that the host can all-reduce the per-channel sums of all ranks in between.
+ *   iif_bn_partial_sums         sums[0][c] / sums[1][c] = column sums of partial rows [n][2][c] (fixed order, fp64)
+ *   iif_bn_stats_sums           the same straight from x [m, c]: (sum x, sum x^2); workspace as iif_bn_forward_stats
+ *   forward: all-reduce sums, then iif_bn_finalize_stats(sums, 1, m * world, ...) (one "partial row", global count)
+ *   iif_bn_backward_sums        (sum g, sum g*xhat) of this rank, g gated by y_mask > 0 or relu_bits
+ *   iif_bn_backward_apply_sums  dgamma / dbeta from the LOCAL sums (the gradient all-reduce averages them as it does every
+ *                               parameter gradient), dx with mean(g), mean(g*xhat) from the all-reduced total_sums and
+ *                               total_count = m * world; gmasked nullable; coef_scratch: 3*c floats */
+int iif_bn_partial_sums(const float* partial, int n_partials, int c, float* sums, void* stream);
+int iif_bn_stats_sums(const void* x, int dtype, int64_t m, int c, float* sums, void* workspace, int64_t workspace_bytes,
+                      void* stream);
+int iif_bn_backward_sums(const void* gy, const void* y_mask, const uint8_t* relu_bits, const void* x, int dtype, int64_t m,
+                         int c, const float* stats, float* sums, void* workspace, int64_t workspace_bytes, void* stream);
+int iif_bn_backward_apply_sums(const void* gy, const void* y_mask, const uint8_t* relu_bits, const void* x, int dtype,
+                               int64_t m, int c, const float* stats, const float* gamma, const float* local_sums,
+                               const float* total_sums, double total_count, float* dgamma, float* dbeta, void* dx,
+                               void* gmasked, float* coef_scratch, void* stream);
 /* the same with the slice reduction and the finalisation of > 512 partial rows in one launch (tickets as above) */
 int iif_bn_backward_partials_fused(const void* gy, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,
                                    const float* stats, const float* gamma, const float* partial, int n_partials,

@@ -82,12 +82,71 @@ def emulate(out_path, steps, world, lr=0.05):
     torch.save({"params": net.param_arena.detach().cpu(), "losses": losses}, out_path)
 
 
+def run_syncbn(out_path, steps, arch, dt_name, world, rank):
+    """``--sync-bn``: every rank feeds its slice of ONE global batch; with cross-replica statistics the data-parallel run is
+    the single-process run on the whole batch (world == 1: that reference run)."""
+    from iif_amd import resnet_cifar, resnet_pytorch
+    from iif_amd.custom import IIFLoss
+    from iif_amd.ddp import broadcast_parameters
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    torch.manual_seed(5)
+    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    if arch == "resnet20":
+        net = resnet_cifar.resnet20(num_classes=10, use_norm="None", device=dev, compute_dtype=dt)
+        hw, C = 32, 10
+    else:
+        net = resnet_pytorch.resnet50(num_classes=10, use_norm="None", pretrained="None", device=dev, compute_dtype=dt)
+        hw, C = 64, 10
+        # random-init ResNet-50 amplifies a single flipped ReLU decision (layer4 has 32 rows per rank here) to 10 % of a
+        # gradient; the conditioned initialisation of fixture G16 (bn3 gamma x 0.1) makes 1e-4 testable
+        with torch.no_grad():
+            for name, p in net.named_parameters():
+                if name.endswith("bn3.weight"):
+                    p.mul_(0.1)
+    net.train()
+
+    class _D(object):
+        def get_cls_num_list(self):
+            return [500, 300, 200, 120, 80, 50, 30, 20, 10, 5]
+    crit = IIFLoss(_D(), variant="raw", reduction="mean", device=dev)
+    g = torch.Generator().manual_seed(91)
+    B = 16
+    x = torch.randn(B, 3, hw, hw, generator=g)
+    y = torch.randint(0, C, (B,), generator=g)
+    reducer = None
+    if world > 1:
+        broadcast_parameters(net)
+        net.enable_sync_bn()
+        reducer = net.make_reducer(bucket_bytes=256 << 10)
+        per = B // world
+        x, y = x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]
+    x, y = x.to(dev), y.to(dev)
+    scale = reducer.grad_scale if reducer is not None else 1.0
+    losses, logits0, rstat0 = [], None, None
+    for it in range(steps):
+        loss, lg = net.loss_and_backward(x, y, crit, reducer=reducer)
+        if it == 0:
+            logits0 = lg.detach().float().cpu().clone()
+            rstat0 = net._rstat.detach().cpu().clone()       # after ONE forward: depends on the statistics only
+        net.sgd_step(0.01 if arch == "resnet20" else 0.002, 0.9, 1e-4, grad_scale=scale)
+        losses.append(float(loss.item()))
+    torch.cuda.synchronize()
+    torch.save({"params": net.param_arena.detach().cpu(), "losses": losses, "logits0": logits0,
+                "rstat": net._rstat.detach().cpu(), "rstat0": rstat0}, out_path)
+
+
 if __name__ == "__main__":
     out_dir, steps = sys.argv[1], int(sys.argv[2])
     data = sys.argv[3] if len(sys.argv) > 3 else "same"
     mode = sys.argv[4] if len(sys.argv) > 4 else "allreduce"
     bf16 = len(sys.argv) > 5 and sys.argv[5] == "bf16"
     dist.init_process_group("gloo")
+    if data == "syncbn":
+        run_syncbn(os.path.join(out_dir, "rank%d.pt" % dist.get_rank()), steps, mode, sys.argv[5], dist.get_world_size(), dist.get_rank())
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0)
     # the bf16 comparison needs a well-conditioned recipe: at lr 0.05 the raw-IIF loss of this random net swings
     # 8 -> 70 -> 7 within six steps and amplifies any rounding; at 0.002 it descends smoothly
     run(os.path.join(out_dir, "rank%d.pt" % dist.get_rank()), steps, True, data, mode, bf16, lr=BF16_LR if bf16 else 0.05)

@@ -63,3 +63,33 @@ def test_bf16_buckets_keep_the_fp32_loss_curve(tmp_path):
             assert abs(a - b) <= 1e-3 * abs(b), (got["losses"], emu["losses"][rk])
         assert ((got["params"] - emu["params"]).norm() / emu["params"].norm()).item() <= 1e-3
     assert torch.equal(low[0]["params"], low[1]["params"])        # replicas stay identical
+
+
+@pytest.mark.parametrize("arch,dt,port", [("resnet20", "f32", 29551), ("resnet50", "f32", 29552), ("resnet50", "bf16", 29553)])
+def test_sync_bn_two_ranks_equal_the_whole_batch_on_one_rank(tmp_path, arch, dt, port):
+    """``--sync-bn`` (classification/train.py:190-191): two ranks, each with half of one batch and cross-replica batch
+    statistics, against ONE process on the whole batch.  fp32: logits of both halves, the mean of the two ranks' losses and the
+    parameters after 3 SGD steps within 1e-4 / 2e-4 (summation order is all that differs); bf16: the fused-statistics
+    path, logits within bf16 rounding.  Running statistics are the global ones on every rank.
+    The statistics of the two runs differ in the last bits (order of summation), which flips an occasional ReLU decision of a
+    pre-activation within 1e-6 of zero (scripts/dbg_sync_bn.py counts them: 1 of 131072 in layer4's output, worth 1/64 of a
+    dbeta entry there); later losses therefore get 1e-3, and the parameters are compared in the 2-norm."""
+    import ddp_gpu_worker
+    ranks = _launch(tmp_path, port, 3, "syncbn", arch, dt)
+    ddp_gpu_worker.run_syncbn(str(tmp_path / "single.pt"), 3, arch, dt, 1, 0)
+    one = torch.load(tmp_path / "single.pt", weights_only=False)
+    full = torch.cat([ranks[0]["logits0"], ranks[1]["logits0"]], 0)
+    tol = 1e-4 if dt == "f32" else 3e-2
+    assert (full - one["logits0"]).abs().max().item() <= tol * one["logits0"].abs().max().item()
+    for it in range(3):
+        both = 0.5 * (ranks[0]["losses"][it] + ranks[1]["losses"][it])
+        ltol = 3e-2 if dt != "f32" else (1e-4 if it == 0 else 1e-3)
+        assert abs(both - one["losses"][it]) <= ltol * abs(one["losses"][it]), (it, both, one["losses"][it])
+    assert torch.equal(ranks[0]["params"], ranks[1]["params"])
+    if dt == "f32":
+        assert ((ranks[0]["params"] - one["params"]).norm() / one["params"].norm()).item() <= 2e-4
+        # running statistics: global mean / unbiased variance with the global count — exact after the first forward,
+        # then as close as the parameters are
+        assert (ranks[0]["rstat0"] - one["rstat0"]).abs().max().item() <= 2e-5 * one["rstat0"].abs().max().item()
+        assert (ranks[0]["rstat"] - one["rstat"]).abs().max().item() <= 1e-3 * one["rstat"].abs().max().item()
+        assert torch.equal(ranks[0]["rstat"], ranks[1]["rstat"])

@@ -352,3 +352,64 @@ def test_bn_reduce_and_finalize_in_one_launch_is_bit_identical(nt, c):
         assert tickets.abs().sum().item() == 0
         for a_, b_ in zip(res[0], res[1]):
             assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 14, 14), (2, 2048, 2, 2), (6, 24, 5, 3)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("masked", ["bits", "ymask", "plain", "gmasked"])
+def test_sync_bn_pieces_of_two_halves_equal_the_whole_batch(shape, dt, masked):
+    """SyncBatchNorm split entry points (classification/train.py:190-191): two "ranks" hold the halves of one batch; their
+    per-rank sums added (what the all-reduce does) and finalised with the global count give the whole-batch statistics, and the
+    backward pieces (local sums -> dgamma / dbeta, total sums -> dx) add up to the whole-batch bn_backward."""
+    from iif_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(3 * c + h)
+    m, mh = n * h * w, (n // 2) * h * w
+    xd = (torch.randn(m, c, generator=g) * 1.3 + 0.2).to(dt).to(DEV)
+    gyd = torch.randn(m, c, generator=g).to(dt).to(DEV)
+    gd, bd = (torch.rand(c, generator=g) + 0.5).to(DEV), (torch.randn(c, generator=g) * 0.2).to(DEV)
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    ws = ops.bn_workspace(m, c, DEV)
+    stats = torch.empty(4, c, device=DEV)
+    ops.bn_forward_stats(xd, gd, bd, rm, rv, stats, ws)
+    # forward pieces
+    halves = [slice(0, mh), slice(mh, m)]
+    sums = [ops.bn_stats_sums(xd[s], torch.empty(2, c, device=DEV), ws).clone() for s in halves]
+    total = sums[0] + sums[1]
+    rm2, rv2 = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    stats2 = torch.empty(4, c, device=DEV)
+    ops.bn_finalize_stats(total, 1, m, c, gd, bd, rm2, rv2, stats2, 1e-5, 0.1)
+    assert (stats2[:2] - stats[:2]).abs().max().item() <= 2e-5 * stats[:2].abs().max().item()
+    assert (rm2 - rm).abs().max().item() <= 1e-5 and (rv2 - rv).abs().max().item() <= 1e-5 * rv.abs().max().item()
+    # backward pieces against the whole-batch kernel, on the SAME statistics
+    vec = 8 if dt == torch.bfloat16 else 4
+    yd = torch.empty_like(xd)
+    bits = torch.zeros(m * c // vec, dtype=torch.uint8, device=DEV)
+    ops.bn_apply(xd, stats, yd, relu=True, relu_bits=bits)
+    ymask = yd if masked in ("ymask", "gmasked") else None
+    rbits = bits if masked == "bits" else None
+    dg, db, dx = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty_like(xd)
+    gm = torch.empty_like(xd) if masked == "gmasked" else None
+    ops.bn_backward(gyd, ymask, xd, stats, gd, dg, db, dx, ws, gmasked=gm, relu_bits=rbits)
+    local = []
+    for s in halves:
+        hb = None if rbits is None else rbits[s.start * c // vec:s.stop * c // vec]
+        local.append(ops.bn_backward_sums(gyd[s], None if ymask is None else ymask[s], xd[s], stats, torch.empty(2, c, device=DEV), ws,
+                                          relu_bits=hb).clone())
+    tot = local[0] + local[1]
+    dgs, dbs = [], []
+    dx2 = torch.empty_like(xd)
+    gm2 = torch.empty_like(xd) if gm is not None else None
+    coef = torch.empty(3, c, device=DEV)
+    for s, lc in zip(halves, local):
+        hb = None if rbits is None else rbits[s.start * c // vec:s.stop * c // vec]
+        dgh, dbh = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+        ops.bn_backward_apply_sums(gyd[s], None if ymask is None else ymask[s], xd[s], stats, gd, lc, tot, float(m), dgh, dbh, dx2[s], coef,
+                                   gmasked=None if gm2 is None else gm2[s], relu_bits=hb)
+        dgs.append(dgh); dbs.append(dbh)
+    tol = 2e-5 if dt == torch.float32 else 2.0 ** -7
+    assert ((dgs[0] + dgs[1]) - dg).abs().max().item() <= 2e-5 * max(1.0, dg.abs().max().item())
+    assert ((dbs[0] + dbs[1]) - db).abs().max().item() <= 2e-5 * max(1.0, db.abs().max().item())
+    assert (dx2.float() - dx.float()).abs().max().item() <= tol * max(1e-3, dx.float().abs().max().item())
+    if gm is not None:
+        assert torch.equal(gm2, gm)
