@@ -763,6 +763,8 @@ class _Plan(object):
             pr = os.environ.get("IIF_WGRAD_STREAM_PRIORITY")
             self.wg_stream = torch.cuda.Stream(device=dev) if pr is None else torch.cuda.Stream(device=dev, priority=int(pr))
         self._wg_events = {}
+        self.stem_wgrad_main = self.wg_stream is not None and not os.environ.get("IIF_STEM_WGRAD_SIDE")
+        self.wg_ws_stem = None
         # blocks the weight-gradient stream may lag behind the compute stream: dx buffers rotate over `wg_lag` slots,
         # block-input gradients over wg_lag + 1, and block b waits for the weight gradients of the blocks >= b + wg_lag
         self.wg_lag = max(2, int(os.environ.get("IIF_WGRAD_LAG", "2")))
@@ -1073,6 +1075,15 @@ class _Plan(object):
     def _stem_wgrad(self, u, dx4):
         cv = u.conv
         if u.s2d:
+            if self.stem_wgrad_main:
+                # last kernel of backward: on the compute stream (own split-K workspace) it runs next to the weight
+                # gradients the side stream still owes, instead of queueing behind them while the compute stream idles
+                if self.wg_ws_stem is None:
+                    self.wg_ws_stem = torch.empty(64 << 20, dtype=torch.uint8, device=self.dev)
+                ops.conv_wgrad(u.src, dx4, 4, 4, 1, 2, ldw=u.dwp.shape[1], out=u.dwp, workspace=self.wg_ws_stem)
+                ops.stem_s2d_unpack_grad(u.dwp, cv.cout, cv.cin, cv.k, S2D_CPAD, cv._g2d)
+                return
+
             def stem():
                 ops.conv_wgrad(u.src, dx4, 4, 4, 1, 2, ldw=u.dwp.shape[1], out=u.dwp, workspace=self.wg_ws)
                 ops.stem_s2d_unpack_grad(u.dwp, cv.cout, cv.cin, cv.k, S2D_CPAD, cv._g2d)

@@ -216,9 +216,14 @@ def init_distributed_mode(args):
         args.distributed = False
         return
     args.distributed = True
+    # IIF_REHEARSE_ONE_GPU=1: every rank on GPU 0 with gloo carrying the collectives (RCCL refuses two ranks on one
+    # device) — the multi-rank control flow of train.py on a one-GPU box (tests/test_ddp_gpu.py); never a measured path
+    rehearse = bool(os.environ.get("IIF_REHEARSE_ONE_GPU"))
+    if rehearse:
+        args.gpu = 0
     if torch.cuda.is_available():
         torch.cuda.set_device(args.gpu)
-        args.dist_backend = "nccl"
+        args.dist_backend = "gloo" if rehearse else "nccl"
     else:
         args.dist_backend = "gloo"
     print("| distributed init (rank %d): %s" % (args.rank, args.dist_url), flush=True)

@@ -93,3 +93,23 @@ def test_sync_bn_two_ranks_equal_the_whole_batch_on_one_rank(tmp_path, arch, dt,
         assert (ranks[0]["rstat0"] - one["rstat0"]).abs().max().item() <= 2e-5 * one["rstat0"].abs().max().item()
         assert (ranks[0]["rstat"] - one["rstat"]).abs().max().item() <= 1e-3 * one["rstat"].abs().max().item()
         assert torch.equal(ranks[0]["rstat"], ranks[1]["rstat"])
+
+
+@pytest.mark.parametrize("extra,port", [([], 29561), (["--sync-bn", "--reduce-mode", "rs_ag"], 29562)])
+def test_train_cli_two_ranks_end_to_end(tmp_path, extra, port):
+    """``python -m torch.distributed.run ... -m iif_amd.train`` with two ranks (one-GPU rehearsal: both on GPU 0, gloo):
+    init_distributed_mode, the distributed sampler, parameter broadcast, the bucketed reducer under backward, optional
+    SyncBatchNorm + reduce-scatter buckets, evaluation with rank 0's BN buffers and the metric all-reduce, and the checkpoint
+    (written once, loadable, finite).  classification/train.py:176-292."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", IIF_REHEARSE_ONE_GPU="1")
+    out = tmp_path / "out"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "iif_amd.train", "--model", "resnet20", "--dset_name", "cifar10", "--classif", "iif",
+           "--iif", "raw", "-b", "16", "--epochs", "1", "--max-iters", "4", "-j", "0", "--print-freq", "2", "--output-dir", str(out),
+           "--compute-dtype", "f32"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    assert "Acc@1" in r.stdout and "best acc is" in r.stdout
+    assert r.stdout.count("Start training") == 1                  # printing is rank 0's (utils.setup_for_distributed)
+    ckpt = torch.load(out / "checkpoint.pth", map_location="cpu", weights_only=False)
+    assert ckpt["epoch"] == 0 and all(torch.isfinite(v).all() for v in ckpt["model"].values() if v.is_floating_point())
