@@ -170,8 +170,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* x, const float* 
             }
         }
         float v[V], w[V];
-        VT<T>::load(x + i * V, v);
-        if (RES) VT<T>::load(r + i * V, w);
+        VT<T>::load_nt(x + i * V, v);
+        if (RES) VT<T>::load_nt(r + i * V, w);
         unsigned bits = 0;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -285,8 +285,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T*
             }
         }
         float dy[V], xv[V], yv[V];
-        VT<T>::load(g_ + i * V, dy);
-        VT<T>::load(x + i * V, xv);
+        VT<T>::load_nt(g_ + i * V, dy);
+        VT<T>::load_nt(x + i * V, xv);
         if (MASK == 1) VT<T>::load(ymask + i * V, yv);
         unsigned mb = 0;
         if (MASK == 2) mb = bits[i];

@@ -28,6 +28,9 @@
 #include <stdlib.h>
 
 #include "common.h"
+#ifndef IIF_CONV_AUX_SRC
+#define IIF_CONV_AUX_SRC 0
+#endif
 
 namespace {
 
@@ -340,7 +343,11 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
             u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PITCH + chunk * 16);
             const int64_t o = (dst_row(a, m) * a.dpitch + goff + n) * 2;
             if (a.res) {
+#ifdef IIF_NT_RES
+                const u32x4 rr = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res + o));
+#else
                 const u32x4 rr = *reinterpret_cast<const u32x4*>(a.res + o);
+#endif
                 const unsigned rb = a.res_bits ? a.res_bits[o >> 4] : 0xffu;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -535,7 +542,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const unsigned off = ((vmask[i] >> t) & 1u) ? vbase[i] : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(A + (2 * wave + i) * 1024), 16, off, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(A + (2 * wave + i) * 1024), 16, off, soff, 0, IIF_CONV_AUX_SRC);
             }
 #pragma unroll
             for (int i = 0; i < NBI; ++i)
@@ -979,7 +986,7 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
             const unsigned soff = (unsigned)iks * 64u;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(dstl + i * 1024), 16, vb[i], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(dstl + i * 1024), 16, vb[i], soff, 0, IIF_CONV_AUX_SRC);
             ++gi;
             if (++iks == nk) { iks = 0; ++ij; if (ij < my_tiles) tile_rows(ij); }
         };

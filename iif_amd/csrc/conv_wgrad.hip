@@ -18,6 +18,12 @@
 #include <stdlib.h>
 
 #include "common.h"
+#ifndef IIF_WG_AUX_X
+#define IIF_WG_AUX_X 0
+#endif
+#ifndef IIF_WG_AUX_Y
+#define IIF_WG_AUX_Y 0
+#endif
 
 namespace {
 
@@ -324,13 +330,13 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
             const int ys = (py[i] << a.sshift) - a.pad + ttr[i], xs = (px[i] << a.sshift) - a.pad + tts[i];
             const bool ok = nval[i] && pm[i] < a.M && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
             const unsigned off = ok ? ((unsigned)(pb[i] + ys * a.Ws + xs) * (unsigned)a.xpitch + (unsigned)tch[i]) * (unsigned)sizeof(T) + gx : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_w*)(X + (NIX * wave + i) * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_w*)(X + (NIX * wave + i) * 1024), 16, off, 0, 0, IIF_WG_AUX_X);
         }
 #pragma unroll
         for (int i = 0; i < NIY; ++i) {
             const int m = step * ROWS + yr[i];
             const unsigned off = (ycol[i] != OOB && m < a.M) ? (unsigned)m * (unsigned)a.ypitch * (unsigned)sizeof(T) + ycol[i] + gy : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)(Y + (NIY * wave + i) * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)(Y + (NIY * wave + i) * 1024), 16, off, 0, 0, IIF_WG_AUX_Y);
         }
     };
     auto advance = [&]() {
@@ -508,7 +514,7 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, u
         const int lc = SW::logical(lane & 7, prow);
         const bool ok = (unsigned)cx.n < (unsigned)a.N && (unsigned)(cx.yp - 1) < (unsigned)a.H && (unsigned)(cx.xp - 1) < (unsigned)a.W;
         const unsigned off = ok ? ((unsigned)(cx.n * HW + (cx.yp - 1) * a.W + cx.xp - 1) * (unsigned)a.Cs + (unsigned)(ci0 + lc * 8)) * 2u : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_w*)(XS + ((xblk * 32 + 8 * wave) & (XR - 1)) * RB), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_w*)(XS + ((xblk * 32 + 8 * wave) & (XR - 1)) * RB), 16, off, 0, 0, IIF_WG_AUX_X);
         advance(cx); ++xblk;
     };
     auto issue_y = [&]() {
@@ -516,7 +522,7 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, u
         const int lc = SW::logical(lane & 7, prow);
         const bool ok = (unsigned)cy.n < (unsigned)a.N && (unsigned)(cy.yp - 1) < (unsigned)a.H && (unsigned)(cy.xp - 1) < (unsigned)a.W;
         const unsigned off = ok ? ((unsigned)(cy.n * HW + (cy.yp - 1) * a.W + cy.xp - 1) * (unsigned)a.Cd + (unsigned)(co0 + lc * 8)) * 2u : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)(YS + ((yblk * 32 + 8 * wave) & (YR - 1)) * RB), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)(YS + ((yblk * 32 + 8 * wave) & (YR - 1)) * RB), 16, off, 0, 0, IIF_WG_AUX_Y);
         advance(cy); ++yblk;
     };
 
@@ -653,7 +659,7 @@ __global__ void __launch_bounds__(256) conv4x4_s2d_wgrad_kernel(WgStemArgs a, un
     auto issue_x = [&]() {
         const bool ok = (unsigned)cx.n < (unsigned)a.N && (unsigned)(cx.yp - 2) < (unsigned)a.H && (unsigned)(cx.xp - 2) < (unsigned)a.W;
         const unsigned off = ok ? ((unsigned)(cx.n * HW + (cx.yp - 2) * a.W + cx.xp - 2) * 16u + (unsigned)((lane & 1) * 8)) * 2u : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_w*)(XS + ((xblk * 32) & (XR - 1)) * XRB), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_w*)(XS + ((xblk * 32) & (XR - 1)) * XRB), 16, off, 0, 0, IIF_WG_AUX_X);
         advance(cx); ++xblk;
     };
     auto issue_y = [&]() {
@@ -661,7 +667,7 @@ __global__ void __launch_bounds__(256) conv4x4_s2d_wgrad_kernel(WgStemArgs a, un
         const int lc = SW::logical(lane & 7, prow);
         const bool ok = (unsigned)cy.n < (unsigned)a.N && (unsigned)(cy.yp - 2) < (unsigned)a.H && (unsigned)(cy.xp - 2) < (unsigned)a.W;
         const unsigned off = ok ? ((unsigned)(cy.n * HW + (cy.yp - 2) * a.W + cy.xp - 2) * 64u + (unsigned)(lc * 8)) * 2u : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)(YS + ((yblk * 32 + 8 * wave) & (YR - 1)) * YRB), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)(YS + ((yblk * 32 + 8 * wave) & (YR - 1)) * YRB), 16, off, 0, 0, IIF_WG_AUX_Y);
         advance(cy); ++yblk;
     };
 
@@ -724,6 +730,11 @@ __global__ void __launch_bounds__(256) conv4x4_s2d_wgrad_kernel(WgStemArgs a, un
 // dw[k][n] = sum_s slab[s][k][n] for n < K (pad columns untouched), fixed order.  blockIdx.y selects a chunk
 // of `chunk` consecutive slabs; with gridDim.y > 1 the chunk sums go to out + blockIdx.y*slab (second stage
 // then runs with the chunk sums as its slabs).
+#ifdef IIF_NT_SLABS
+#define IIF_SLAB_LD(p) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p))
+#else
+#define IIF_SLAB_LD(p) (*reinterpret_cast<const f32x4*>(p))
+#endif
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int splits, int chunk, int64_t slab, int Cd,
                                                            int ldw, int K, float* out, int64_t out_stride) {
     const int64_t total4 = (int64_t)Cd * ldw / 4;
@@ -734,16 +745,16 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int 
         const int64_t e = i * 4;
         const int n = (int)(e % ldw);
         if (n >= K) continue;
-        f32x4 s = *reinterpret_cast<const f32x4*>(ws + (int64_t)s0 * slab + e);
+        f32x4 s = IIF_SLAB_LD(ws + (int64_t)s0 * slab + e);
         int j = s0 + 1;
         for (; j + 3 < s1; j += 4) {                      // 4 slabs in flight, added in slab order
-            const f32x4 t0 = *reinterpret_cast<const f32x4*>(ws + (int64_t)j * slab + e);
-            const f32x4 t1 = *reinterpret_cast<const f32x4*>(ws + (int64_t)(j + 1) * slab + e);
-            const f32x4 t2 = *reinterpret_cast<const f32x4*>(ws + (int64_t)(j + 2) * slab + e);
-            const f32x4 t3 = *reinterpret_cast<const f32x4*>(ws + (int64_t)(j + 3) * slab + e);
+            const f32x4 t0 = IIF_SLAB_LD(ws + (int64_t)j * slab + e);
+            const f32x4 t1 = IIF_SLAB_LD(ws + (int64_t)(j + 1) * slab + e);
+            const f32x4 t2 = IIF_SLAB_LD(ws + (int64_t)(j + 2) * slab + e);
+            const f32x4 t3 = IIF_SLAB_LD(ws + (int64_t)(j + 3) * slab + e);
             s += t0; s += t1; s += t2; s += t3;
         }
-        for (; j < s1; ++j) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)j * slab + e);
+        for (; j < s1; ++j) s += IIF_SLAB_LD(ws + (int64_t)j * slab + e);
         *reinterpret_cast<f32x4*>(dst + e) = s;
     }
 }

@@ -12,6 +12,12 @@ template <> struct VT<float> {
     static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
         *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
     }
+    // Non-temporal load: the line will not be used again for a long time (an activation that is next read in backward, an
+    // operand at its last use).  The hint keeps it from displacing what the NEXT kernel reads back (the tensor this kernel
+    // writes) in L2 / the Infinity Cache: -2.2 % on the ResNet50 step from the two BN apply kernels alone.
+    static __device__ __forceinline__ void load_nt(const float* p, float (&v)[4]) {
+        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
 };
 template <> struct VT<unsigned short> {
     static constexpr int V = 8;
@@ -20,11 +26,20 @@ template <> struct VT<unsigned short> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_bits_to_f32(t[i] & 0xffffu); v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u); }
     }
+    static __device__ __forceinline__ void load_nt(const unsigned short* p, float (&v)[8]) {
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_bits_to_f32(t[i] & 0xffffu); v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u); }
+    }
     static __device__ __forceinline__ void store(unsigned short* p, const float (&v)[8]) {
         u32x4 t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) t[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+#ifdef IIF_NT_STORE
+        __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+#else
         *reinterpret_cast<u32x4*>(p) = t;
+#endif
     }
 };
 }  // namespace
