@@ -356,7 +356,11 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
                     v[q] = pack_bf16x2(lo, hi);
                 }
             }
+#ifndef IIF_NO_NT_CONV_STORE     // the tile is next read by another XCD (BN apply): streaming it out keeps the pixel operand's lines in L2 (-0.7 % on the step)
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + o));
+#else
             *reinterpret_cast<u32x4*>(a.dst + o) = v;
+#endif
             if (a.bw_x) {
                 const u32x4 xv = *reinterpret_cast<const u32x4*>(a.bw_x + o);
                 const unsigned mb = a.bw_bits ? a.bw_bits[o >> 4] : 0xffu;
@@ -1127,7 +1131,11 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
                         v[q] = pack_bf16x2(lo, hi);
                     }
                 }
+#ifndef IIF_NO_NT_CONV_STORE     // the tile is next read by another XCD (BN apply): streaming it out keeps the pixel operand's lines in L2 (-0.7 % on the step)
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + o));
+#else
                 *reinterpret_cast<u32x4*>(a.dst + o) = v;
+#endif
                 if (a.bw_x) {
                     const u32x4 xv = *reinterpret_cast<const u32x4*>(a.bw_x + o);
                     const unsigned mb = a.bw_bits ? a.bw_bits[o >> 4] : 0xffu;
