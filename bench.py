@@ -176,7 +176,7 @@ def profiled_traffic():
                 step_mb += float(row[4])
             except ValueError:
                 continue
-            if "conv_igemm" in row[0] or "conv_wgrad" in row[0] or "conv3x3_halo" in row[0]:
+            if any(t in row[0] for t in ("conv_igemm", "conv_wgrad", "conv3x3_", "conv4x4_", "gemm1x1_stream")):
                 mb += float(row[4]); launches += float(row[1])
     if launches <= 0:
         return None

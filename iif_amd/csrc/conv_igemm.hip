@@ -343,7 +343,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
             u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PITCH + chunk * 16);
             const int64_t o = (dst_row(a, m) * a.dpitch + goff + n) * 2;
             if (a.res) {
-#ifdef IIF_NT_RES
+#ifndef IIF_NO_NT_EPILOGUE_LOADS   // the residual's last use
                 const u32x4 rr = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res + o));
 #else
                 const u32x4 rr = *reinterpret_cast<const u32x4*>(a.res + o);
@@ -362,7 +362,11 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
             *reinterpret_cast<u32x4*>(a.dst + o) = v;
 #endif
             if (a.bw_x) {
+#ifndef IIF_NO_NT_EPILOGUE_LOADS   // streamed once by this kernel (next reader: the BN backward, from another XCD)
+                const u32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.bw_x + o));
+#else
                 const u32x4 xv = *reinterpret_cast<const u32x4*>(a.bw_x + o);
+#endif
                 const unsigned mb = a.bw_bits ? a.bw_bits[o >> 4] : 0xffu;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1137,7 +1141,11 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
                 *reinterpret_cast<u32x4*>(a.dst + o) = v;
 #endif
                 if (a.bw_x) {
-                    const u32x4 xv = *reinterpret_cast<const u32x4*>(a.bw_x + o);
+    #ifndef IIF_NO_NT_EPILOGUE_LOADS   // streamed once by this kernel (next reader: the BN backward, from another XCD)
+                const u32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.bw_x + o));
+#else
+                const u32x4 xv = *reinterpret_cast<const u32x4*>(a.bw_x + o);
+#endif
                     const unsigned mb = a.bw_bits ? a.bw_bits[o >> 4] : 0xffu;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
