@@ -439,6 +439,10 @@ def main():
                 "traffic_unit": "bytes/launch",
                 "traffic_detail": traffic,
                 # shape-aware speed of light: per launch max(FLOPs / MFMA peak, ideal bytes / HBM peak)
+                # both roofs of the family as a whole ("against max(t_MFMA, t_HBM) with both terms shown"): at
+                # 153 FLOP per ideal byte the binding one is HBM (machine balance 2500 / 8 = 312 FLOP per byte)
+                "t_mfma_ms_per_step": round(tot_fl / nsamp / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3, 3),
+                "t_hbm_ms_per_step": round(sum(v[3] for v in by.values()) / nsamp / 8e12 * 1e3, 3),
                 "sol_ms_per_step": round(timer.sol_ms / nsamp, 3),
                 "frac_of_shape_sol": round(timer.sol_ms / tot_ms, 4) if tot_ms > 0 else None,
                 "bracketed_steps": timer.sampled_steps,
