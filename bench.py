@@ -11,10 +11,14 @@ SGD, all through the hand-written gfx950 kernels (libiif_amd.so); inputs are
 resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects in that line:
-  roofline     - the MFMA implicit-GEMM convolution family (forward / dgrad /
-                 wgrad kernels): algorithmic FLOPs of every launch in one step
-                 divided by the summed launch durations measured with HIP events
-                 on the launching stream over the timed region.
+  roofline     - the step against both roofs, from THIS run's wall clock (nothing in it can exceed
+                 ms_per_step): algorithmic FLOPs of the convolution launches of one step / ms_per_step
+                 against the dense bf16 MFMA peak (`frac`), and `hbm` = algorithmic bytes of one step
+                 (every convolution operand and result once + the BN / pooling / SGD passes this
+                 dataflow cannot avoid, formula in `hbm.formula`) / ms_per_step against 8 TB/s, which
+                 is the roof that binds.  `brackets` keeps the HIP-event table per launch kind; those
+                 durations OVERLAP (three streams) and are labelled so.  profiles/README.md holds the
+                 recipe that recomputes every number from profiles/r3_*.
   cpu_baseline - the CPU oracle (torch-CPU restatement of the reference step,
                  oracle/) timed on the host cores of this box on a bounded sample.
 """
@@ -153,6 +157,41 @@ class ConvTimer(object):
         return tot_ms, tot_fl, by
 
 
+def streaming_pass_bytes(net, batch, image):
+    """Algorithmic HBM bytes per step of everything that is NOT a convolution launch, for the dataflow this design
+    cannot go below: per conv+BN unit with an output of E elements (s = element size)
+        forward  normalise (+ReLU):   read y, write a                     2 s E   (batch statistics ride on the conv epilogue: 0)
+        backward normalise:           read g, read y, write dy            3 s E   (the two BN-backward sums ride on the dgrad epilogue: 0)
+        block outputs:                + read the residual                  1 s E
+    plus the stem's max-pool (forward: the stem's activation is never stored, only the pooled tensor is written; backward:
+    read pooled gradient, write stem gradient), the global average pool, SGD = 20 B / parameter (read p, g, m; write p, m)
+    and the fused IIF loss (B*C*(4+4) + 8B + 4C + 4).  ReLU decisions are 1 bit per element (s E / 16 bytes, written once,
+    read once).  Returns (bytes, formula text)."""
+    plan = net._plan(batch, image, image)
+    s = 2 if plan.dt == torch.bfloat16 else 4
+    total = 0.0
+    for u in plan.units:
+        e = float(u.n * u.ho * u.wo * u.conv.cout)
+        total += (2 + 3) * s * e + 2 * e / 8.0
+    for b in plan.blocks:
+        last = b["units"][-1]
+        total += s * float(last.n * last.ho * last.wo * last.conv.cout)        # residual read of the block-end normalise
+    if net.style == "imagenet":
+        u = plan.stem
+        e_pool = float(plan.pool_out.numel())
+        e_stem = float(u.n * u.ho * u.wo * u.conv.cout)
+        # fused bn1+relu+maxpool: the generic unit terms above charged write-a / read-a-side passes the fusion removes
+        total += s * e_pool * 2 + e_pool          # pooled tensor written + index byte; pooled gradient read
+        total -= s * e_stem                       # the activation a is never written
+    total += 2 * s * float(plan.final.numel())    # global average pool forward read + backward write
+    params = float(sum(p.numel() for p in net.parameters()))
+    total += 20.0 * params
+    C = net.num_classes
+    total += batch * C * 8.0 + 8.0 * batch + 4.0 * C + 4.0
+    return total, ("sum over conv+BN units of (2+3)*s*E + E/4 bits, + s*E residual per block, max-pool and average pool passes, "
+                   "20 B/parameter SGD, fused IIF loss B*C*8; s = %d" % s)
+
+
 def profiled_traffic():
     """HBM bytes per launch of the convolution family from the committed rocprofv3 PMC passes
     (profiles/r<round>_*_pmc_hbm_traffic.csv, the newest round: FETCH_SIZE x2 + WRITE_SIZE of the same bench command, collected in
@@ -258,6 +297,7 @@ def main():
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-step", action="store_true", help="skip the fp32 (parity mode) step timing")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
@@ -286,8 +326,15 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
         else:
             dist.init_process_group("gloo")
-    if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        # a scaling run that silently measured another world size would poison SCALE_r*.json
+        if args.backend == "nccl" and (args.gpus > 1 or world > 1):
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d under nccl: launch with torch.distributed.run "
+                             "--nproc-per-node %d" % (args.gpus, world, args.gpus))
+        if rank == 0:
+            print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if dist.is_initialized() and dist.get_world_size() != world:
+        raise SystemExit("bench.py: process group has %d ranks, WORLD_SIZE says %d" % (dist.get_world_size(), world))
 
     from iif_amd import ops, resnet_pytorch
     from iif_amd.custom import IIFLoss
@@ -422,39 +469,73 @@ def main():
         if timer is not None:
             tot_ms, tot_fl, by = timer.summary()
             nl = len(timer.records)
-            ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-            traffic = profiled_traffic() if (args.model, B, C, args.image, args.dtype) == ("resnet50", 256, 1000, 224, "bf16") else None
-            if traffic:
-                # the step as a whole against the HBM roofline: profiled bytes of every kernel / this run's step time
-                gbps = traffic["all_kernels_GB_per_step"] / (out["ms_per_step"] * 1e-3)
-                out["step_hbm"] = {"bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
-                                   "frac": round(gbps / 8000.0, 4), "traffic_GB_per_step": traffic["all_kernels_GB_per_step"],
-                                   "source": traffic["source"]}
+            headline = (args.model, B, C, args.image, args.dtype) == ("resnet50", 256, 1000, 224, "bf16")
+            traffic = profiled_traffic() if headline else None
+            step_ms = out["ms_per_step"]
+            gflop_step = tot_fl / nsamp / 1e9
+            conv_bytes = sum(v[3] for v in by.values()) / nsamp           # every operand / result of a launch exactly once
+            pass_bytes, formula = streaming_pass_bytes(net, B, args.image)
+            alg_bytes = conv_bytes + pass_bytes
+            ach_tf = gflop_step / step_ms                                   # GFLOP / ms = TFLOP/s
+            ach_gbs = alg_bytes / (step_ms * 1e-3) / 1e9
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_dma*_kernel + conv_wgrad_dma_kernel (implicit-GEMM convolution family)",
-                "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                # HBM bytes per launch of the same kernels from the committed PMC passes (null off the profiled config)
-                "traffic": round(traffic["MB_per_launch"] * 1e6) if traffic else None,
-                "traffic_unit": "bytes/launch",
-                "traffic_detail": traffic,
-                # shape-aware speed of light: per launch max(FLOPs / MFMA peak, ideal bytes / HBM peak)
-                # both roofs of the family as a whole ("against max(t_MFMA, t_HBM) with both terms shown"): at
-                # 153 FLOP per ideal byte the binding one is HBM (machine balance 2500 / 8 = 312 FLOP per byte)
-                "t_mfma_ms_per_step": round(tot_fl / nsamp / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3, 3),
-                "t_hbm_ms_per_step": round(sum(v[3] for v in by.values()) / nsamp / 8e12 * 1e3, 3),
-                "sol_ms_per_step": round(timer.sol_ms / nsamp, 3),
-                "frac_of_shape_sol": round(timer.sol_ms / tot_ms, 4) if tot_ms > 0 else None,
-                "bracketed_steps": timer.sampled_steps,
-                "launches_per_step": nl // nsamp,
-                "avg_launch_us": round(1000.0 * tot_ms / max(nl, 1), 2),
-                "algorithmic_gflop_per_step": round(tot_fl / nsamp / 1e9, 1),
-                "conv_ms_per_step": round(tot_ms / nsamp, 3),
-                "by_kind_ms_per_step": {k: round(v[1] / nsamp, 3) for k, v in by.items()},
-                "by_kind_tflops": {k: round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0},
-                # every operand / result of a launch moved exactly once (what `traffic_detail` is to be compared with)
-                "by_kind_ideal_GB_per_step": {k: round(v[3] / nsamp / 1e9, 2) for k, v in by.items()},
+                # the matrix roof north_star names: algorithmic convolution FLOPs of one step over THIS run's step time
+                "bound": "mfma", "kernel": "whole training step (implicit-GEMM convolution family carries the FLOPs)",
+                "achieved": round(ach_tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach_tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                "algorithmic_gflop_per_step": round(gflop_step, 1),
+                "t_mfma_ms_per_step": round(gflop_step / MFMA_BF16_PEAK_TFLOPS, 3),
+                # measured HBM bytes of one step (committed PMC passes of the same command; null off the profiled config)
+                "traffic": round(traffic["all_kernels_GB_per_step"] * 1e9) if traffic else None,
+                "traffic_unit": "bytes/step",
+                "traffic_source": traffic["source"] if traffic else None,
+                # the roof that BINDS this step: algorithmic bytes (formula below) over the same step time
+                "hbm": {"bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach_gbs / HBM_PEAK_GBS, 4),
+                        "algorithmic_GB_per_step": round(alg_bytes / 1e9, 2),
+                        "conv_operands_once_GB": round(conv_bytes / 1e9, 2),
+                        "streaming_passes_GB": round(pass_bytes / 1e9, 2),
+                        "t_hbm_ms_per_step": round(alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
+                        "formula": "conv: bytes of src + weights + dst (+ residual, + upstream x of a fused BN-backward sum) per launch, "
+                                   "each once; passes: " + formula,
+                        "measured_over_algorithmic": round(traffic["all_kernels_GB_per_step"] * 1e9 / alg_bytes, 3) if traffic else None},
+                "binding": "hbm",
+                # HIP-event brackets per launch kind.  The three streams of a step run CONCURRENTLY, so these durations overlap
+                # and their sum may exceed ms_per_step: they rank kernels, they are not a share of the step.
+                "brackets": {
+                    "note": "overlapped, sums across 3 streams; not comparable with ms_per_step",
+                    "bracketed_steps": timer.sampled_steps,
+                    "launches_per_step": nl // nsamp,
+                    "avg_launch_us": round(1000.0 * tot_ms / max(nl, 1), 2),
+                    "sum_ms_per_step_overlapped": round(tot_ms / nsamp, 3),
+                    "by_kind_ms_per_step_overlapped": {k: round(v[1] / nsamp, 3) for k, v in by.items()},
+                    "by_kind_tflops_in_bracket": {k: round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0},
+                    "by_kind_ideal_GB_per_step": {k: round(v[3] / nsamp / 1e9, 2) for k, v in by.items()},
+                    "conv_family_profiled_GB_per_step": traffic["GB_per_step"] if traffic else None,
+                },
             }
+        if world == 1 and not args.no_fp32_step and args.dtype == "bf16" and hasattr(resnet_pytorch, args.model):
+            # the parity mode (fp32 storage, exact-fp32 MFMA chains: the mode whose loss curve meets north_star's 1e-4) has a
+            # number too: same batch, same step, outside the timed region
+            del net
+            torch.cuda.empty_cache()
+            net32 = getattr(resnet_pytorch, args.model)(num_classes=C, use_norm="None", pretrained="None", device=dev,
+                                                        compute_dtype=torch.float32)
+            net32.train()
+            for _ in range(2):
+                net32.loss_and_backward(x, y, crit)
+                net32.sgd_step(1e-4, 0.9, 1e-4)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n32 = 3
+            for _ in range(n32):
+                net32.loss_and_backward(x, y, crit)
+                net32.sgd_step(1e-4, 0.9, 1e-4)
+            torch.cuda.synchronize()
+            out["fp32_ms_per_step"] = round(1000.0 * (time.perf_counter() - t1) / n32, 3)
+            out["fp32_note"] = "same step in fp32 storage / exact fp32 MFMA (v_mfma_f32_16x16x4_f32), %d steps after 2 warm-up, not the headline" % n32
+            del net32
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(counts, args.cpu_batch, args.cpu_steps, dev if args.model == "resnet50" else None)
         print(json.dumps(out))

@@ -362,6 +362,18 @@ def g16_nets_conditioned():
     return out
 
 
+# -------------------------------------------------------------------------- G17
+def g17_resnet50_224():
+    """The headline shape: ResNet50, C = 1000, 224x224 images (the benchmark's geometry: 112/56/28/14/7 feature maps), 8 images,
+    seed-7 initialisation conditioned as in G16 (last BN gain of every bottleneck x0.1), three SGD steps with warm-up.  Until
+    this fixture the 224x224 geometry was tied to the reference only through the oracle; here it is the reference's own run."""
+    out = {}
+    for k, v in _net_case("resnet50", 1000, COUNT_SETS["imagenet1000"], 8, 224, 3, 0.1, damp=0.1).items():
+        out["resnet50_224_" + k] = v
+    out["resnet50_224_damp"] = np.array(0.1)
+    return out
+
+
 # --------------------------------------------------------------------------- G9
 def g9_heads():
     """Classifier heads run from the reference's own forward code.  CosNorm_Classifier.__init__
@@ -419,7 +431,8 @@ def g8_warmup():
 
 def main():
     sets = {"g1_class_counts": g1_class_counts, "g2_class_map": g2_class_map, "g3_tables": g3_tables,
-            "g4_loss": g4_loss, "g7_nets": g7_nets, "g8_warmup": g8_warmup, "g9_heads": g9_heads, "g10_se": g10_se, "g16_nets_conditioned": g16_nets_conditioned}
+            "g4_loss": g4_loss, "g7_nets": g7_nets, "g8_warmup": g8_warmup, "g9_heads": g9_heads, "g10_se": g10_se, "g16_nets_conditioned": g16_nets_conditioned,
+            "g17_resnet50_224": g17_resnet50_224}
     only = sys.argv[1:]
     if only:
         sets = {k: v for k, v in sets.items() if k in only}

@@ -460,6 +460,8 @@ REF_NET_CASES = [("g7_nets", "resnet32", "resnet32", 100, 8, 32, None), ("g10_se
                  ("g16_nets_conditioned", "resnet50", "resnet50", 1000, 8, 64, 0.1),
                  ("g16_nets_conditioned", "resnext50", "resnext50_32x4d", 365, 8, 64, 0.1),
                  ("g16_nets_conditioned", "se_resnet50", "se_resnet50", 1000, 8, 64, 0.1),
+                 # the headline geometry (224x224: 112/56/28/14/7 feature maps), the reference's own run, no oracle, no replay
+                 ("g17_resnet50_224", "resnet50_224", "resnet50", 1000, 8, 224, 0.1),
                  ("g7_nets", "resnet50", "resnet50", 1000, 2, 64, None), ("g7_nets", "resnext50", "resnext50_32x4d", 365, 2, 64, None),
                  ("g10_se", "se_resnet50", "se_resnet50", 1000, 2, 64, None)]
 REF_COUNTS = {100: lambda: O.img_num_per_cls(100, 50000, "exp", 0.01),
@@ -468,7 +470,7 @@ REF_COUNTS = {100: lambda: O.img_num_per_cls(100, 50000, "exp", 0.01),
 
 
 @pytest.mark.parametrize("fixture,prefix,arch,C,B,hw,damp", REF_NET_CASES,
-                         ids=[c[1] + ("_conditioned" if c[6] else "") for c in REF_NET_CASES])
+                         ids=[c[1] + ("_conditioned" if c[6] and c[5] != 224 else "") for c in REF_NET_CASES])
 def test_hip_step_against_reference_fixture(golden, fixture, prefix, arch, C, B, hw, damp):
     """fp32 HIP training steps on the reference's inputs vs the reference's outputs.
     Always: logits and loss of step 0 within 1e-4 relative (north_star).  Well-conditioned cases (see above): every
