@@ -68,6 +68,9 @@ SIGNATURES = {
     "iif_rownorm_backward": [_P, _P, _P, _P, _I, _I, _L, _L, _F, _F, _F, _P, _L, _P],
     "iif_weight_transpose_batched": [_P, _P, _I, _I, _I, _P, _P],
     "iif_conv_igemm_masked_res": [_P, _P, _P, _P, _P, _P, _P],
+    "iif_conv_reload_env": [],
+    "iif_conv_pack_fragments": [_P, _P, _I, _I, _P, _P],
+    "iif_conv3x3_frag_ok": [_P],
     "iif_mask_gather": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
     "iif_mask_bce_fwd_bwd": [_P, _I, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "iif_class_accumulate": [_P, _P, _I, _I, _P, _P, _P],
@@ -88,7 +91,13 @@ SIGNATURES = {
 class ConvDesc(ctypes.Structure):
     """Mirror of ``iif_conv_desc`` (include/iif_amd.h)."""
     _fields_ = [(k, ctypes.c_int32) for k in ("n", "hs", "ws", "cs", "hd", "wd", "cd", "r", "s", "stride", "pad",
-                                               "transposed", "ldw", "dtype", "dst_dtype", "groups")]
+                                               "transposed", "ldw", "dtype", "dst_dtype", "groups")] + [("wgt_frag", ctypes.c_void_p)]
+
+
+class PackDesc(ctypes.Structure):
+    """Mirror of ``iif_pack_desc`` (include/iif_amd.h)."""
+    _fields_ = [("src_off", ctypes.c_int64), ("dst_off", ctypes.c_int64)] + [(k, ctypes.c_int32) for k in (
+        "rows", "taps", "k", "ld", "block_start", "reserved")]
 
 
 _lib = None

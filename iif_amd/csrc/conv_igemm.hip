@@ -40,6 +40,7 @@ template <> struct ET<float> { static constexpr int PE = 4, KE = 16; };
 
 struct ConvArgs {
     const unsigned char* src; const unsigned char* wgt; unsigned char* dst; const unsigned char* res;
+    const unsigned char* wfrag;      // nullable: the same weights as MFMA fragments (iif_conv_pack_fragments), 3x3 generation-2 kernel
     const float* bias;
     const unsigned char* res_bits;   // nullable: 1 bit per residual element (ReLU decisions); the residual is masked by it
     // nullable: the batch-norm BACKWARD partial sums of the unit whose output gradient this launch writes
@@ -302,15 +303,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
 // written back with 16 B per lane, i.e. whole 128-B lines (the direct form writes 8 B per lane in 32-B
 // runs).  The residual is read the same way.  With bn_partial the per-channel (sum, sum of squares) of the
 // bf16-rounded tile are emitted too, so batch-norm statistics need no extra pass over the activation.
+template <int BN, int BM, int NT>
+__device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* smem, int m0, int n0, int mt, int goff);
+
 template <int BN, int BM = 128>
 __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&acc)[BN / 32][4], unsigned char* smem,
                                                      int m0, int n0, int mt, int wm, int wn, int fr, int fc, int goff) {
     constexpr int CI = BN / 32;
     constexpr int NT = BM * 2;                  // threads of the block (4 or 8 waves)
     constexpr int PITCH = BN * 2 + 16;
-    constexpr int CPR = BN / 8;                 // 16-byte chunks per row
-    constexpr int RPP = NT / CPR;               // rows per pass
-    const int tid = threadIdx.x;
     __syncthreads();                            // every wave is done reading the last stage
 #pragma unroll
     for (int pj = 0; pj < 4; ++pj)
@@ -323,6 +324,17 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
             *reinterpret_cast<u32x2*>(smem + row * PITCH + ch * 2) = w;
         }
     __syncthreads();
+    staged_drain<BN, BM, NT>(a, smem, m0, n0, mt, goff);
+}
+
+// The [BM x BN] bf16 tile parked in LDS (row pitch BN * 2 + 16) goes out with 16 bytes per lane; residual, ReLU-bit masks,
+// forward BN statistics / upstream BN-backward sums ride on the store loop.  Independent of the wave tiling that staged it.
+template <int BN, int BM, int NT>
+__device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* smem, int m0, int n0, int mt, int goff) {
+    constexpr int PITCH = BN * 2 + 16;
+    constexpr int CPR = BN / 8;                 // 16-byte chunks per row
+    constexpr int RPP = NT / CPR;               // rows per pass
+    const int tid = threadIdx.x;
     const int chunk = tid % CPR, r0 = tid / CPR;
     const int n = n0 + chunk * 8;
     // batch-norm partial sums of the STORED (bf16-rounded) values ride along with the store loop: every thread
@@ -912,25 +924,303 @@ __global__ void __launch_bounds__(256) conv3x3_halo128_kernel(ConvArgs a, unsign
     conv3x3_halo_body<128>(a, src_bytes, wgt_bytes);
 }
 
+// ---------------------------------------------------------------- 3x3 / stride 1 / pad 1, generation 2 (round 3)
+// What bounded the halo kernel above (26-31 % MFMA busy): eight waves of 64 x 64 meet at ONE BARRIER PER TAP (the weights of
+// every tap pass through a shared LDS ring), read 8 KB of fragments per 16 MFMAs and, being in lock step, all sit in their
+// fetch phase together.  Here
+//   * the WEIGHTS never touch LDS: they are stored once per step as ready-made MFMA fragments (iif_conv_pack_fragments:
+//     [channel tile of 16][tap][32-channel chunk] -> 1 KB, lane l's 16 bytes at l * 16), so a wave fetches the four
+//     fragments of its 64 output channels with four fully coalesced 1-KB loads straight from L2 into registers, one step
+//     ahead of their use.  No weight ring, no weight barrier: the only block-wide hand-over left is the halo window;
+//   * the halo window ((rows + 2) x (W + 2) source pixels of a 256-pixel tile, 32 channels = 64 B per pixel, double
+//     buffered, virtual rows as above) is refilled ONCE PER 32-CHANNEL CHUNK by LDS-DMA: one barrier per nine taps;
+//   * a wave owns 128 pixels x 64 channels (128 accumulator registers): 12 KB of operands per 32 MFMAs instead of 8 KB per
+//     16; four waves = one per SIMD, two blocks per CU (75 KB of LDS, <= 256 registers) so that one block's prologue /
+//     epilogue / barrier runs under the other's MFMAs.  Layers with 64 output channels use four 64 x 64 waves along M.
+// Same accumulation order per output as the halo kernel (chunk outer, tap inner, 32 channels per MFMA): bit-identical results.
+// exact floor(x / d) for 0 <= x < 2^22 and 0 < d < 2^16 with rd = 1.0f / d (IEEE): (x + 0.5) / d is never closer than 0.5 / d to an
+// integer, far outside the product's rounding error.  The tile geometry needs ~30 of these per lane and tile; as integer
+// divisions they were ~4 us of every tile's prologue.
+__device__ __forceinline__ int fdiv(int x, float rd) { return (int)(((float)x + 0.5f) * rd); }
+
+template <int WM, int WN, int TM, int NAP, bool PERSIST, int WD>
+__device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_bytes) {
+    constexpr int BM = WM * TM, BN = WN * 64, NWV = WM * WN, PJ = TM / 16, CI = 4;
+    static_assert(NWV == 4 && BM == 256, "four waves, 256-pixel tiles");
+    // NAP halo pieces (16 rows) per wave and chunk, all of them always issued: 10 covers 56x56 windows (10 x 58 = 580 rows),
+    // 8 every window of <= 512 rows (28x28 and smaller)
+    constexpr int HR = NAP * NWV * 16, ABUF = HR * 64;   // halo rows per buffer
+    constexpr int PITCH = BN * 2 + 16, STG = BM * PITCH;
+    // PERSIST (one block per CU walking tiles): the staged output tile has its own buffer, so the next tile's halo window and
+    // first weights are already in flight while this tile is drained.  Otherwise (two blocks per CU) it overlays the halo buffers.
+    constexpr int SMEM = PERSIST ? 2 * ABUF + STG : (STG > 2 * ABUF ? STG : 2 * ABUF);
+    static_assert(PERSIST ? SMEM <= 160 * 1024 : SMEM <= 80 * 1024, "LDS budget");
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+    unsigned char* const stage = PERSIST ? smem + 2 * ABUF : smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int H = a.Hd, W = a.Wd, HW = H * W, W2 = W + 2, H2 = H + 2;
+    const float rHW = 1.0f / (float)HW, rW = 1.0f / (float)W, rW2 = 1.0f / (float)W2, rH2 = 1.0f / (float)H2;
+    const int fr = lane & 15, fc = lane >> 4;
+    const int nchunks = a.Cs / 32;
+    const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src), 0, src_bytes, 0x00020000);
+    // (buffer loads: ONE address register per lane = lane * 16, the fragment is selected by the scalar offset)
+    const auto rs_wf = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wfrag), 0, (unsigned)a.Cd * 9u * (unsigned)a.Cs * 2u, 0x00020000);
+    const unsigned wv = (unsigned)lane * 16u;
+    const unsigned ci_stride = 9u * (unsigned)nchunks * 1024u;
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) toff[t] = a.tap_dy[t] * W2 + a.tap_dx[t];
+
+    // ---- per-tile state
+    int m0 = 0, n0 = 0, mt = 0;
+    unsigned wbase = 0;
+    unsigned avoff[NAP];                                 // halo DMA roles: piece p (16 halo rows) belongs to wave p % 4
+    unsigned hrow_pk[PJ / 2];                            // two halo rows (< 640) of this lane's pixel fragments per register
+    // tile index -> (pixel tile, channel tile), XCD-aware: the channel tiles of a pixel tile are neighbours on one XCD
+    auto set_tile = [&](int b) -> bool {
+        const int xcd = b & 7, j = b >> 3;
+        mt = (j / a.ntiles) * 8 + xcd;
+        const int nt = j % a.ntiles;
+        if (mt >= a.mtiles) return false;
+        m0 = mt * BM; n0 = nt * BN;
+        // virtual row of the tile's first / last pixel (every image carries its own zero rows above and below)
+        const int nf = m0 / HW, remf = m0 - nf * HW;
+        const int vfirst = nf * H2 + remf / W + 1;
+        const int mlast = (m0 + BM - 1 < a.M ? m0 + BM - 1 : a.M - 1);
+        const int nl = mlast / HW, reml = mlast - nl * HW;
+        const int vlast = nl * H2 + reml / W + 1;
+        const int vbase = vfirst - 1;
+        const int Hn = (vlast - vfirst + 3) * W2;        // halo rows in use (host guarantees <= HR)
+#pragma unroll
+        for (int i = 0; i < NAP; ++i) {
+            const int hr = 16 * (wave + NWV * i) + (lane >> 2);
+            const int chunk = (lane & 3) ^ swz(hr);
+            const int q1 = fdiv(hr, rW2);
+            const int vr = vbase + q1, xx = hr - q1 * W2 - 1;
+            const int nn = fdiv(vr, rH2), yy = vr - nn * H2 - 1;
+            const bool ok = hr < Hn && nn < a.N && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            // branch-free: bit 31 puts the lane out of range whatever the rest is (operands are < 2 GiB)
+            avoff[i] = ((((unsigned)((nn * H + yy) * W + xx) * (unsigned)a.spitch + (unsigned)(chunk * 8)) * 2u) & 0x7fffffffu) | (ok ? 0u : OOB);
+        }
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) {
+            const int m = m0 + wm * TM + pj * 16 + fr;
+            const int mm = m < a.M ? m : m0;
+            const int n = fdiv(mm, rHW), rem = mm - n * HW;
+            const int y = fdiv(rem, rW), x = rem - y * W;
+            const unsigned hrw = (unsigned)((n * H2 + y + 1 - vbase) * W2 + x + 1);
+            if (pj & 1) hrow_pk[pj >> 1] |= hrw << 16; else hrow_pk[pj >> 1] = hrw;
+        }
+        // weight fragments of this wave: channel tiles (n0 + wn * 64) / 16 + ci; fragment (ci, tap slot, chunk) is 1 KB
+        wbase = (unsigned)((n0 + wn * 64) >> 4) * 9u * (unsigned)nchunks * 1024u;
+        return true;
+    };
+    auto issue_halo = [&](int c) {
+        unsigned char* dst = smem + (c & 1) * ABUF;
+#pragma unroll
+        for (int i = 0; i < NAP; ++i)                         // pieces beyond the window in use are out-of-range lanes: zeros, no traffic
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(dst + (wave + NWV * i) * 1024), 16, avoff[i], (unsigned)(c * 64), 0, 0);
+    };
+    auto wload = [&](int t, int c, u32x4 (&wf)[CI]) {
+        const unsigned so = wbase + ((unsigned)a.tap_w[t] * (unsigned)nchunks + (unsigned)c) * 1024u;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+            wf[ci] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wf, wv, so + ci * ci_stride, 0));
+    };
+
+    // The chunk body is a software pipeline over HALF steps (one tap, four of the wave's pixel fragments = 16 MFMAs):
+    //   reads of half h + 1 are issued before the MFMAs of half h, the address arithmetic of half h + 2 (the XOR swizzle
+    //   follows the tap-displaced row) sits in their shadow, the weights of tap t + 2 are requested at the start of tap t
+    //   (three register sets: one tap ahead left the first MFMA of every tap waiting for L2).  The straightforward order
+    //   (addresses, reads, wait, MFMAs per half) had the matrix pipe idle half the time: ~110 cycles of address VALU + ~140
+    //   of LDS latency in front of every 256 cycles of MFMAs.
+    constexpr int HPT = PJ / 4;                            // halves per tap (2 for 128-pixel wave tiles, 1 for 64)
+    constexpr int NH = 9 * HPT;                            // halves per chunk
+    const unsigned smem_base = (unsigned)(uintptr_t)smem;   // LDS byte address of the halo buffers (1 KB aligned)
+    const unsigned fcs = (unsigned)fc << 4;
+    // Weights: a ring of NINE taps (144 registers), slot = tap.  vmcnt retires in issue order, so a wait for any register load
+    // also waits for every LDS-DMA piece issued before it: with the weights requested only two taps ahead, the third tap of
+    // every chunk sat waiting for the NEXT chunk's halo window to come back from HBM (~2 us per chunk, measured as 32 % of
+    // the wave cycles in s_waitcnt).  Here the weights of (chunk c + 1, tap t) are requested right after tap t of chunk c has
+    // used its slot: every register load is either older than the halo pieces of its chunk or a whole chunk younger.
+    // (WD = 3: the two-taps-ahead scheme, for the 64-channel variant whose 256 registers cannot hold the ring and whose
+    // layers have two chunks only.)
+    static_assert(WD == 9 || WD == 3, "ring of nine taps, or two taps ahead");
+    u32x4 wb[WD][CI];
+
+    int tile = (int)blockIdx.x;
+    if (!set_tile(tile)) return;
+    issue_halo(0);
+#pragma unroll
+    for (int t = 0; t < (WD == 9 ? 9 : 2); ++t) wload(t, 0, wb[t]);
+    for (;;) {
+        f32x4 acc[CI][PJ];
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int pj = 0; pj < PJ; ++pj) acc[ci][pj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // halo window of chunk 0 (and the previous tile's stores)
+        __builtin_amdgcn_s_barrier();
+        for (int c = 0; c < nchunks; ++c) {
+            // buffer (c + 1) & 1 was last read in chunk c - 1, which every wave has left (barrier at its end)
+            if (c + 1 < nchunks) issue_halo(c + 1);
+            const unsigned fcsb = fcs + smem_base + (unsigned)((c & 1) * ABUF);
+            // (an opaque zero per chunk: without it the fragment addresses of all nine taps are hoisted out of the chunk loop as
+            // loop invariants, 72 registers the weight ring needs)
+            int opaque0 = 0;
+            asm volatile("" : "+s"(opaque0));
+            // LDS address of pixel fragment q of half h: row hr = pixel's halo row + tap shift; 64-byte row, 16-byte chunk fc ^ swz(hr)
+            auto addr4 = [&](int h, unsigned (&ad)[4]) {
+                const int t = h / HPT, ph = (h % HPT) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned hr = ((hrow_pk[(ph + q) >> 1] >> (((ph + q) & 1) * 16)) & 0xffffu) + (unsigned)(toff[t] + opaque0);
+                    ad[q] = (hr << 6) + (fcsb ^ ((hr << 3) & 32u));
+                }
+            };
+            auto read4 = [&](const unsigned (&ad)[4], u32x4 (&xf)[4]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xf[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(ad[q]);
+            };
+            u32x4 xfb[2][4];
+            unsigned ad[4];
+            addr4(0, ad);
+            read4(ad, xfb[0]);
+            addr4(1, ad);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const int t = h / HPT, ph = (h % HPT) * 4;
+                if (h + 1 < NH) read4(ad, xfb[(h + 1) & 1]);
+                if constexpr (WD == 9) {
+                    if (h % HPT == 0 && t > 0 && c + 1 < nchunks) wload(t - 1, c + 1, wb[t - 1]);   // the previous tap's slot is free
+                } else if (h % HPT == 0) {                // start of tap t: the weights of tap t + 2 (of the next chunk at the end)
+                    const int t2 = t + 2 < 9 ? t + 2 : t + 2 - 9, c2 = t + 2 < 9 ? c : c + 1;
+                    if (c2 < nchunks) wload(t2, c2, wb[(t + 2) % 3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);        // memory requests stay in front of this half's MFMAs
+                unsigned adn[4];
+                if (h + 2 < NH) addr4(h + 2, adn);
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[ci][ph + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, wb[t % WD][ci]), __builtin_bit_cast(bf16x8, xfb[h & 1][q]), acc[ci][ph + q], 0, 0, 0);
+                // one MFMA, then up to two of the next-but-one half's address instructions in its shadow
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (h + 2 < NH) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ad[q] = adn[q];
+                }
+            }
+            // chunk boundary: the last tap's slot, then: this wave's halo pieces of chunk c + 1 have landed (everything but the
+            // 9 CI loads issued after them = the next chunk's weights), its reads of buffer c & 1 are done; then all waves
+            if (c + 1 < nchunks) {
+                if constexpr (WD == 9) wload(8, c + 1, wb[8]);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WD == 9 ? 9 * CI : 2 * CI) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        // ---- epilogue: park the tile in LDS, then the shared 16-byte drain
+        const int dm0 = m0, dn0 = n0, dmt = mt;
+        __syncthreads();                                // every wave is done reading the last halo buffer (and the stage of the previous tile)
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj)
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) {
+                const int row = wm * TM + pj * 16 + fr, ch = wn * 64 + ci * 16 + fc * 4;
+                u32x2 w;
+                w.x = pack_bf16x2(acc[ci][pj].x, acc[ci][pj].y);
+                w.y = pack_bf16x2(acc[ci][pj].z, acc[ci][pj].w);
+                *reinterpret_cast<u32x2*>(stage + row * PITCH + ch * 2) = w;
+            }
+        bool more_tiles = false;
+        if constexpr (PERSIST) {
+            // the next tile's window and first weights fly while this one is drained
+            tile += (int)gridDim.x;
+            more_tiles = set_tile(tile);
+            if (more_tiles) {
+                issue_halo(0);
+#pragma unroll
+                for (int t = 0; t < (WD == 9 ? 9 : 2); ++t) wload(t, 0, wb[t]);
+            }
+        }
+        __syncthreads();
+        staged_drain<BN, BM, 256>(a, stage, dm0, dn0, dmt, 0);
+        if (!more_tiles) return;
+    }
+}
+
+__global__ void __launch_bounds__(256, 1) conv3x3_v2_kernel(ConvArgs a, unsigned src_bytes) {
+    conv3x3_v2_body<2, 2, 128, 8, true, 9>(a, src_bytes);
+}
+__global__ void __launch_bounds__(256, 1) conv3x3_v2big_kernel(ConvArgs a, unsigned src_bytes) {
+    conv3x3_v2_body<2, 2, 128, 10, true, 9>(a, src_bytes);
+}
+__global__ void __launch_bounds__(256, 2) conv3x3_v2n64_kernel(ConvArgs a, unsigned src_bytes) {
+    conv3x3_v2_body<4, 1, 64, 10, false, 3>(a, src_bytes);
+}
+
+// Weights as MFMA fragments.  src: [N][ld] bf16 rows of taps x K channels (forward: [cout][9 * cin]; data gradient: the
+// transposed copy [cin][9 * cout]); dst fragment (n / 16, tap, k / 32): 1 KB, lane l = (row l & 15, 8 channels (l >> 4) * 8..)
+// at l * 16.  One thread per 16-byte piece; a descriptor table lets one launch pack every layer of a network.
+__global__ void __launch_bounds__(256) pack_fragments_kernel(const unsigned short* src_base, const iif_pack_desc* tab, int n_desc,
+                                                             unsigned short* dst_base) {
+    const int b = blockIdx.x;
+    int lo = 0, hi = n_desc - 1;
+    while (lo < hi) {                                    // last descriptor whose first block is <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].block_start <= b) lo = mid; else hi = mid - 1;
+    }
+    const iif_pack_desc d = tab[lo];
+    const int64_t piece = (int64_t)(b - d.block_start) * 256 + threadIdx.x;
+    const int kc_n = d.k / 32;
+    const int64_t pieces = (int64_t)(d.rows / 16) * d.taps * kc_n * 64;
+    if (piece >= pieces) return;
+    const int lane = (int)(piece & 63);
+    int64_t f = piece >> 6;
+    const int kc = (int)(f % kc_n); f /= kc_n;
+    const int tap = (int)(f % d.taps);
+    const int nt = (int)(f / d.taps);
+    const int row = nt * 16 + (lane & 15), k0 = kc * 32 + (lane >> 4) * 8;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src_base + d.src_off + (int64_t)row * d.ld + tap * d.k + k0);
+    *reinterpret_cast<u32x4*>(dst_base + d.dst_off + piece * 8) = v;
+}
+
 template <typename T, bool OUTF32>
 __global__ void __launch_bounds__(512) conv_igemm_dma_utap256_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     conv_igemm_dma_body<T, 128, OUTF32, true, 8>(a, src_bytes, wgt_bytes);
 }
 
 // ---------------------------------------------------------------- streaming 1x1 GEMM, weights resident in LDS
-// dst[M, N] = src[M, K] * wgt[N, K]^T for the bandwidth-bound 1x1 / stride-1 layers (56x56 and 28x28 stages: M = 0.2-0.8 M
-// pixels, K, N <= 256): forward and data gradient.  The tile kernels above spend most of a short-K tile outside the
-// multiply (prologue, one exposed load latency, epilogue) and re-read the activation tile once per 128-channel N tile;
-// in the step these launches ran at 2.3-3.1 TB/s.  Here:
-//   * persistent blocks (one per CU, 8 waves), the whole weight matrix stays in LDS (<= 64 KB), every activation row
-//     is read exactly once;
-//   * 4 COMPUTE waves, each owning 32 rows of the 128-row tile and ALL N channels: a wave multiplies only rows its own
-//     LDS-DMA fetched, so the K loop has no barrier at all, only counted vmcnt waits on a private ring of R K-slabs
-//     (16 rows x 64 B pieces) that runs continuously across tiles: the next tiles' rows are in flight during the
+// dst[M, N] = src[M, K] * wgt[N, K]^T for the bandwidth-bound 1x1 / stride-1 layers (56x56 ... 14x14 stages, K <= 512):
+// forward and data gradient.  The tile kernels above spend most of a short-K tile outside the multiply (prologue, one
+// exposed load latency, epilogue) and hold at most four tiles per CU; in the step these launches ran at 2.3-3.4 TB/s.  Here:
+//   * persistent blocks (one per CU, 12 waves).  A block owns ONE N slice of BN output channels whose weights
+//     [BN x K] stay in LDS (<= 64 KB) and walks a sequence of 128-row tiles.  The S = N / BN slices of a tile sequence
+//     sit on blocks b, b + 8, ... (one XCD under round-robin placement: speed only), walk the same tiles in the same order
+//     and so share each activation tile through that XCD's L2: every activation row leaves HBM once;
+//   * 4 COMPUTE waves, each owning 32 rows of the 128-row tile and ALL BN channels of the slice: a wave multiplies only
+//     rows its own LDS-DMA fetched, so the K loop has no barrier at all, only counted vmcnt waits on a private ring of R
+//     K-slabs (32 rows x 64 B) that runs continuously across tiles: the next tiles' rows are in flight during the
 //     epilogue of the current one;
 //   * 8 STORE waves drain the previous tile from an LDS staging buffer (16 B per lane, whole lines; residual add,
 //     ReLU-bit masks, forward BN statistics or upstream BN-backward sums as in conv_epilogue_staged) while the
 //     compute waves multiply the next one.  Two block-wide barriers per tile hand the staging buffer over.
+//     The epilogue's OPERANDS (residual, upstream x, ReLU bits: up to 8.1 of the 13 bytes a conv1 data gradient moves per
+//     output element) do not depend on the product, so a store thread fetches them for tile j + 1 right after it has
+//     drained tile j and holds them in registers across the barriers (round 2 had these loads inside the drain loop:
+//     two exposed memory latencies per tile, level with the tile kernel).
 // Compute waves issue no vector-memory instruction besides their DMA, so the vmcnt arithmetic is exact; the store
 // waves' loads and stores live on their own counters.
 constexpr int STREAM_SW = 8;
@@ -941,7 +1231,9 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
     constexpr int RING = 4 * R * 2048;                    // per compute wave: R slabs of its 32 rows x 64 B
     constexpr int PITCH = BN * 2 + 16;
     constexpr int CPR = BN / 8, RPP = 64 * SW / CPR;
+    constexpr int NR = BM / RPP;                          // rows of a tile per store thread (BN / 32)
     constexpr unsigned OOB = 0x80000000u;
+    static_assert(WBYTES + RING + BM * PITCH + SW * 2 * BN * 4 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[WBYTES + RING + BM * PITCH + SW * 2 * BN * 4];
     unsigned char* const wl = smem;
     unsigned char* const ring = smem + WBYTES;
@@ -951,18 +1243,24 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = a.Cs / 32;
-    const int my_tiles = ((int)a.mtiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // block -> (tile sequence, N slice): the S slices of a sequence are S consecutive blocks OF ONE XCD (b, b + 8, ...)
+    const int S = a.ntiles;
+    const int xcd = (int)blockIdx.x & 7, bi = (int)blockIdx.x >> 3;
+    const int slice = bi % S, seq = (bi / S) * 8 + xcd;
+    const int G = (int)gridDim.x / S;                      // tile sequences (the host makes the grid a multiple of 8 S)
+    const int n0 = slice * BN;
+    const int my_tiles = seq < a.mtiles ? (a.mtiles - seq + G - 1) / G : 0;
     const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src), 0, src_bytes, 0x00020000);
     const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wgt), 0, wgt_bytes, 0x00020000);
     const int prow = lane >> 2;
     const int chunk = (lane & 3) ^ swz(prow);
 
-    // ---- resident weights: slab ks, 16-row piece p -> wl + ks * BN * 64 + p * 1024; all 8 waves fetch
+    // ---- resident weights: slab ks, 16-row piece p -> wl + ks * BN * 64 + p * 1024; all 12 waves fetch
     {
         const int pieces = nk * (BN / 16);
         for (int q = wave; q < pieces; q += 4 + SW) {
             const int ks = q / (BN / 16), p = q - ks * (BN / 16);
-            const int n = p * 16 + prow;
+            const int n = n0 + p * 16 + prow;
             const unsigned off = n < a.Cd ? ((unsigned)n * (unsigned)a.ldw + (unsigned)(ks * 32 + chunk * 8)) * 2u : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)(wl + q * 1024), 16, off, 0, 0, 0);
         }
@@ -981,7 +1279,7 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
         int gi = 0, ij = 0, iks = 0;
         unsigned vb[2];
         auto tile_rows = [&](int j) {
-            const int m0 = ((int)blockIdx.x + j * (int)gridDim.x) * BM + cw * 32;
+            const int m0 = (seq + j * G) * BM + cw * 32;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int m = m0 + i * 16 + prow;
@@ -1079,25 +1377,54 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
     // ===================================================================== store waves
     const int ts = tid - 256, sw = wave - 4;             // store-thread index 0 .. 64*SW-1
     const int chk = ts % CPR, r0 = ts / CPR;
-    const int n = chk * 8;
+    const int n = n0 + chk * 8;
     const bool stats = a.bn_partial != nullptr;
+    const bool col_ok = n < a.Cd;
     float bmean[8], bistd[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { bmean[q] = 0.f; bistd[q] = 0.f; }
-    if (a.bw_x && n < a.Cd) {
+    if (a.bw_x && col_ok) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[n + q]; bistd[q] = a.bw_stats[a.Cd + n + q]; }
     }
     // combine the store waves' sums of tile `mt` (already in scratch) into its partial row
     auto emit_partial = [&](int mt) {
-        if (ts < BN && ts < a.Cd) {
+        if (ts < BN && n0 + ts < a.Cd) {
             float s2 = 0.f, q2 = 0.f;
 #pragma unroll
             for (int w = 0; w < SW; ++w) { s2 += scratch[(w * 2 + 0) * BN + ts]; q2 += scratch[(w * 2 + 1) * BN + ts]; }
-            float* p = a.bn_partial + (int64_t)(a.bn_row0 + mt) * 2 * a.dpitch + ts;
+            float* p = a.bn_partial + (int64_t)(a.bn_row0 + mt) * 2 * a.dpitch + n0 + ts;
             p[0] = s2; p[a.dpitch] = q2;
         }
     };
+    // epilogue operands of the NEXT tile, fetched ahead: residual rows, upstream-x rows, the two ReLU-bit bytes
+    const bool has_res = a.res != nullptr, has_up = a.bw_x != nullptr;
+    const bool prefetching = has_res || has_up;           // block-uniform
+    u32x4 pres[NR], pupx[NR];
+    unsigned pbit[NR];                                    // residual bits | upstream bits << 8
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { pres[i] = u32x4{0u, 0u, 0u, 0u}; pupx[i] = u32x4{0u, 0u, 0u, 0u}; pbit[i] = 0xffffu; }
+    const int64_t ostep = (int64_t)RPP * a.dpitch * 2;
+    auto prefetch = [&](int j) {
+        const int m0 = (seq + j * G) * BM;
+        int64_t o = ((int64_t)(m0 + r0) * a.dpitch + n) * 2;
+#pragma unroll
+        for (int i = 0; i < NR; ++i, o += ostep) {
+            if (m0 + r0 + i * RPP < a.M && col_ok) {
+                unsigned rb = 0xffu, ub = 0xffu;
+                if (has_res) {
+                    pres[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res + o));     // last use of the residual
+                    if (a.res_bits) rb = a.res_bits[o >> 4];
+                }
+                if (has_up) {
+                    pupx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.bw_x + o));    // next reader: BN backward, another XCD
+                    if (a.bw_bits) ub = a.bw_bits[o >> 4];
+                }
+                pbit[i] = rb | (ub << 8);
+            }
+        }
+    };
+    if (prefetching) prefetch(0);
 #ifdef IIF_CONV_STAMPS
     unsigned long long u_bar = 0, u_drain = 0, u_red = 0, u0, u1, u2, u3, u_begin;
     IIF_STAMP(u_begin);
@@ -1107,27 +1434,26 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
         IIF_STAMP(u0);
 #endif
         __builtin_amdgcn_s_barrier();                     // A
-        if (stats && j > 0) emit_partial((int)blockIdx.x + (j - 1) * (int)gridDim.x);   // idle window: the compute waves stage tile j
+        if (stats && j > 0) emit_partial(seq + (j - 1) * G);   // idle window: the compute waves stage tile j
         __builtin_amdgcn_s_barrier();                     // B
 #ifdef IIF_CONV_STAMPS
         IIF_STAMP(u1); u_bar += u1 - u0;
 #endif
-        const int mt = (int)blockIdx.x + j * (int)gridDim.x;
+        const int mt = seq + j * G;
         const int m0 = mt * BM;
         float bs[8], bq[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) { bs[q] = 0.f; bq[q] = 0.f; }
-        if (n < a.Cd) {
-            const int rows_here = a.M - m0 < BM ? a.M - m0 : BM;          // only the last tile is short
+        if (col_ok) {
             const unsigned char* sp = stage + r0 * PITCH + chk * 16;
             int64_t o = ((int64_t)(m0 + r0) * a.dpitch + n) * 2;
-            const int64_t ostep = (int64_t)RPP * a.dpitch * 2;
-#pragma unroll 4
-            for (int row = r0; row < rows_here; row += RPP, sp += RPP * PITCH, o += ostep) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i, sp += RPP * PITCH, o += ostep) {
+                if (m0 + r0 + i * RPP >= a.M) break;                          // only the last tile is short
                 u32x4 v = *reinterpret_cast<const u32x4*>(sp);
-                if (a.res) {
-                    const u32x4 rr = *reinterpret_cast<const u32x4*>(a.res + o);
-                    const unsigned rb = a.res_bits ? a.res_bits[o >> 4] : 0xffu;
+                if (has_res) {
+                    const u32x4 rr = pres[i];
+                    const unsigned rb = pbit[i] & 0xffu;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float lo = bf16_bits_to_f32(v[q] & 0xffffu) + ((rb >> (2 * q)) & 1u ? bf16_bits_to_f32(rr[q] & 0xffffu) : 0.f);
@@ -1140,13 +1466,9 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
 #else
                 *reinterpret_cast<u32x4*>(a.dst + o) = v;
 #endif
-                if (a.bw_x) {
-    #ifndef IIF_NO_NT_EPILOGUE_LOADS   // streamed once by this kernel (next reader: the BN backward, from another XCD)
-                const u32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.bw_x + o));
-#else
-                const u32x4 xv = *reinterpret_cast<const u32x4*>(a.bw_x + o);
-#endif
-                    const unsigned mb = a.bw_bits ? a.bw_bits[o >> 4] : 0xffu;
+                if (has_up) {
+                    const u32x4 xv = pupx[i];
+                    const unsigned mb = pbit[i] >> 8;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float glo = (mb >> (2 * q)) & 1u ? bf16_bits_to_f32(v[q] & 0xffffu) : 0.f;
@@ -1166,6 +1488,8 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
                 }
             }
         }
+        // the next tile's operands go out behind this tile's stores and fly while the compute waves multiply and stage it
+        if (prefetching && j + 1 < my_tiles) prefetch(j + 1);
 #ifdef IIF_CONV_STAMPS
         IIF_STAMP(u2); u_drain += u2 - u1;
 #endif
@@ -1193,25 +1517,54 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
     }
 #endif
     __builtin_amdgcn_s_barrier();                         // C
-    if (stats) emit_partial((int)blockIdx.x + (my_tiles - 1) * (int)gridDim.x);
+    if (stats) emit_partial(seq + (my_tiles - 1) * G);
 }
 
-inline bool use_stream1x1(const ConvArgs& a, bool utap, int esz, bool outf32, int* bn, int* kmax) {
-    const char* off = getenv("IIF_CONV_NO_STREAM1X1");                        // read per call: A/B runs toggle it
-    if (off || !utap || esz != 2 || outf32 || a.groups > 1 || a.scatter || a.in_shift != 0 || a.sshift != 0) return false;
+// Experiment / test switches of this file, read from the environment ONCE (they used to cost several getenv per launch on
+// the hot host path); iif_conv_reload_env() re-reads them (tests and A/B scripts flip them between calls).
+struct ConvSwitches {
+    bool no_stream, force_stream, stream_fwd_only, stream_r2, no_shortk, regstage, no_v2, no_halo, force_halo, v2_wide;
+    int force_bn64_k, twostage_k;
+    static ConvSwitches read() {
+        ConvSwitches c;
+        c.no_stream = getenv("IIF_CONV_NO_STREAM1X1") != nullptr;
+        c.force_stream = getenv("IIF_CONV_STREAM1X1_FORCE") != nullptr;
+        c.stream_fwd_only = getenv("IIF_CONV_STREAM1X1_FWD_ONLY") != nullptr;
+        c.stream_r2 = getenv("IIF_CONV_STREAM1X1_R2") != nullptr;
+        c.no_shortk = getenv("IIF_CONV_NO_SHORTK") != nullptr;
+        c.regstage = getenv("IIF_CONV_REGSTAGE") != nullptr;
+        c.no_v2 = getenv("IIF_CONV_NO_V2") != nullptr;
+        c.no_halo = getenv("IIF_CONV_NO_HALO") != nullptr;
+        c.v2_wide = getenv("IIF_CONV_V2_WIDE") != nullptr;
+        c.force_halo = getenv("IIF_CONV_HALO_FORCE") != nullptr;
+        const char* f64 = getenv("IIF_CONV_FORCE_BN64");
+        c.force_bn64_k = f64 ? atoi(f64) : -1;
+        const char* k2 = getenv("IIF_CONV_TWOSTAGE_K");
+        c.twostage_k = k2 ? atoi(k2) : 2304;
+        return c;
+    }
+};
+ConvSwitches g_sw = ConvSwitches::read();
+
+// Which launches the streaming kernel takes, and its slice width: (K, N) -> BN columns per block with [BN x K] <= 64 KB
+// resident; S = N / BN slices.  A tile sequence needs a few tiles to pipeline across: mtiles * S >= 4 * grid.
+struct StreamPlan { int bn, kmax, slices; };
+inline bool use_stream1x1(const ConvArgs& a, bool utap, int esz, bool outf32, StreamPlan* pl) {
+    const bool off_ = g_sw.no_stream, force_ = g_sw.force_stream, no_dgrad = g_sw.stream_fwd_only, old_only = g_sw.stream_r2;
+    if (off_ || !utap || esz != 2 || outf32 || a.groups > 1 || a.scatter || a.in_shift != 0 || a.sshift != 0) return false;
     if (a.R != 1 || a.S != 1 || a.pad != 0 || a.ntaps != 1 || a.bias) return false;
     if (a.Hs != a.Hd || a.Ws != a.Wd || (a.Cs % 32) || a.spitch != a.Cs || a.dpitch != a.Cd) return false;
-    if (a.Cd == 256 && a.Cs <= 64) { *bn = 256; *kmax = 64; }
-    else if (a.Cd == 128 && a.Cs <= 256) { *bn = 128; *kmax = 256; }
-    else if (a.Cd == 64 && a.Cs <= 256 && (a.Cs >= 128 || getenv("IIF_CONV_STREAM1X1_FORCE"))) { *bn = 64; *kmax = 256; }   // 64->64: the tile kernel wins (0.038 vs 0.060 ms)
+    const int K = a.Cs, N = a.Cd;
+    if (K <= 64 && N == 256) *pl = {256, 64, 1};
+    else if (K == 128 && N % 128 == 0 && N <= 1024) *pl = {128, 128, N / 128};
+    else if (K > 64 && K <= 256 && N == 64 && (K >= 128 || force_)) *pl = {64, 256, 1};     // 64->64: the tile kernel wins (0.038 vs 0.060 ms)
+    else if (K > 128 && K <= 256 && N % 128 == 0 && N <= 1024) *pl = {128, 256, N / 128};
+    else if (K > 256 && K <= 512 && N % 64 == 0 && N <= 256) *pl = {64, 512, N / 64};
     else return false;
-    const char* force = getenv("IIF_CONV_STREAM1X1_FORCE");                   // tests: small grids too (read per call)
-    if (force) return true;
-    // Measured alone (scripts/bm_stream1x1.py, bs 256, 8 store waves): forward 64->256 0.152 -> 0.113 ms (4.5 TB/s),
-    // 256->128 0.136 -> 0.121, 256->64 0.105 -> 0.100, 28x28 64->256 0.033 -> 0.029 against the 4-blocks-per-CU tile
-    // kernel; the data gradients with the upstream BN-backward sums are level or slower here (their epilogue loads
-    // wait inside the store waves: 64->256 0.220 -> 0.243 ms), so they stay on the tile kernels.
-    return !a.transposed && !a.bw_x && (a.M + 127) / 128 >= 1024;             // >= 4 tiles per persistent block
+    if (old_only && (pl->slices > 1 || a.transposed || a.bw_x || pl->kmax == 128 || pl->kmax == 512)) return false;
+    if (no_dgrad && (a.transposed || a.bw_x)) return false;
+    if (force_) return true;
+    return (int64_t)((a.M + 127) / 128) * pl->slices >= 1024;               // >= 4 tiles per persistent block
 }
 
 // 256-pixel tiles: bf16 uniform-tap launches wide enough for the 128-channel tile whose 256-row grid still fills
@@ -1236,7 +1589,7 @@ inline int claim_partial_rows(const ConvArgs& a) {
 
 // halo kernel: bf16 3x3 / stride 1 / pad 1, dense, >= 128 output channels, window of a 256-pixel tile <= 512 halo rows
 inline bool use_halo(const ConvArgs& a, bool utap, int esz, bool outf32) {
-    static const char* off = getenv("IIF_CONV_NO_HALO");
+    const bool off = g_sw.no_halo;
     if (off || !utap || esz != 2 || outf32 || a.groups > 1 || a.scatter || a.in_shift != 0) return false;
     if (a.ntaps != 9 || a.R != 3 || a.S != 3 || a.pad != 1 || a.Hs != a.Hd || a.Ws != a.Wd) return false;
     if (a.Cd < 128 || (a.Cd & 7) || a.bias || (a.Cs % 32)) return false;
@@ -1245,13 +1598,55 @@ inline bool use_halo(const ConvArgs& a, bool utap, int esz, bool outf32) {
     if ((span + 2) * (a.Wd + 2) > 512) return false;
     const int span1 = (128 + a.Wd - 1) / a.Wd + 1 + 2 * (128 / HW + 1);      // the same for a 128-pixel tile
     if ((span1 + 2) * (a.Wd + 2) > 304) return false;
-    static const char* force = getenv("IIF_CONV_HALO_FORCE");                 // tests: small grids too
+    const bool force = g_sw.force_halo;                                       // tests: small grids too
     return force || (int64_t)((a.M + 255) / 256) * ((a.Cd + 127) / 128) >= 192;
+}
+
+// generation-2 3x3: fragment-packed weights supplied, bf16, stride 1 / pad 1, dense, channels in 32s / 64s, halo of a
+// 256-pixel tile within 640 rows
+inline bool v2_geometry_ok(int N, int H, int W, int Cs, int Cd) {
+    if ((Cs % 32) || (Cd % 64) || H <= 0 || W <= 0 || W > 1022) return false;
+    // Measured alone (scripts/bm_conv3x3.py, bs 256): the 64-channel variant (56x56) 0.132 -> 0.102 ms forward, 0.171 -> 0.134
+    // data gradient; the persistent 128-channel variant is level with or behind the halo kernel (28x28 0.078 -> 0.098,
+    // 14x14 0.067 -> 0.076, 7x7 0.057 -> 0.066 ms) and stays opt-in (IIF_CONV_V2_WIDE) until its loop is as good as its plan.
+    if ((Cd % 128) == 0 && !g_sw.v2_wide) return false;
+    if ((int64_t)N * H * W >= (1 << 22)) return false;                    // fdiv's exact range
+    const int HW = H * W;
+    const int span = (256 + W - 1) / W + 1 + 2 * (256 / HW + 1);            // virtual rows a 256-pixel tile can touch
+    return (span + 2) * (W + 2) <= 640;
+}
+inline bool use_v2(const ConvArgs& a, bool utap, int esz, bool outf32) {
+    if (!a.wfrag || g_sw.no_v2 || !utap || esz != 2 || outf32 || a.groups > 1 || a.scatter || a.in_shift != 0) return false;
+    if (a.ntaps != 9 || a.R != 3 || a.S != 3 || a.pad != 1 || a.Hs != a.Hd || a.Ws != a.Wd || a.bias) return false;
+    if (a.spitch != a.Cs || a.dpitch != a.Cd) return false;
+    return v2_geometry_ok(a.N, a.Hd, a.Wd, a.Cs, a.Cd);
 }
 
 template <typename T, bool OUTF32>
 int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
     static const bool force_v1_ = getenv("IIF_CONV_REGSTAGE") != nullptr;
+    if (!force_v1_ && src_bytes < 0x7f000000LL && use_v2(a, utap, (int)sizeof(T), OUTF32)) {
+        const bool wide = (a.Cd % 128) == 0;
+        a.mtiles = (a.M + 255) / 256;
+        a.ntiles = wide ? a.Cd / 128 : a.Cd / 64;
+        if (const int rc = claim_partial_rows(a)) return rc;
+        const int64_t blocks2 = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
+        if (blocks2 > 0x7fffffff) return IIF_EUNSUPPORTED;
+        const int HWv = a.Hd * a.Wd;
+        const int window = ((256 + a.Wd - 1) / a.Wd + 1 + 2 * (256 / HWv + 1) + 2) * (a.Wd + 2);   // halo rows a tile can need
+        // the 128-channel kernels are persistent: one block per CU walks the tiles (tile index -> the same XCD-aware map)
+        static const int cus2 = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+            return n > 0 ? n : 256;
+        }();
+        const unsigned pgrid = (unsigned)(blocks2 < cus2 ? blocks2 : cus2);
+        if (wide && window <= 512) hipLaunchKernelGGL(conv3x3_v2_kernel, dim3(pgrid), dim3(256), 0, st, a, (unsigned)src_bytes);
+        else if (wide) hipLaunchKernelGGL(conv3x3_v2big_kernel, dim3(pgrid), dim3(256), 0, st, a, (unsigned)src_bytes);
+        else hipLaunchKernelGGL(conv3x3_v2n64_kernel, dim3((unsigned)blocks2), dim3(256), 0, st, a, (unsigned)src_bytes);
+        IIF_LAUNCH_CHECK();
+        return IIF_OK;
+    }
     if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_halo(a, utap, (int)sizeof(T), OUTF32)) {
         // measured (scripts/halo_ab.sh): two 128-row blocks per CU win at 28x28 (+8 %), one 256-row block elsewhere
         static const char* hbm = getenv("IIF_CONV_HALO_BM");
@@ -1268,23 +1663,33 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
         IIF_LAUNCH_CHECK();
         return IIF_OK;
     }
-    int sbn = 0, skmax = 0;
-    if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_stream1x1(a, utap, (int)sizeof(T), OUTF32, &sbn, &skmax)) {
-        a.mtiles = (a.M + 127) / 128;
-        a.ntiles = 1;
-        if (const int rc = claim_partial_rows(a)) return rc;
+    StreamPlan sp{0, 0, 0};
+    if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_stream1x1(a, utap, (int)sizeof(T), OUTF32, &sp)) {
         static const int cus = [] {
             int dev = 0, n = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
             return n > 0 ? n : 256;
         }();
-        const unsigned grid = (unsigned)(a.mtiles < cus ? a.mtiles : cus);
-        const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
-        if (sbn == 256) hipLaunchKernelGGL((gemm1x1_stream_kernel<256, 64>), dim3(grid), dim3(64 * (4 + STREAM_SW)), 0, st, a, sb, wb);
-        else if (sbn == 128) hipLaunchKernelGGL((gemm1x1_stream_kernel<128, 256>), dim3(grid), dim3(64 * (4 + STREAM_SW)), 0, st, a, sb, wb);
-        else hipLaunchKernelGGL((gemm1x1_stream_kernel<64, 256>), dim3(grid), dim3(64 * (4 + STREAM_SW)), 0, st, a, sb, wb);
-        IIF_LAUNCH_CHECK();
-        return IIF_OK;
+        a.mtiles = (a.M + 127) / 128;
+        a.ntiles = sp.slices;
+        // one block per CU, in whole groups of 8 S (the S slices of a tile sequence on one XCD); a short layer takes fewer
+        // sequences, never more than it has tiles
+        const int unit = 8 * sp.slices;
+        int grid = cus / unit * unit;
+        const int need = (a.mtiles + 7) / 8 * unit;         // sequences in multiples of 8, S blocks each
+        if (need < grid) grid = need;
+        if (grid >= unit) {
+            if (const int rc = claim_partial_rows(a)) return rc;
+            const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
+            const dim3 g((unsigned)grid), blk(64 * (4 + STREAM_SW));
+            if (sp.bn == 256) hipLaunchKernelGGL((gemm1x1_stream_kernel<256, 64>), g, blk, 0, st, a, sb, wb);
+            else if (sp.bn == 128 && sp.kmax == 128) hipLaunchKernelGGL((gemm1x1_stream_kernel<128, 128>), g, blk, 0, st, a, sb, wb);
+            else if (sp.bn == 128) hipLaunchKernelGGL((gemm1x1_stream_kernel<128, 256>), g, blk, 0, st, a, sb, wb);
+            else if (sp.kmax == 256) hipLaunchKernelGGL((gemm1x1_stream_kernel<64, 256>), g, blk, 0, st, a, sb, wb);
+            else hipLaunchKernelGGL((gemm1x1_stream_kernel<64, 512>), g, blk, 0, st, a, sb, wb);
+            IIF_LAUNCH_CHECK();
+            return IIF_OK;
+        }
     }
     if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_bm256(a, utap, (int)sizeof(T))) {
         a.mtiles = (a.M + 255) / 256;
@@ -1298,8 +1703,8 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
         return IIF_OK;
     }
     a.mtiles = (a.M + 127) / 128;
-    const char* f64 = getenv("IIF_CONV_FORCE_BN64");       // experiment: 128x64 tiles (4 blocks per CU) for wider outputs too
-    const bool narrow = a.Cd <= 64 || (f64 && a.ntaps * a.Cs <= atoi(f64));
+    // (IIF_CONV_FORCE_BN64 = K: experiment, 128x64 tiles / 4 blocks per CU for wider outputs too)
+    const bool narrow = a.Cd <= 64 || (g_sw.force_bn64_k >= 0 && a.ntaps * a.Cs <= g_sw.force_bn64_k);
     const int bn = narrow ? 64 : 128;
     a.ntiles = (a.Cd + bn - 1) / bn;
     const int64_t blocks = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
@@ -1315,9 +1720,9 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
     if (dma) {
         const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
         if (utap) {
-            const char* k2 = getenv("IIF_CONV_TWOSTAGE_K");          // two-stage / 4-blocks-per-CU variant up to this K
-            const bool shortk = sizeof(T) == 2 && !OUTF32 && a.ntaps * a.Cs <= (k2 ? atoi(k2) : 2304) && (a.Cd & 7) == 0 && !a.bias &&
-                                getenv("IIF_CONV_NO_SHORTK") == nullptr;
+            // two-stage / 4-blocks-per-CU variant up to K = IIF_CONV_TWOSTAGE_K (default 2304)
+            const bool shortk = sizeof(T) == 2 && !OUTF32 && a.ntaps * a.Cs <= g_sw.twostage_k && (a.Cd & 7) == 0 && !a.bias &&
+                                !g_sw.no_shortk;
             if constexpr (sizeof(T) == 2 && !OUTF32) {
                 if (shortk) {
                     if (narrow) hipLaunchKernelGGL((conv_igemm_dma_utap_k64_kernel<64>), grid, blk, 0, st, a, sb, wb);
@@ -1350,7 +1755,7 @@ template <typename T, bool OUTF32>
 int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
     ConvArgs a = a0;
     static const bool no_fast = getenv("IIF_CONV_GENERAL_ADDR") != nullptr;
-    const bool dma_ok = getenv("IIF_CONV_REGSTAGE") == nullptr && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL;
+    const bool dma_ok = !g_sw.regstage && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL;
     const bool utap = !no_fast && dma_ok && (a.Cs % ET<T>::KE) == 0 && a.R * a.S <= 16 && a.R <= 16 && a.S <= 16;
     a.scatter = 0; a.ds_shift = 0; a.doy = a.dox = 0; a.Hfull = a.Hd; a.Wfull = a.Wd; a.ntaps = 0; a.in_shift = 0;
     if (!utap) return launch_one<T, OUTF32>(a, false, src_bytes, wgt_bytes, st);
@@ -1404,6 +1809,29 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
                const float* bw_stats = nullptr);
 }
 
+extern "C" int iif_conv_pack_fragments(const void* src_base, const iif_pack_desc* table, int n_desc, int total_blocks,
+                                       void* dst_base, void* stream) {
+    if (!src_base || !table || !dst_base || n_desc <= 0 || total_blocks <= 0) return IIF_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(src_base) | reinterpret_cast<uintptr_t>(dst_base)) & 15) return IIF_EUNSUPPORTED;
+    hipLaunchKernelGGL(pack_fragments_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream),
+                       (const unsigned short*)src_base, table, n_desc, (unsigned short*)dst_base);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
+extern "C" int iif_conv3x3_frag_ok(const iif_conv_desc* d) {
+    if (!d || g_sw.no_v2 || g_sw.regstage) return 0;
+    if (d->dtype != IIF_BF16 || d->dst_dtype != IIF_BF16 || d->groups > 1 || d->r != 3 || d->s != 3 || d->stride != 1 || d->pad != 1) return 0;
+    if (d->hs != d->hd || d->ws != d->wd) return 0;
+    if ((int64_t)d->n * d->hs * d->ws * d->cs * 2 >= 0x7f000000LL) return 0;
+    return v2_geometry_ok(d->n, d->hd, d->wd, d->cs, d->cd) ? 1 : 0;
+}
+
+extern "C" int iif_conv_reload_env(void) {
+    g_sw = ConvSwitches::read();
+    return IIF_OK;
+}
+
 extern "C" int iif_conv_igemm_dgrad_bnbwd(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                                           const unsigned char* res_bits, const void* up_x, const unsigned char* up_bits,
                                           const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,
@@ -1455,6 +1883,7 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
     ConvArgs a{};
     a.src = (const unsigned char*)src; a.wgt = (const unsigned char*)wgt; a.dst = (unsigned char*)dst;
     a.res = (const unsigned char*)res; a.bias = bias;
+    a.wfrag = (const unsigned char*)d->wgt_frag;
     a.res_bits = res_bits;
     a.bn_partial = nullptr;
     if (n_partials) *n_partials = 0;
@@ -1464,7 +1893,7 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
         // pipelined kernels; one partial row per pixel tile, counted where the tile height is chosen (launch_one)
         const int64_t esz0 = 2;
         const bool ok = d->dtype == IIF_BF16 && d->dst_dtype == IIF_BF16 && (d->cd % 8) == 0 && !bias && (bw_x || !res) &&
-                        (!bw_x || d->groups <= 1) && getenv("IIF_CONV_REGSTAGE") == nullptr &&
+                        (!bw_x || d->groups <= 1) && !g_sw.regstage &&
                         (int64_t)d->n * d->hs * d->ws * d->cs * (d->groups > 1 ? d->groups : 1) * esz0 < 0x7f000000LL;
         if (!ok) return IIF_EUNSUPPORTED;
         a.bn_partial = bn_partial;

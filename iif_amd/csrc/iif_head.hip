@@ -32,7 +32,6 @@ template <> struct Io<float> {
     static __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
     static __device__ __forceinline__ float load1(const float* p) { return *p; }
     static __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
-    static constexpr int kAlign = 16;
 };
 template <> struct Io<unsigned short> {  // bf16 bits
     static __device__ __forceinline__ f32x4 load4(const unsigned short* p) {
@@ -48,7 +47,44 @@ template <> struct Io<unsigned short> {  // bf16 bits
     }
     static __device__ __forceinline__ float load1(const unsigned short* p) { return bf16_bits_to_f32(*p); }
     static __device__ __forceinline__ void store1(unsigned short* p, float v) { *p = f32_to_bf16_bits(v); }
-    static constexpr int kAlign = 8;
+};
+
+// One lane's V consecutive columns of a row as V floats: 16 bytes per lane for both element types (4 fp32 / 8 bf16), so
+// every wave instruction moves whole 1-KB runs.  `nv` (0 < nv <= V, multiple of 4) is the number of columns that exist:
+// the bf16 row tail of a class count that is 4 but not 0 modulo 8 (1204) is an 8-byte access.
+template <typename T> struct RowIo;
+// A row is fetched as RAW 16-byte vectors and unpacked where it is used, so rows in flight cost 4 registers per lane and
+// chunk whatever the element type: DEPTH rows are kept in flight per wave (bf16 rows are half the bytes, so two of them
+// give a CU the same bytes in flight as one fp32 row: with one, [65536, 1000] bf16 ran at 3.2 TB/s against 4.9 for fp32).
+template <> struct RowIo<float> {
+    static constexpr int V = 4, DEPTH = 1;
+    using Raw = f32x4;
+    static __device__ __forceinline__ Raw load_raw(const float* p, int) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void unpack(const Raw& t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    static __device__ __forceinline__ void store(float* p, int, const float (&v)[4]) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+};
+template <> struct RowIo<unsigned short> {
+    static constexpr int V = 8, DEPTH = 2;
+    using Raw = u32x4;
+    static __device__ __forceinline__ Raw load_raw(const unsigned short* p, int nv) {
+        u32x4 w = u32x4{0u, 0u, 0u, 0u};
+        if (nv == 8) w = *reinterpret_cast<const u32x4*>(p);
+        else { const u32x2 h = *reinterpret_cast<const u32x2*>(p); w.x = h.x; w.y = h.y; }
+        return w;
+    }
+    static __device__ __forceinline__ void unpack(const Raw& w, float (&v)[8]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[2 * q] = bf16_bits_to_f32(w[q] & 0xffffu); v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(unsigned short* p, int nv, const float (&v)[8]) {
+        u32x4 w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
+        if (nv == 8) *reinterpret_cast<u32x4*>(p) = w;
+        else *reinterpret_cast<u32x2*>(p) = u32x2{w.x, w.y};
+    }
 };
 
 struct CeArgs {
@@ -137,26 +173,34 @@ __device__ __forceinline__ RowCoef row_coef(const CeArgs& a, int row) {
 // A wave walks rows wave_id, wave_id + n_waves, ...  The IIF table sits in LDS (one copy per block, <= 8 KB) and the
 // next row's logits are already in flight while the current row is reduced and stored (6-8 waves per SIMD at
 // C = 1000 / 1204; a register-held table cost 110 VGPRs = half the occupancy).
+// (launch bound: 16 row values per lane = C <= 1024 fit 72 registers, i.e. 7 waves per SIMD, when the allocator is told so)
 template <typename T, int NCH, int MODE>
-__global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, int64_t ld_sm) {
-    __shared__ __attribute__((aligned(16))) float tab_s[NCH * 256];
+__global__ void __launch_bounds__(256, (NCH * RowIo<T>::V <= 16 ? 7 : 1)) row_reg_kernel(CeArgs a, float* sm_out, int64_t ld_sm) {
+    constexpr int V = RowIo<T>::V;                     // columns per lane and chunk: 16 bytes of T
+    __shared__ __attribute__((aligned(16))) float tab_s[NCH * 64 * V];
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int nwaves = gridDim.x * wpb;
     int row = blockIdx.x * wpb + (threadIdx.x >> 6);
-    f32x4 xn[NCH];
-    if (row < a.B) {                              // wave-uniform: the first row is in flight while the table is staged
-        const T* x0 = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
+    constexpr int DEPTH = RowIo<T>::DEPTH;            // rows in flight per wave
+    typename RowIo<T>::Raw xr[DEPTH][NCH];
+    // columns of chunk j that exist for this lane: V, or 4 on the tail of a bf16 row with C % 8 == 4, or 0
+    // (recomputed where needed, 2 VALU: kept in registers it costs one wave per SIMD at C = 1000)
+    const int cl = a.C - lane * V;
+    auto nvf = [&](int j) { const int left = cl - j * 64 * V; return left >= V ? V : (left > 0 ? left : 0); };
+    auto load_row = [&](int r, typename RowIo<T>::Raw (&dst)[NCH]) {
+        const T* xp = static_cast<const T*>(a.x) + (int64_t)r * a.ldx;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int c0 = (j * 64 + lane) * 4;
-            if (c0 < a.C) xn[j] = Io<T>::load4(x0 + c0);
-        }
-    }
+        for (int j = 0; j < NCH; ++j)
+            { const int n = nvf(j); if (n > 0) dst[j] = RowIo<T>::load_raw(xp + (j * 64 + lane) * V, n); }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (row + d * nwaves < a.B) load_row(row + d * nwaves, xr[d]);        // wave-uniform: in flight while the table is staged
     // table -> LDS in 16-byte pieces, all loads of a thread issued before the first LDS write (a scalar loop cost a
     // single-wave block 20 dependent round trips to L2: 22 us at [1024, 1204])
     {
-        constexpr int V4 = NCH * 64;                       // float4 pieces of the padded table
+        constexpr int V4 = NCH * 16 * V;                   // float4 pieces of the padded table
         f32x4 tv[(V4 + 63) / 64];
 #pragma unroll
         for (int q = 0; q < (V4 + 63) / 64; ++q) {
@@ -174,36 +218,36 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
     for (; row < a.B; row += nwaves) {
         asm volatile("" ::: "memory");            // keep the table reads in LDS: hoisted into registers they halve the occupancy
         const T* x = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
-        f32x4 z[NCH];
+        float z[NCH][V];
         float m = -INFINITY;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            const int c0 = (j * 64 + lane) * 4;
-            if (c0 < a.C) {
-                z[j] = xn[j] * *reinterpret_cast<const f32x4*>(tab_s + c0);
-                m = fmaxf(m, fmaxf(fmaxf(z[j].x, z[j].y), fmaxf(z[j].z, z[j].w)));
-            } else {
-                z[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            const float* tp = tab_s + (j * 64 + lane) * V;
+            const int n = nvf(j);
+            float xv[V];
+            RowIo<T>::unpack(xr[0][j], xv);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                z[j][e] = e < n ? xv[e] * tp[e] : -INFINITY;
+                m = fmaxf(m, z[j][e]);
             }
         }
         // The next row's loads go out BEFORE this row's stores: vmcnt retires in order, so a load issued after the
         // stores could only be waited for together with them (write latency + read latency per row, 1.9 TB/s).
-        if (row + nwaves < a.B) {                 // wave-uniform
-            const T* x1 = static_cast<const T*>(a.x) + (int64_t)(row + nwaves) * a.ldx;
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int c0 = (j * 64 + lane) * 4;
-                if (c0 < a.C) xn[j] = Io<T>::load4(x1 + c0);
-            }
-        }
+        for (int d = 0; d + 1 < DEPTH; ++d)
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) xr[d][j] = xr[d + 1][j];
+        if (row + DEPTH * nwaves < a.B) load_row(row + DEPTH * nwaves, xr[DEPTH - 1]);   // wave-uniform
         m = wave_max(m);
         const float m2 = m * kLog2e;
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {           // 2^(z*log2e - m*log2e): one fma + v_exp_f32 per element
-            z[j].x = fast_exp2(__builtin_fmaf(z[j].x, kLog2e, -m2)); z[j].y = fast_exp2(__builtin_fmaf(z[j].y, kLog2e, -m2));
-            z[j].z = fast_exp2(__builtin_fmaf(z[j].z, kLog2e, -m2)); z[j].w = fast_exp2(__builtin_fmaf(z[j].w, kLog2e, -m2));
-            s += (z[j].x + z[j].y) + (z[j].z + z[j].w);
+#pragma unroll
+            for (int e = 0; e < V; ++e) z[j][e] = fast_exp2(__builtin_fmaf(z[j][e], kLog2e, -m2));
+#pragma unroll
+            for (int e = 0; e < V; e += 4) s += (z[j][e] + z[j][e + 1]) + (z[j][e + 2] + z[j][e + 3]);
         }
         s = wave_sum(s);
         const float inv_s = 1.0f / s;
@@ -211,8 +255,11 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
             float* o = sm_out + (int64_t)row * ld_sm;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
-                const int c0 = (j * 64 + lane) * 4;
-                if (c0 < a.C) *reinterpret_cast<f32x4*>(o + c0) = z[j] * inv_s;
+                const int c0 = (j * 64 + lane) * V;
+                const int n = nvf(j);
+#pragma unroll
+                for (int e = 0; e < V; e += 4)
+                    if (e < n) *reinterpret_cast<f32x4*>(o + c0 + e) = f32x4{z[j][e] * inv_s, z[j][e + 1] * inv_s, z[j][e + 2] * inv_s, z[j][e + 3] * inv_s};
             }
             continue;
         }
@@ -230,17 +277,21 @@ __global__ void __launch_bounds__(256) row_reg_kernel(CeArgs a, float* sm_out, i
         const int ia = (int)rc.ta, ib = (int)rc.tb;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            const int c0 = (j * 64 + lane) * 4;
-            if (c0 < a.C) {
-                f32x4 p = z[j] * gs;
+            const int c0 = (j * 64 + lane) * V;
+            const int n = nvf(j);
+            if (n > 0) {
+                const float* tp = tab_s + c0;
+                float p[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) p[e] = z[j][e] * gs;
                 const unsigned da = (unsigned)(ia - c0), db = (unsigned)(ib - c0);
-                if ((da < 4u) | (db < 4u)) {      // only the lane(s) owning a target column
-                    p.x -= (da == 0u ? ga : 0.f) + (db == 0u ? gb : 0.f);
-                    p.y -= (da == 1u ? ga : 0.f) + (db == 1u ? gb : 0.f);
-                    p.z -= (da == 2u ? ga : 0.f) + (db == 2u ? gb : 0.f);
-                    p.w -= (da == 3u ? ga : 0.f) + (db == 3u ? gb : 0.f);
+                if ((da < (unsigned)V) | (db < (unsigned)V)) {      // only the lane(s) owning a target column
+#pragma unroll
+                    for (int e = 0; e < V; ++e) p[e] -= (da == (unsigned)e ? ga : 0.f) + (db == (unsigned)e ? gb : 0.f);
                 }
-                Io<T>::store4(dx + c0, p * *reinterpret_cast<const f32x4*>(tab_s + c0));
+#pragma unroll
+                for (int e = 0; e < V; ++e) p[e] *= tp[e];
+                RowIo<T>::store(dx + c0, n, p);
             }
         }
     }
@@ -355,25 +406,38 @@ constexpr unsigned kMaxRowBlocks = 2048;      // = partial slots of the single-l
 template <typename T, int MODE>
 int launch_rows(CeArgs a, float* sm_out, int64_t ld_sm, hipStream_t st, bool* inline_reduce = nullptr) {
     static const char* wpb_env = getenv("IIF_HEAD_WPB");
-    // waves per block: every block stages the table once and takes one ticket, so small batches use fewer, fatter blocks
-    const int wpb = wpb_env ? atoi(wpb_env) : 4;          // measured 1 / 2 / 4: [1024, 1204] 23.2 / 13.3 / 9.5 us, [256, 1000] 9.1 / 7.6 / 6.6 us
+    // waves per block: every block stages the table once and takes one ticket, so small batches use fewer, fatter blocks.
+    // finish_with_ticket's tree needs a power of two <= 4 (sh[256], __launch_bounds__(256)): anything else falls back to 4
+    int wpb = wpb_env ? atoi(wpb_env) : 4;                // measured 1 / 2 / 4: [1024, 1204] 23.2 / 13.3 / 9.5 us, [256, 1000] 9.1 / 7.6 / 6.6 us
+    if (wpb != 1 && wpb != 2 && wpb != 4) wpb = 4;
     const dim3 grid((a.B + wpb - 1) / wpb), block(64 * wpb);
-    // register-row kernel: at most 256 CUs x 8 blocks; beyond that a wave walks several rows
+    // register-row kernel: at most 256 CUs x 8 blocks; beyond that a wave walks several rows.  Never more blocks than the
+    // single-launch loss workspace has partial slots.
     static const char* mb_env = getenv("IIF_HEAD_MAXBLOCKS");
-    const unsigned maxb = mb_env ? (unsigned)atoi(mb_env) : 1024u;     // 256 / 512 / 1024 / 2048 blocks: [8192, 1204] 25.9 / 23.6 / 26.5 / 35.3 us, [65536, 1000] bf16 0.213 / 0.129 / 0.085 / 0.090 ms
+    unsigned maxb = mb_env ? (unsigned)atoi(mb_env) : 1024u;           // 256 / 512 / 1024 / 2048 blocks: [8192, 1204] 25.9 / 23.6 / 26.5 / 35.3 us, [65536, 1000] bf16 0.213 / 0.129 / 0.085 / 0.090 ms
+    if (maxb < 1u) maxb = 1u;
+    if (maxb > kMaxRowBlocks) maxb = kMaxRowBlocks;
     const dim3 pgrid(grid.x < maxb ? grid.x : maxb);
-    bool vec = (a.C % 4 == 0) && (a.C <= 2048) && (a.ldx % 4 == 0) && aligned(a.x, Io<T>::kAlign) &&
-               aligned(a.tab, 16);
-    if (MODE == 0 && a.dx) vec = vec && (a.lddx % 4 == 0) && aligned(a.dx, Io<T>::kAlign);
+    // rows in 16-byte lane vectors: 4 fp32 / 8 bf16 columns; a bf16 row may end on a half vector (C % 8 == 4: 1204)
+    constexpr int V = RowIo<T>::V;
+    bool vec = (a.C % 4 == 0) && (a.C <= 2048) && (a.ldx % V == 0) && aligned(a.x, 16) && aligned(a.tab, 16);
+    if (MODE == 0 && a.dx) vec = vec && (a.lddx % V == 0) && aligned(a.dx, 16);
     if (MODE == 1) vec = vec && (ld_sm % 4 == 0) && aligned(sm_out, 16);
     if (vec) {
-        const int nch = (a.C + 255) / 256;
+        const int nch = (a.C + 64 * V - 1) / (64 * V);
         if (nch <= 1) hipLaunchKernelGGL((row_reg_kernel<T, 1, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
         else if (nch <= 2) hipLaunchKernelGGL((row_reg_kernel<T, 2, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
+        else if (nch <= 3) hipLaunchKernelGGL((row_reg_kernel<T, 3, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);     // bf16: C = 1204 (LVIS head)
         else if (nch <= 4) hipLaunchKernelGGL((row_reg_kernel<T, 4, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
-        else if (nch <= 5) hipLaunchKernelGGL((row_reg_kernel<T, 5, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);     // C = 1204 (LVIS head)
-        else if (nch <= 6) hipLaunchKernelGGL((row_reg_kernel<T, 6, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
-        else hipLaunchKernelGGL((row_reg_kernel<T, 8, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
+        else {
+            if constexpr (V == 4) {
+                if (nch <= 5) hipLaunchKernelGGL((row_reg_kernel<T, 5, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);     // fp32: C = 1204 (LVIS head)
+                else if (nch <= 6) hipLaunchKernelGGL((row_reg_kernel<T, 6, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
+                else hipLaunchKernelGGL((row_reg_kernel<T, 8, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);
+            } else {
+                return IIF_EUNSUPPORTED;           // unreachable: C <= 2048 is at most 4 chunks of 512 bf16 columns
+            }
+        }
     } else {
         if (grid.x > kMaxRowBlocks) {
             a.ticket = nullptr;

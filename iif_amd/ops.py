@@ -9,17 +9,19 @@ from . import _lib
 from ._lib import ConvDesc, check, dtype_code, lib, ptr, require_gpu, stream_ptr
 
 
-def _desc(n, hs, ws, cs, hd, wd, cd, r, s, stride, pad, transposed, ldw, dtype, dst_dtype, groups=1):
-    return ConvDesc(n, hs, ws, cs, hd, wd, cd, r, s, stride, pad, transposed, ldw, dtype, dst_dtype, groups)
+def _desc(n, hs, ws, cs, hd, wd, cd, r, s, stride, pad, transposed, ldw, dtype, dst_dtype, groups=1, w_frag=None):
+    return ConvDesc(n, hs, ws, cs, hd, wd, cd, r, s, stride, pad, transposed, ldw, dtype, dst_dtype, groups,
+                    ptr(w_frag) if w_frag is not None else None)
 
 
 def conv_out_hw(h, w, r, s, stride, pad):
     return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
 
 
-def conv_forward(x, w, r, s, stride, pad, out=None, out_dtype=None, bias=None, res=None, groups=1, out_hw=None):
+def conv_forward(x, w, r, s, stride, pad, out=None, out_dtype=None, bias=None, res=None, groups=1, out_hw=None, w_frag=None):
     """x: [N,H,W,Cin] NHWC; w: [Cout, ldw] (rows = r*s*Cin K-contiguous, KRSC).  groups > 1: the
-    channels split into `groups` chunks, w holds the chunk matrices one after the other."""
+    channels split into `groups` chunks, w holds the chunk matrices one after the other.  w_frag: the same weights as
+    MFMA fragments (pack_fragments), used by the 3x3 / stride-1 kernel where it applies."""
     require_gpu(x, w, bias, res)
     n, h, wd_, cin = x.shape
     cout, ldw = w.shape
@@ -28,18 +30,18 @@ def conv_forward(x, w, r, s, stride, pad, out=None, out_dtype=None, bias=None, r
     if out is None:
         out = torch.empty((n, ho, wo, cout), dtype=odt, device=x.device)
     d = _desc(n, h, wd_, cin // groups, ho, wo, cout // groups, r, s, stride, pad, 0, ldw, dtype_code(x), dtype_code(out),
-              groups)
+              groups, w_frag)
     check(lib().iif_conv_igemm(ctypes.byref(d), ptr(x), ptr(w), ptr(out), ptr(res), ptr(bias), stream_ptr()), "iif_conv_igemm")
     return out
 
 
-def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial, groups=1):
+def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial, groups=1, w_frag=None):
     """conv_forward (bf16) that also writes per-tile BN partial sums; returns the tile count."""
     n, h, wd_, cin = x.shape
     cout, ldw = w.shape
     ho, wo = out.shape[1], out.shape[2]
     d = _desc(n, h, wd_, cin // groups, ho, wo, cout // groups, r, s, stride, pad, 0, ldw, dtype_code(x), dtype_code(out),
-              groups)
+              groups, w_frag)
     nt = ctypes.c_int32(0)
     check(lib().iif_conv_igemm_bnstats(ctypes.byref(d), ptr(x), ptr(w), ptr(out), 0, 0, ptr(partial), partial.numel(),
                                        ctypes.byref(nt), stream_ptr()), "iif_conv_igemm_bnstats")
@@ -62,7 +64,7 @@ def bn_finalize_stats(partial, n_partials, m, c, gamma, beta, running_mean, runn
     return stats
 
 
-def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, out=None, res=None, groups=1, res_bits=None):
+def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, out=None, res=None, groups=1, res_bits=None, w_frag=None):
     """dy: [N,Ho,Wo,Cout]; wt: [Cin, ldw] rows of r*s*Cout (the CRSK transpose);
     returns dx [N,H,W,Cin] (+ res, gated element-wise by the ReLU bits ``res_bits`` if given)."""
     require_gpu(dy, wt, res)
@@ -72,7 +74,7 @@ def conv_dgrad(dy, wt, r, s, stride, pad, in_hw, out=None, res=None, groups=1, r
     if out is None:
         out = torch.empty((n, h, w_, cin), dtype=dy.dtype, device=dy.device)
     d = _desc(n, ho, wo, cout // groups, h, w_, cin // groups, r, s, stride, pad, 1, ldw, dtype_code(dy), dtype_code(out),
-              groups)
+              groups, w_frag)
     if res_bits is not None:
         check(lib().iif_conv_igemm_masked_res(ctypes.byref(d), ptr(dy), ptr(wt), ptr(out), ptr(res), ptr(res_bits),
                                               stream_ptr()), "iif_conv_igemm_masked_res")
@@ -362,6 +364,31 @@ def wt_table(entries, device):
     return t, start
 
 
+def conv3x3_frag_ok(n, h, w, cin, cout, dtype):
+    """True when a dense 3x3 / stride-1 / pad-1 convolution of this geometry runs on the fragment-weights kernel."""
+    d = _desc(n, h, w, cin, h, w, cout, 3, 3, 1, 1, 0, 9 * cin, _lib.IIF_BF16 if dtype == torch.bfloat16 else _lib.IIF_F32,
+              _lib.IIF_BF16 if dtype == torch.bfloat16 else _lib.IIF_F32, 1)
+    return bool(lib().iif_conv3x3_frag_ok(ctypes.byref(d)))
+
+
+def pack_table(entries, device):
+    """entries: [(src_off, dst_off, rows, taps, k, ld)] in elements -> (device table of iif_pack_desc, total blocks)."""
+    import struct
+    blob, start = b"", 0
+    for (so, do, rows, taps, k, ld) in entries:
+        blob += struct.pack("<qqiiiiii", so, do, rows, taps, k, ld, start, 0)
+        start += (rows * taps * k // 8 + 255) // 256
+    return torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device), start
+
+
+def pack_fragments(src, table, n_desc, total_blocks, out):
+    """src / out: bf16 arenas the table's element offsets refer to (iif_conv_pack_fragments)."""
+    require_gpu(src, out, table)
+    check(lib().iif_conv_pack_fragments(ptr(src), ptr(table), n_desc, total_blocks, ptr(out), stream_ptr()),
+          "iif_conv_pack_fragments")
+    return out
+
+
 def weight_transpose_batched(arena, table, n_desc, total_blocks, out):
     check(lib().iif_weight_transpose_batched(ptr(arena), ptr(table), n_desc, total_blocks, dtype_code(out), ptr(out),
                                              stream_ptr()), "iif_weight_transpose_batched")
@@ -369,13 +396,14 @@ def weight_transpose_batched(arena, table, n_desc, total_blocks, out):
 
 
 # ------------------------------------------------------------ BN backward sums fused into the producing dgrad
-def conv_dgrad_bnbwd(dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits, up_stats, partial, res=None, res_bits=None):
+def conv_dgrad_bnbwd(dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits, up_stats, partial, res=None, res_bits=None,
+                     w_frag=None):
     """conv_dgrad that also writes the upstream unit's BN-backward partial sums; returns the partial row count."""
     require_gpu(dy, wt, res, up_x)
     n, ho, wo, cout = dy.shape
     cin, ldw = wt.shape
     h, w_ = in_hw
-    d = _desc(n, ho, wo, cout, h, w_, cin, r, s, stride, pad, 1, ldw, dtype_code(dy), dtype_code(out), 1)
+    d = _desc(n, ho, wo, cout, h, w_, cin, r, s, stride, pad, 1, ldw, dtype_code(dy), dtype_code(out), 1, w_frag)
     nt = ctypes.c_int32(0)
     check(lib().iif_conv_igemm_dgrad_bnbwd(ctypes.byref(d), ptr(dy), ptr(wt), ptr(out), ptr(res), ptr(res_bits), ptr(up_x),
                                            ptr(up_bits), ptr(up_stats), ptr(partial), partial.numel(), ctypes.byref(nt),

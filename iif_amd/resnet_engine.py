@@ -624,7 +624,7 @@ class _NetFunction(torch.autograd.Function):
 class _ConvUnit(object):
     """Buffers of one conv+BN unit inside a plan."""
     __slots__ = ("conv", "bn", "src", "x", "stats", "y", "w", "wt", "n", "hi", "wi", "ho", "wo", "is_patch_gemm",
-                 "groups", "dwp", "bits", "geom", "s2d")
+                 "groups", "dwp", "bits", "geom", "s2d", "wf", "wtf")
 
 
 class _Plan(object):
@@ -801,6 +801,36 @@ class _Plan(object):
             self.head_wt = self.wt_arena[o:o + rows * ld].view(rows, ld)
         self.wt_n = len(entries)
         self.wt_table, self.wt_blocks = ops.wt_table(entries, self.dev) if entries else (None, 0)
+        # 3x3 / stride-1 layers: the same weights once more as MFMA fragments (forward from the bf16 parameter arena, data
+        # gradient from the transposed arena), ONE pack launch per source arena and step; the fragment kernel reads them
+        # straight into registers (csrc/conv_igemm.hip, conv3x3_v2_body)
+        self.frag_arena, self.frag_fwd, self.frag_bwd = None, None, None
+        if self.dt == torch.bfloat16 and not os.environ.get("IIF_CONV_NO_V2"):
+            fwd, bwd, off = [], [], 0
+            for (u, o, rows, ld) in views:
+                cv = u.conv
+                if cv.k != 3 or cv.stride != 1 or cv.pad != 1 or cv.cin % 32 or cv.cout % 32:
+                    continue
+                if ops.conv3x3_frag_ok(u.n, u.hi, u.wi, cv.cin, cv.cout, self.dt):
+                    po = net._offsets[(id(cv), "weight")]
+                    fwd.append((po[0], off, cv.cout, 9, cv.cin, po[2]))
+                    u.wf = off
+                    off += cv.cout * 9 * cv.cin
+                if ops.conv3x3_frag_ok(u.n, u.ho, u.wo, cv.cout, cv.cin, self.dt):
+                    bwd.append((o, off, cv.cin, 9, cv.cout, ld))
+                    u.wtf = off
+                    off += cv.cout * 9 * cv.cin
+            if off:
+                self.frag_arena = torch.empty(off, dtype=self.dt, device=self.dev)
+                for u in self.units:
+                    if isinstance(u.wf, int):
+                        u.wf = self.frag_arena[u.wf:]
+                    if isinstance(u.wtf, int):
+                        u.wtf = self.frag_arena[u.wtf:]
+                if fwd:
+                    self.frag_fwd = ops.pack_table(fwd, self.dev) + (len(fwd),)
+                if bwd:
+                    self.frag_bwd = ops.pack_table(bwd, self.dev) + (len(bwd),)
 
     def _unit(self, conv, bn, src, n, ho, wo, patch=False, need_y=True):
         dt, dev = self.dt, self.dev
@@ -817,6 +847,7 @@ class _Plan(object):
         vec = 8 if dt == torch.bfloat16 else 4                     # channels per 16-byte vector
         u.bits = torch.empty(n * ho * wo * conv.cout // vec, dtype=torch.uint8, device=dev) if need_y else None
         u.groups, u.dwp = 1, None
+        u.wf = u.wtf = None
         if conv.groups > 1:
             # grouped conv: dense inside chunks of conv.chunk channels, block-diagonal packed weights
             ldp = conv.k * conv.k * conv.chunk
@@ -838,6 +869,10 @@ class _Plan(object):
             ops.cast(net._arena, self.lp_arena)
         if need_transposed and self.wt_n:
             ops.weight_transpose_batched(net._arena, self.wt_table, self.wt_n, self.wt_blocks, self.wt_arena)
+        if self.frag_fwd is not None:
+            ops.pack_fragments(self.lp_arena, self.frag_fwd[0], self.frag_fwd[2], self.frag_fwd[1], self.frag_arena)
+        if need_transposed and self.frag_bwd is not None:
+            ops.pack_fragments(self.wt_arena, self.frag_bwd[0], self.frag_bwd[2], self.frag_bwd[1], self.frag_arena)
         for u in self.units:
             cv = u.conv
             if u.s2d:
@@ -892,7 +927,7 @@ class _Plan(object):
         if training and self.dt == torch.bfloat16 and cv.cout % 8 == 0 and _dma_ok(u.src):
             # statistics come out of the convolution's epilogue: no extra pass over x
             partial, scratch = (self.bn_partial_side, self.bn_scratch_side) if side else (self.bn_partial, self.bn_scratch)
-            nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, partial, groups=u.groups)
+            nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, partial, groups=u.groups, w_frag=u.wf)
             if sync is not None:
                 self._sync_finalize(u, ops.bn_partial_sums(partial, nt, cv.cout, self._sync_sums(cv.cout, side)), m, sync)
                 return x2
@@ -900,7 +935,7 @@ class _Plan(object):
                                   u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM, scratch=scratch,
                                   tickets=self.bn_tickets_side if side else self.bn_tickets)
             return x2
-        ops.conv_forward(u.src, u.w, k, k, st, pd, out=u.x, groups=u.groups, out_hw=(u.ho, u.wo))
+        ops.conv_forward(u.src, u.w, k, k, st, pd, out=u.x, groups=u.groups, out_hw=(u.ho, u.wo), w_frag=u.wf)
         if sync is not None:
             self._sync_finalize(u, ops.bn_stats_sums(x2, self._sync_sums(cv.cout, side), self.bn_ws), m, sync)
             return x2
@@ -1165,11 +1200,11 @@ class _Plan(object):
         if fuse_up is not None and self.fuse_bwd and u.groups == 1 and dgrad_out is not None and _dma_ok(dx4):
             up, up_bits = fuse_up
             nt = ops.conv_dgrad_bnbwd(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), dgrad_out, up.x, up_bits, up.stats,
-                                      self.bw_partial, res=dgrad_res, res_bits=dgrad_res_bits)
+                                      self.bw_partial, res=dgrad_res, res_bits=dgrad_res_bits, w_frag=u.wtf)
             self._bw_ready = (up, nt)
             return dgrad_out
         return ops.conv_dgrad(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), out=dgrad_out, res=dgrad_res,
-                              groups=u.groups, res_bits=dgrad_res_bits)
+                              groups=u.groups, res_bits=dgrad_res_bits, w_frag=u.wtf)
 
     def backward(self, reducer=None):
         net = self.net

@@ -136,6 +136,10 @@ typedef struct iif_conv_desc {
                              /* tensors hold G*cs / G*cd channels per pixel, wgt is G   */
                              /* consecutive [cd][ldw] matrices (grouped convolution,    */
                              /* resnet_pytorch.py:137,141 ResNeXt)                      */
+    const void* wgt_frag;    /* nullable: the SAME weights as MFMA fragments            */
+                             /* (iif_conv_pack_fragments); used by the 3x3 / stride-1   */
+                             /* kernel where iif_conv3x3_frag_ok(d) says so, ignored    */
+                             /* elsewhere.  wgt must be valid either way.               */
 } iif_conv_desc;
 
 /* Implicit-GEMM convolution on the matrix cores:
@@ -356,6 +360,29 @@ typedef struct iif_wt_desc {
 } iif_wt_desc;
 int iif_weight_transpose_batched(const float* arena, const iif_wt_desc* table, int n_desc, int total_blocks,
                                  int out_dtype, void* out, void* stream);
+
+/* Weights as ready-made MFMA fragments for the 3x3 / stride-1 / pad-1 bf16 kernel (conv3x3 of resnet_pytorch.py:46-57,
+ * forward and data gradient).  Source: bf16 rows [rows][ld] of `taps` x `k` channels — the forward weights
+ * [cout][9 * cin] or the transposed copy [cin][9 * cout] of iif_weight_transpose.  Destination, rows * taps * k elements:
+ * fragment (row / 16, tap, channel / 32) = 1 KB, lane l's 16 bytes (row l & 15, channels (l >> 4) * 8 .. + 8) at l * 16,
+ * so that a wavefront fetches one operand of v_mfma_f32_16x16x32_bf16 with one coalesced load and the weights never pass
+ * through LDS.  rows % 16 == 0, k % 32 == 0.  `table` is a DEVICE array of descriptors (element offsets into src_base /
+ * dst_base, block_start = first 256-thread block of the descriptor, ascending); total_blocks = sum of
+ * ceil(rows * taps * k / 8 / 256).  iif_conv3x3_frag_ok: 1 when a convolution with this descriptor (wgt_frag set) runs on
+ * the fragment kernel, 0 when it would take the row-weights path. */
+typedef struct iif_pack_desc {
+    int64_t src_off, dst_off;
+    int32_t rows, taps, k, ld, block_start, reserved;
+} iif_pack_desc;
+int iif_conv_pack_fragments(const void* src_base, const iif_pack_desc* table, int n_desc, int total_blocks, void* dst_base,
+                            void* stream);
+int iif_conv3x3_frag_ok(const iif_conv_desc* d);
+
+/* The convolution library reads its experiment / test switches (IIF_CONV_NO_STREAM1X1, IIF_CONV_STREAM1X1_FORCE,
+ * IIF_CONV_NO_SHORTK, IIF_CONV_TWOSTAGE_K, IIF_CONV_FORCE_BN64, IIF_CONV_REGSTAGE, IIF_CONV_NO_V2) from the environment once, when it is
+ * loaded: nothing on the launch path calls getenv.  A harness that changes one of them afterwards calls this to have them
+ * read again.  Not needed (and not used) by the product path. */
+int iif_conv_reload_env(void);
 
 /* Data gradient with a MASKED residual: dst = dgrad(src, wgt) + res * [bit], where res_bits holds one ReLU
  * decision bit per element of res (the relu_bits of iif_bn_apply: one byte per 16-byte vector).  This is the

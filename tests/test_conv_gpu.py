@@ -327,6 +327,98 @@ print(json.dumps({"nt": nt, "m": m, "e_fwd": e_fwd, "e_sum": e_sum, "e_sq": e_sq
     assert abs(hres["digest"] - tres["digest"]) <= 1e-3 * max(1.0, abs(tres["digest"]))
 
 
+V2_CASES = [(4, 128, 28, 28, 128), (3, 256, 14, 14, 256), (7, 512, 7, 7, 512), (2, 64, 56, 56, 64), (2, 128, 9, 11, 256),
+            (1, 64, 5, 30, 192), (40, 64, 5, 5, 128), (3, 128, 17, 13, 64), (5, 64, 14, 14, 320)]
+
+
+def _pack_frag(w2d, rows, taps, k):
+    """bf16 rows [rows][taps * k] -> fragment layout through the C entry point."""
+    from iif_amd import ops
+    tab, blocks = ops.pack_table([(0, 0, rows, taps, k, w2d.shape[1])], DEV)
+    out = torch.empty(rows * taps * k, dtype=w2d.dtype, device=DEV)
+    return ops.pack_fragments(w2d, tab, 1, blocks, out)
+
+
+@pytest.mark.parametrize("case", V2_CASES, ids=["%dx%dx%d_%d_to_%d" % (c[0], c[2], c[3], c[1], c[4]) for c in V2_CASES])
+def test_conv3x3_fragment_kernel(case, conv_env):
+    """Generation-2 3x3 kernel (weights as MFMA fragments straight from L2 into registers, halo window in LDS, one barrier
+    per 32-channel chunk, 128 x 64 wave tiles): the fragment layout itself, forward with fused BN partial sums, data
+    gradient with residual, data gradient with the upstream BN-backward sums — against torch conv2d, and the stored
+    tensors BIT-IDENTICAL to the round-1 halo kernel where that one applies (same accumulation order)."""
+    import torch.nn.functional as F
+    from iif_amd import ops
+    n, cin, h, w, cout = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g).to(dt)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).to(dt)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()                                    # noqa: E731
+    krsc = lambda w_: w_.permute(0, 2, 3, 1).reshape(w_.shape[0], -1).contiguous()          # noqa: E731
+    xd, wd = nhwc(x).to(DEV), krsc(wt).to(DEV)
+    conv_env(IIF_CONV_V2_WIDE="1")                        # the 128-channel variant is opt-in (see v2_geometry_ok)
+    assert ops.conv3x3_frag_ok(n, h, w, cin, cout, dt) and ops.conv3x3_frag_ok(n, h, w, cout, cin, dt)
+    wf = _pack_frag(wd, cout, 9, cin)
+    # the layout: fragment (row tile, tap, chunk), lane (row & 15, 8 channels of (lane >> 4))
+    wv = wd.cpu().view(cout // 16, 16, 9, cin // 32, 4, 8)
+    expect = wv.permute(0, 2, 3, 4, 1, 5).contiguous().view(-1)                             # [nt][tap][kc][fc][fr][8]
+    assert torch.equal(wf.cpu(), expect)
+    ref = F.conv2d(x.float(), wt.float(), None, 1, 1)
+    m = n * h * w
+    res = {}
+    dy = torch.randn(n, cout, h, w, generator=g).to(dt)
+    rs = torch.randn(n, cin, h, w, generator=g).to(dt)
+    upx = torch.randn(m, cin, generator=g).to(dt)
+    bits = torch.randint(0, 256, (m * cin // 8,), dtype=torch.uint8, generator=g).to(DEV)
+    stats = torch.zeros(4, cin)
+    stats[0] = torch.randn(cin, generator=g) * 0.1
+    stats[1] = torch.rand(cin, generator=g) + 0.5
+    wtt = krsc(wt.permute(1, 0, 2, 3).contiguous()).to(DEV)
+    wtf = _pack_frag(wtt, cin, 9, cout)
+    for mode in ("v2", "old"):
+        conv_env(IIF_CONV_NO_V2=None if mode == "v2" else "1", IIF_CONV_HALO_FORCE="1", IIF_CONV_V2_WIDE="1")
+        out = torch.full((n, h, w, cout), float("nan"), dtype=dt, device=DEV)
+        partial = torch.full((((m + 127) // 128) * 2 * cout,), float("nan"), device=DEV)
+        nt = ops.conv_forward_bnstats(xd, wd, 3, 3, 1, 1, out, partial, w_frag=wf)
+        dx = ops.conv_dgrad(nhwc(dy).to(DEV), wtt, 3, 3, 1, 1, (h, w), res=nhwc(rs).to(DEV), w_frag=wtf)
+        dx2 = torch.full((n, h, w, cin), float("nan"), dtype=dt, device=DEV)
+        partial2 = torch.full(((m + 127) // 128 + 8, 2, cin), float("nan"), device=DEV)
+        nt2 = ops.conv_dgrad_bnbwd(nhwc(dy).to(DEV), wtt, 3, 3, 1, 1, (h, w), dx2, upx.view(n, h, w, cin).to(DEV), bits,
+                                   stats.to(DEV), partial2.view(-1), w_frag=wtf)
+        res[mode] = (out, partial[:nt * 2 * cout].view(nt, 2, cout).sum(0).cpu(), nt, dx, dx2, partial2[:nt2].sum(0).cpu(), nt2)
+    out, ps, nt, dx, dx2, ps2, nt2 = res["v2"]
+    assert nt == (m + 255) // 256 and nt2 == (m + 255) // 256                     # the fragment kernel ran: 256-pixel tiles
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    st = out.float().cpu().reshape(-1, cout)
+    assert not torch.isnan(ps).any()
+    assert (ps[0] - st.sum(0)).abs().max().item() <= 1e-5 * max(1.0, st.sum(0).abs().max().item())
+    assert (ps[1] - st.square().sum(0)).abs().max().item() <= 1e-5 * max(1.0, st.square().sum(0).abs().max().item())
+    refdx = torch.nn.grad.conv2d_input(x.shape, wt.float(), dy.float(), 1, 1) + rs.float()
+    assert (dx.float().cpu().permute(0, 3, 1, 2) - refdx).abs().max().item() <= 2.0 ** -7 * refdx.abs().max().item()
+    mask = ((bits.cpu().view(-1, 1).int() >> torch.arange(8).view(1, 8)) & 1).view(m, cin).float()
+    gq = dx2.float().cpu().view(m, cin) * mask
+    s1, s2 = gq.sum(0), (gq * ((upx.float() - stats[0]) * stats[1])).sum(0)
+    assert not torch.isnan(ps2).any()
+    assert (ps2[0] - s1).abs().max().item() <= 2e-6 * max(1.0, s1.abs().max().item()) * 8
+    assert (ps2[1] - s2).abs().max().item() <= 2e-6 * max(1.0, s2.abs().max().item()) * 8
+    # against the kernels it replaces: the halo kernel accumulates in the same order (chunk outer, tap inner) -> identical
+    # bits; the tap kernel (cout < 128 or a window beyond its 512 halo rows) is tap-major -> equal within the bf16 rounding
+    o_out, _, o_nt, o_dx, o_dx2 = res["old"][:5]
+    span = (256 + w - 1) // w + 1 + 2 * (256 // (h * w) + 1)
+    span1 = (128 + w - 1) // w + 1 + 2 * (128 // (h * w) + 1)
+    halo_ok = (span + 2) * (w + 2) <= 512 and (span1 + 2) * (w + 2) <= 304            # use_halo's window conditions
+    halo_fwd = cout >= 128 and halo_ok
+    halo_bwd = cin >= 128 and halo_ok
+    if halo_fwd:
+        assert torch.equal(out, o_out)
+    else:
+        assert (out.float() - o_out.float()).abs().max().item() <= 2.0 ** -6 * ref.abs().max().item()
+    if halo_bwd:
+        assert torch.equal(dx, o_dx) and torch.equal(dx2, o_dx2)
+    else:
+        assert (dx.float() - o_dx.float()).abs().max().item() <= 2.0 ** -6 * refdx.abs().max().item()
+
+
 @pytest.mark.parametrize("case", [(4, 64, 14, 14, 128, 1, 1, True, True), (4, 128, 14, 14, 64, 3, 1, False, False),
                                   (3, 64, 16, 16, 128, 3, 2, False, True), (3, 256, 16, 16, 512, 1, 2, True, False),
                                   (8, 256, 28, 28, 128, 3, 1, False, True), (2, 64, 15, 13, 128, 3, 2, False, True)])
@@ -395,17 +487,39 @@ def test_stem_s2d_weight_gradient_all_taps_per_block(n, h, w):
 
 
 # ------------------------------------------------------------------------------------------- streaming 1x1 kernel
-STREAM_CASES = [  # N, Cin, H, W, Cout : the three instantiations, ragged last tile, fewer tiles than blocks, many tiles per block
+STREAM_CASES = [  # N, Cin, H, W, Cout : every instantiation, ragged last tile, fewer tiles than blocks, many tiles per block
     (3, 64, 20, 23, 256), (2, 256, 17, 19, 64), (2, 256, 24, 24, 128), (1, 64, 9, 7, 64), (2, 32, 40, 40, 256),
     (5, 128, 12, 12, 64), (40, 64, 56, 56, 256), (37, 256, 56, 56, 64),
+    # round 3: N slices of a tile sequence on neighbouring blocks (S = 2, 4, 8), K = 128 and K = 512 residents; both directions
+    # of every bottleneck 1x1 layer of the 28x28 / 14x14 stages (the data gradient of Cin -> Cout runs Cout -> Cin)
+    (3, 128, 28, 28, 512), (3, 512, 28, 28, 128), (2, 128, 13, 11, 256), (5, 256, 14, 14, 1024), (2, 256, 28, 28, 512),
+    (2, 512, 28, 28, 256), (9, 128, 28, 28, 512), (1, 512, 5, 5, 128), (2, 256, 56, 56, 128), (2, 128, 56, 56, 256),
 ]
 
 
-@pytest.mark.parametrize("case", STREAM_CASES)
-def test_stream1x1_forward_stats_and_dgrad_epilogues(case, monkeypatch):
-    """gemm1x1_stream_kernel (persistent, weights resident in LDS, compute / store wave groups) forced onto small
-    grids: forward + fused BN statistics, data gradient with a ReLU-masked residual, data gradient with the upstream
-    BN-backward sums — each against torch and BIT-IDENTICAL in the stored tensor to the tile kernels it replaces."""
+@pytest.fixture
+def conv_env(monkeypatch):
+    """Set / unset convolution switches AND make the library read them again (it caches them when it is loaded)."""
+    from iif_amd import _lib
+
+    def set_(**kv):
+        for k, v in kv.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        _lib.check(_lib.lib().iif_conv_reload_env(), "iif_conv_reload_env")
+    yield set_
+    monkeypatch.undo()
+    _lib.lib().iif_conv_reload_env()
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=["%dx%dx%d_%d_to_%d" % (c[0], c[2], c[3], c[1], c[4]) for c in STREAM_CASES])
+def test_stream1x1_forward_stats_and_dgrad_epilogues(case, conv_env):
+    """gemm1x1_stream_kernel (persistent, an N slice of the weights resident in LDS, compute / store wave groups, epilogue
+    operands fetched a tile ahead) forced onto small grids: forward + fused BN statistics, data gradient with a ReLU-masked
+    residual, data gradient with the upstream BN-backward sums, and the conv1 form with BOTH (masked residual + upstream
+    sums) — each against torch and BIT-IDENTICAL in the stored tensor to the tile kernels it replaces."""
     from iif_amd import ops
     n, cin, h, w, cout = case
     dt = torch.bfloat16
@@ -419,11 +533,9 @@ def test_stream1x1_forward_stats_and_dgrad_epilogues(case, monkeypatch):
 
     def run(force):
         if force:
-            monkeypatch.setenv("IIF_CONV_STREAM1X1_FORCE", "1")
-            monkeypatch.delenv("IIF_CONV_NO_STREAM1X1", raising=False)
+            conv_env(IIF_CONV_STREAM1X1_FORCE="1", IIF_CONV_NO_STREAM1X1=None)
         else:
-            monkeypatch.delenv("IIF_CONV_STREAM1X1_FORCE", raising=False)
-            monkeypatch.setenv("IIF_CONV_NO_STREAM1X1", "1")
+            conv_env(IIF_CONV_STREAM1X1_FORCE=None, IIF_CONV_NO_STREAM1X1="1")
         out = torch.full((n, h, w, cout), float("nan"), dtype=dt, device=DEV)
         partial = torch.full((((m + 127) // 128) * 2 * cout,), float("nan"), device=DEV)
         nt = ops.conv_forward_bnstats(xd, wd, 1, 1, 1, 0, out, partial)
@@ -458,18 +570,33 @@ def test_stream1x1_forward_stats_and_dgrad_epilogues(case, monkeypatch):
     stats[0] = torch.randn(cin, generator=g) * 0.1
     stats[1] = torch.rand(cin, generator=g) + 0.5
     got = {}
+    bits2 = torch.randint(0, 256, (m * cin // 8,), dtype=torch.uint8, generator=g).to(DEV)
     for force in (True, False):
         if force:
-            monkeypatch.setenv("IIF_CONV_STREAM1X1_FORCE", "1"); monkeypatch.delenv("IIF_CONV_NO_STREAM1X1", raising=False)
+            conv_env(IIF_CONV_STREAM1X1_FORCE="1", IIF_CONV_NO_STREAM1X1=None)
         else:
-            monkeypatch.delenv("IIF_CONV_STREAM1X1_FORCE", raising=False); monkeypatch.setenv("IIF_CONV_NO_STREAM1X1", "1")
+            conv_env(IIF_CONV_STREAM1X1_FORCE=None, IIF_CONV_NO_STREAM1X1="1")
         dx = ops.conv_dgrad(dyd, wtt, 1, 1, 1, 0, (h, w), res=res.view(n, h, w, cin).to(DEV), res_bits=bits)
         out2 = torch.full((n, h, w, cin), float("nan"), dtype=dt, device=DEV)
         partial = torch.full(((m + 127) // 128 + 8, 2, cin), float("nan"), device=DEV)
         nt = ops.conv_dgrad_bnbwd(dyd, wtt, 1, 1, 1, 0, (h, w), out2, upx.view(n, h, w, cin).to(DEV), bits, stats.to(DEV),
                                   partial.view(-1))
-        got[force] = (dx, out2, partial[:nt].sum(0).cpu(), nt)
-    dx_s, out2_s, ps, nt = got[True]
+        # the conv1 form: masked residual (block-output gradient) AND the upstream sums on one launch
+        out3 = torch.full((n, h, w, cin), float("nan"), dtype=dt, device=DEV)
+        partial3 = torch.full(((m + 127) // 128 + 8, 2, cin), float("nan"), device=DEV)
+        nt3 = ops.conv_dgrad_bnbwd(dyd, wtt, 1, 1, 1, 0, (h, w), out3, upx.view(n, h, w, cin).to(DEV), bits2, stats.to(DEV),
+                                   partial3.view(-1), res=res.view(n, h, w, cin).to(DEV), res_bits=bits)
+        got[force] = (dx, out2, partial[:nt].sum(0).cpu(), nt, out3, partial3[:nt3].sum(0).cpu(), nt3, bits2.cpu())
+    dx_s, out2_s, ps, nt = got[True][:4]
+    out3_s, ps3, nt3, bits2 = got[True][4:]
+    assert torch.equal(out3_s, got[False][4]) and torch.equal(out3_s, dx_s)           # the sums do not touch the stored tensor
+    assert nt3 == (m + 127) // 128 and not torch.isnan(ps3).any()
+    mask2 = ((bits2.view(-1, 1).int() >> torch.arange(8).view(1, 8)) & 1).view(m, cin).float()
+    g3 = out3_s.float().cpu().view(m, cin) * mask2
+    t1, t2 = g3.sum(0), (g3 * ((upx.float() - stats[0]) * stats[1])).sum(0)
+    assert (ps3[0] - t1).abs().max().item() <= 2e-6 * max(1.0, t1.abs().max().item()) * 8
+    assert (ps3[1] - t2).abs().max().item() <= 2e-6 * max(1.0, t2.abs().max().item()) * 8
+    assert (ps3 - got[False][5]).abs().max().item() <= 1e-4 * max(1.0, got[False][5].abs().max().item())
     assert (dx_s.float().cpu().view(m, cin) - refdx).abs().max().item() <= 2.0 ** -7 * refdx.abs().max().item()
     assert torch.equal(dx_s, got[False][0]) and torch.equal(out2_s, got[False][1])
     gq = out2_s.float().cpu().view(m, cin) * (pre.float() > 0)

