@@ -64,6 +64,8 @@ SIGNATURES = {
     "iif_se_apply": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "iif_se_backward_sums": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "iif_se_backward_form": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "iif_se_excite_forward": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P],
+    "iif_se_excite_backward": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P],
     "iif_rownorm_forward": [_P, _P, _I, _I, _L, _F, _F, _F, _P, _L, _P, _P],
     "iif_rownorm_backward": [_P, _P, _P, _P, _I, _I, _L, _L, _F, _F, _F, _P, _L, _P],
     "iif_weight_transpose_batched": [_P, _P, _I, _I, _I, _P, _P],

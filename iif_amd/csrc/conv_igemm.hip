@@ -1530,7 +1530,12 @@ struct ConvSwitches {
         c.no_stream = getenv("IIF_CONV_NO_STREAM1X1") != nullptr;
         c.force_stream = getenv("IIF_CONV_STREAM1X1_FORCE") != nullptr;
         c.stream_fwd_only = getenv("IIF_CONV_STREAM1X1_FWD_ONLY") != nullptr;
-        c.stream_r2 = getenv("IIF_CONV_STREAM1X1_R2") != nullptr;
+        // Default coverage = what wins alone AND in the step (scripts/bm_stream1x1.py, gpurun_out/r3/bm_stream_a.log): the forward
+        // launches whose whole weight matrix is resident (64->256, 256->128, 256->64).  The N-sliced shapes and the data
+        // gradients with prefetched epilogue operands are correct (tests force them) but level with or behind the
+        // 4-blocks-per-CU tile kernel (weighted 5.16 against 5.05 ms per step alone, 21.28 against 21.19 ms in the step):
+        // IIF_CONV_STREAM1X1_ALL opts in.
+        c.stream_r2 = getenv("IIF_CONV_STREAM1X1_ALL") == nullptr;
         c.no_shortk = getenv("IIF_CONV_NO_SHORTK") != nullptr;
         c.regstage = getenv("IIF_CONV_REGSTAGE") != nullptr;
         c.no_v2 = getenv("IIF_CONV_NO_V2") != nullptr;
@@ -1561,7 +1566,7 @@ inline bool use_stream1x1(const ConvArgs& a, bool utap, int esz, bool outf32, St
     else if (K > 128 && K <= 256 && N % 128 == 0 && N <= 1024) *pl = {128, 256, N / 128};
     else if (K > 256 && K <= 512 && N % 64 == 0 && N <= 256) *pl = {64, 512, N / 64};
     else return false;
-    if (old_only && (pl->slices > 1 || a.transposed || a.bw_x || pl->kmax == 128 || pl->kmax == 512)) return false;
+    if (old_only && !force_ && (pl->slices > 1 || a.transposed || a.bw_x || pl->kmax == 128 || pl->kmax == 512)) return false;
     if (no_dgrad && (a.transposed || a.bw_x)) return false;
     if (force_) return true;
     return (int64_t)((a.M + 127) / 128) * pl->slices >= 1024;               // >= 4 tiles per persistent block

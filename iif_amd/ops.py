@@ -322,6 +322,24 @@ def se_apply(x, stats, excite, y, relu_bits, residual=None, residual_stats=None)
     return y
 
 
+def se_excite_forward(sums, stats, hw, w1, w2t, q, h, e):
+    """q = mean_hw(bn(x)), h = relu(W1 q), e = sigmoid(W2 h) in one launch; w2t = W2^T [hid, C]."""
+    n, c = sums.shape
+    hid = w1.shape[0]
+    check(lib().iif_se_excite_forward(ptr(sums), ptr(stats), n, hw, c, hid, ptr(w1), w1.stride(0), ptr(w2t), w2t.stride(0),
+                                      ptr(q), ptr(h), ptr(e), stream_ptr()), "iif_se_excite_forward")
+    return e
+
+
+def se_excite_backward(s1, s2, stats, hw, w1, w2t, e, h, q, dz2, dz1, offset, dw1, dw2):
+    n, c = s1.shape
+    hid = w1.shape[0]
+    check(lib().iif_se_excite_backward(ptr(s1), ptr(s2), ptr(stats), n, hw, c, hid, ptr(w1), w1.stride(0), ptr(w2t),
+                                       w2t.stride(0), ptr(e), ptr(h), ptr(q), ptr(dz2), ptr(dz1), ptr(offset), ptr(dw1),
+                                       dw1.stride(0), ptr(dw2), dw2.stride(0), stream_ptr()), "iif_se_excite_backward")
+    return offset
+
+
 def se_backward_sums(g, relu_bits, x, s1, s2):
     n, h, w, c = x.shape
     check(lib().iif_se_backward_sums(ptr(g), ptr(relu_bits), ptr(x), dtype_code(x), n, h * w, c, ptr(s1), ptr(s2),

@@ -691,7 +691,7 @@ class _Plan(object):
                     Z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)   # noqa: E731
                     c, hid = blk.se.c, blk.se.hidden
                     b["se"] = {"sums": Z(n, c), "q": Z(n, c), "h": Z(n, hid), "e": Z(n, c), "s1": Z(n, c), "s2": Z(n, c),
-                               "o": Z(n, c)}
+                               "o": Z(n, c), "w2t": Z(hid, c), "dz2": Z(n, c), "dz1": Z(n, hid)}
                 self.blocks.append(b)
                 cur = last.y
         self.final = cur
@@ -1026,16 +1026,14 @@ class _Plan(object):
     def _se_forward(self, b, last, training):
         """y = relu(bn(x) * e + identity), e = sigmoid(W2 relu(W1 mean_hw(bn(x)))) — SEBottleneck.forward
         (resnet_pytorch.py:358-381) / Se_Block.forward (resnet_cifar.py:163-169).  The squeeze and the
-        rescale are native streaming kernels; the [N, C]-sized excitation is two rocBLAS GEMMs in fp32."""
+        rescale are native streaming kernels; the [N, C]-sized excitation is one native fp32 launch (csrc/se.hip)."""
         se, P = b["blk"].se, b["se"]
         w1, w2 = se.excitation[0]._w2d, se.excitation[2]._w2d
         ops.se_squeeze(last.x, P["sums"])
-        # mean_hw(a*x + b) = a * mean_hw(x) + b
-        torch.addcmul(last.stats[3], P["sums"], last.stats[2], value=1.0 / (last.ho * last.wo), out=P["q"])
-        torch.mm(P["q"], w1.t(), out=P["h"])
-        P["h"].relu_()
-        torch.mm(P["h"], w2.t(), out=P["e"])
-        P["e"].sigmoid_()
+        # one launch: q = a * mean_hw(x) + b (the BN affine commutes with the mean), h = relu(W1 q), e = sigmoid(W2 h);
+        # W2 is read through its transpose so that both matrices stream along the channel axis
+        ops.transpose_f32(w2[:, :se.hidden], P["w2t"])
+        ops.se_excite_forward(P["sums"], last.stats, last.ho * last.wo, w1, P["w2t"], P["q"], P["h"], P["e"])
         res, rstats = b["inp"], None
         if "ds" in b:
             du = b["ds"]
@@ -1053,14 +1051,10 @@ class _Plan(object):
         l1, l2 = se.excitation[0], se.excitation[2]
         hw = last.ho * last.wo
         ops.se_backward_sums(g, last.bits, last.x, P["s1"], P["s2"])
-        # d e[n,c] = sum_hw g * (a*x + b) = a*S2 + b*S1;  back through sigmoid / linear / relu / linear
-        de = torch.addcmul(P["s1"] * last.stats[3], P["s2"], last.stats[2])
-        dz2 = de * P["e"] * (1.0 - P["e"])
-        torch.mm(dz2.t(), P["h"], out=l2._g2d)
-        dz1 = torch.mm(dz2, l2._w2d) * (P["h"] > 0)
-        torch.mm(dz1.t(), P["q"], out=l1._g2d)
-        torch.mm(dz1, l1._w2d, out=P["o"])
-        P["o"].mul_(1.0 / hw)
+        # d e[n,c] = sum_hw g * (a*x + b) = a*S2 + b*S1;  back through sigmoid / linear / relu / linear, the two weight
+        # gradients and the offset (dz1 W1) / HW in three native launches (no vendor GEMM on the path)
+        ops.se_excite_backward(P["s1"], P["s2"], last.stats, hw, l1._w2d, P["w2t"], P["e"], P["h"], P["q"], P["dz2"], P["dz1"],
+                               P["o"], l1._g2d, l2._g2d)
         m = last.n * hw
         G = self._gbuf(("dx", m, last.conv.cout, par), (m, last.conv.cout)).view(last.n, last.ho, last.wo, last.conv.cout)
         return ops.se_backward_form(g, P["e"], P["o"], G)

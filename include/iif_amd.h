@@ -329,7 +329,11 @@ int iif_stem_s2d_unpack_grad(const float* packed, int k, int c, int r, int cpad,
  *                         a2*residual + b2 (residual_stats), relu_bits = 1 bit per element
  *   iif_se_backward_sums  g <- g * [y > 0] in place; s1[n,c] = sum_hw g; s2[n,c] = sum_hw g*x
  *   iif_se_backward_form  out = g * excite[n,c] + offset[n,c]  (gradient w.r.t. the BN output)
- * The [n, c]-sized excitation (two bias-free linears, ReLU, sigmoid) is host-side plumbing. */
+ * The [n, c]-sized excitation (two bias-free linears, ReLU, sigmoid; resnet_pytorch.py:306-311, 315), fp32:
+ *   iif_se_excite_forward   q = a * sums / hw + b (mean of the BN output);  h = relu(W1 q);  e = sigmoid(W2 h)
+ *   iif_se_excite_backward  from s1 / s2 of iif_se_backward_sums: dz2, dz1 (scratch [n,c] / [n,hid]), offset = (dz1 W1) / hw
+ *                           (the `offset` of iif_se_backward_form) and the weight gradients dw1 [hid][ldg1], dw2 [c][ldg2]
+ * w1 is W1 [hid][ld1]; w2t is the TRANSPOSE of W2, [hid][ldt] (iif_transpose_f32), so both matrices are read along c. */
 int iif_se_squeeze(const void* x, int dtype, int n, int hw, int c, float* sums, void* stream);
 int iif_se_apply(const void* x, int dtype, int n, int hw, int c, const float* stats, const float* excite,
                  const void* residual, const float* residual_stats, void* y, unsigned char* relu_bits,
@@ -338,6 +342,11 @@ int iif_se_backward_sums(void* g, const unsigned char* relu_bits, const void* x,
                          int c, float* s1, float* s2, void* stream);
 int iif_se_backward_form(const void* g, int dtype, int n, int hw, int c, const float* excite,
                          const float* offset, void* out, void* stream);
+int iif_se_excite_forward(const float* sums, const float* stats, int n, int hw, int c, int hid, const float* w1, int ld1,
+                          const float* w2t, int ldt, float* q, float* h, float* e, void* stream);
+int iif_se_excite_backward(const float* s1, const float* s2, const float* stats, int n, int hw, int c, int hid, const float* w1,
+                           int ld1, const float* w2t, int ldt, const float* e, const float* h, const float* q, float* dz2,
+                           float* dz1, float* offset, float* dw1, int ldg1, float* dw2, int ldg2, void* stream);
 
 /* mmdet normed predictors (instance_segmentation/mmdet/models/utils/normed_predictor.py: NormedLinear :34-40,
  * IIFNormedLinear :67-73, NormedConv2d with a 1x1 kernel :104-112), fp32:

@@ -27,12 +27,12 @@ MODES = ("k64", "stream")
 
 
 def mode(m):
-    for k in ("IIF_CONV_NO_STREAM1X1", "IIF_CONV_NO_SHORTK", "IIF_CONV_STREAM1X1_FORCE", "IIF_CONV_STREAM1X1_R2"):
+    for k in ("IIF_CONV_NO_STREAM1X1", "IIF_CONV_NO_SHORTK", "IIF_CONV_STREAM1X1_FORCE", "IIF_CONV_STREAM1X1_ALL"):
         os.environ.pop(k, None)
     if m == "k64":
         os.environ["IIF_CONV_NO_STREAM1X1"] = "1"
     elif m == "r2":
-        os.environ["IIF_CONV_STREAM1X1_R2"] = "1"
+        pass                                            # the default coverage
     else:
         os.environ["IIF_CONV_STREAM1X1_FORCE"] = "1"
     _lib.check(_lib.lib().iif_conv_reload_env(), "reload")

@@ -287,6 +287,49 @@ def test_se_kernels_against_torch(dt, n, hw, c, res):
     assert (out.float().cpu() - ref_o).abs().max().item() <= tol_for(dt) * max(1.0, ref_o.abs().max().item())
 
 
+@pytest.mark.parametrize("n,c,hid,hw", [(5, 16, 4, 64), (8, 64, 16, 9), (13, 256, 16, 196), (6, 2048, 128, 49), (256, 512, 32, 784)])
+def test_se_excitation_native_against_torch(n, c, hid, hw):
+    """The squeeze-and-excitation MLP (SE_Block.forward, resnet_pytorch.py:306-317: two bias-free linears, ReLU, sigmoid) as
+    native launches: forward from the squeeze sums and the BN affine, backward from the per-sample sums of
+    iif_se_backward_sums, both weight gradients — against torch autograd in float64 (the kernels are fp32)."""
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(n * 7 + c)
+    sums = torch.randn(n, c, generator=g) * hw ** 0.5
+    stats = torch.zeros(4, c)
+    stats[2] = torch.rand(c, generator=g) + 0.5
+    stats[3] = torch.randn(c, generator=g) * 0.3
+    ld1, ld2 = (c + 15) // 16 * 16, (hid + 15) // 16 * 16            # parameter rows are padded to 16 columns in the arena
+    w1 = torch.zeros(hid, ld1); w1[:, :c] = torch.randn(hid, c, generator=g) / c ** 0.5
+    w2 = torch.zeros(c, ld2); w2[:, :hid] = torch.randn(c, hid, generator=g) / hid ** 0.5
+    s1 = torch.randn(n, c, generator=g)
+    s2 = torch.randn(n, c, generator=g) * 2.0
+    d = lambda t: t.to(DEV)                                          # noqa: E731
+    Z = lambda *sh: torch.full(sh, float("nan"), device=DEV)           # noqa: E731
+    w1d, w2d = d(w1), d(w2)
+    w2t = ops.transpose_f32(w2d[:, :hid], Z(hid, c))
+    q, h, e = Z(n, c), Z(n, hid), Z(n, c)
+    ops.se_excite_forward(d(sums), d(stats), hw, w1d, w2t, q, h, e)
+    # reference in float64
+    W1 = w1[:, :c].double().requires_grad_(True)
+    W2 = w2[:, :hid].double().requires_grad_(True)
+    qr = (stats[2].double() * sums.double() / hw + stats[3].double()).requires_grad_(True)
+    hr = torch.relu(qr @ W1.t())
+    er = torch.sigmoid(hr @ W2.t())
+    assert (q.cpu().double() - qr.detach()).abs().max().item() <= 1e-5 * qr.abs().max().item()
+    assert (h.cpu().double() - hr.detach()).abs().max().item() <= 2e-5 * max(1.0, hr.abs().max().item())
+    assert (e.cpu().double() - er.detach()).abs().max().item() <= 2e-6
+    de = stats[2].double() * s2.double() + stats[3].double() * s1.double()
+    er.backward(de)
+    dz2, dz1, off = Z(n, c), Z(n, hid), Z(n, c)
+    dw1 = torch.zeros(hid, ld1, device=DEV)
+    dw2 = torch.zeros(c, ld2, device=DEV)
+    ops.se_excite_backward(d(s1), d(s2), d(stats), hw, w1d, w2t, e, h, q, dz2, dz1, off, dw1, dw2)
+    rel = lambda a, b: (a.cpu().double() - b).norm().item() / max(b.norm().item(), 1e-30)      # noqa: E731
+    assert rel(off, qr.grad / hw) <= 2e-5
+    assert rel(dw1[:, :c], W1.grad) <= 2e-5 and rel(dw2[:, :hid], W2.grad) <= 2e-5
+    assert not dw1[:, c:].any() and not dw2[:, hid:].any()           # the arena's pad columns stay zero
+
+
 def test_weight_transpose_batched_matches_per_tensor():
     """One-launch tiled transpose of several [cout][rs*cin] tensors out of a flat fp32 arena == iif_weight_transpose
     of each (pad columns zero), for fp32 and bf16 outputs, ragged channel counts included."""
