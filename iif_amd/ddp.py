@@ -25,8 +25,13 @@ class ArenaReducer(object):
       * ``"rs_ag"``: ``reduce_scatter_tensor`` into this rank's 1/world shard of the bucket followed by
         ``all_gather_into_tensor`` back into the arena (on the fully connected xGMI node the
         7 peer shards of either phase travel over the 7 links concurrently instead of around one ring).  Bucket
-        bounds are multiples of 16 elements (arena tensors are 64-byte aligned), so every bucket divides by any
-        world size up to 16; the sum arrives in a different association than the ring's, fp32-rounding apart.
+        bounds are multiples of 16 elements (arena tensors are 64-byte aligned), which divides by world sizes 2, 4, 8
+        and 16 only; for any other world size (3, 5, 6, 7 ...) the constructor keeps just the cuts whose offset is a
+        multiple of the world size (and refuses an arena whose length is not).  The sum arrives in a different
+        association than the ring's, fp32-rounding apart.
+      Both modes, the bf16 staging buckets and the SyncBatchNorm collectives have been rehearsed over gloo (CPU, and two
+      ranks on one GPU) and over RCCL with ONE rank only: no multi-GPU node has been available to the build, so the
+      stream-ordered ``nccl`` branch with world > 1 has not run on hardware yet.
     ``bucket_dtype=torch.bfloat16`` halves the bytes on the links by reducing a bf16 copy of each bucket (fp32
     accumulation is lost: it is refused until ``probe_bf16`` has measured, on real gradients, that the averaged
     gradient stays within a stated tolerance of the fp32 reduction)."""

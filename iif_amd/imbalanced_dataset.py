@@ -174,8 +174,10 @@ class LT_Dataset_Eval(Dataset):
 # ---------------------------------------------------------------------------------------------------
 # Host-side tensor transforms for the list datasets (torchvision is not in this image).  Same geometry and
 # statistics as the reference's pipelines (imbalanced_dataset.py:189-233: RandomResizedCrop(224) + horizontal
-# flip for training, Resize(256) + CenterCrop(224) for evaluation, per-dataset mean / std); colour jitter and
-# the auto-augment policies are CPU augmentation outside the measured path (SURVEY 2a presets.py) and not rebuilt.
+# flip for training, Resize(256) + CenterCrop(224) for evaluation, per-dataset mean / std).  NOT rebuilt (CPU
+# augmentation outside the measured path, SURVEY 2a presets.py): the ColorJitter(0.4, 0.4, 0.4, 0) of the reference's
+# default training transform (imbalanced_dataset.py:196-212) and the auto-augment policies — an accuracy-parity gap on
+# real data, not a throughput one; iif_amd.train warns when --auto-augment is given.
 LT_LISTS = {   # initialisers.py:83-100: (classes, train list, eval list) relative to the reference's working directory
     "imagenet_lt": (1000, "../../../datasets/ImageNet-LT/ImageNet_LT_train.txt", "../../../datasets/ImageNet-LT/ImageNet_LT_test.txt"),
     "inat18": (8142, "../../../datasets/train_val2018/iNaturalist18_train.txt", "../../../datasets/train_val2018/iNaturalist18_val.txt"),
@@ -189,7 +191,20 @@ class TensorTransform(object):
         self.mean = torch.tensor([0.466, 0.471, 0.380] if inat else [0.485, 0.456, 0.406]).view(3, 1, 1)
         self.std = torch.tensor([0.195, 0.194, 0.192] if inat else [0.229, 0.224, 0.225]).view(3, 1, 1)
         self.train, self.size = train, size
-        self.gen = torch.Generator().manual_seed(seed)
+        # The generator is created lazily, per PROCESS, from torch.initial_seed(): the DataLoader sets that to
+        # base_seed + worker_id in every worker and draws a new base_seed every epoch, so workers, epochs and DDP ranks get
+        # different crop / flip sequences (as torchvision transforms on the global RNG do in the reference).  A generator
+        # seeded here once would be forked identically into every worker of every epoch.
+        self.seed = int(seed)
+        self.gen, self._gen_key = None, None
+
+    def _generator(self):
+        import os
+        key = (os.getpid(), torch.initial_seed())
+        if self._gen_key != key:
+            self.gen = torch.Generator().manual_seed((torch.initial_seed() + self.seed) % (1 << 63))
+            self._gen_key = key
+        return self.gen
 
     def _to_chw(self, img):
         import numpy as np
@@ -208,7 +223,8 @@ class TensorTransform(object):
         _, h, w = t.shape
         s = self.size
         if self.train:                                   # RandomResizedCrop(scale 0.08-1, ratio 3/4-4/3), 10 tries, then flip
-            r = lambda: torch.rand((), generator=self.gen).item()      # noqa: E731
+            gen = self._generator()
+            r = lambda: torch.rand((), generator=gen).item()      # noqa: E731
             for _ in range(10):
                 area = h * w * (0.08 + 0.92 * r())
                 logr = math.log(3 / 4) + (math.log(4 / 3) - math.log(3 / 4)) * r()

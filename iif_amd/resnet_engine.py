@@ -764,7 +764,10 @@ class _Plan(object):
             self.wg_stream = torch.cuda.Stream(device=dev) if pr is None else torch.cuda.Stream(device=dev, priority=int(pr))
         self._wg_events = {}
         self.stem_wgrad_main = self.wg_stream is not None and not os.environ.get("IIF_STEM_WGRAD_SIDE")
-        self.wg_ws_stem = None
+        # own split-K workspace of the stem's weight gradient (it runs on the compute stream next to the side stream's):
+        # allocated here, never inside backward (a lazy allocation there would land inside a hipGraph capture)
+        self.wg_ws_stem = (torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+                           if (self.stem_wgrad_main and self.stem_s2d) else None)
         # blocks the weight-gradient stream may lag behind the compute stream: dx buffers rotate over `wg_lag` slots,
         # block-input gradients over wg_lag + 1, and block b waits for the weight gradients of the blocks >= b + wg_lag
         self.wg_lag = max(2, int(os.environ.get("IIF_WGRAD_LAG", "2")))
@@ -935,6 +938,9 @@ class _Plan(object):
                                   u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM, scratch=scratch,
                                   tickets=self.bn_tickets_side if side else self.bn_tickets)
             return x2
+        # the unfused statistics below use the compute stream's BN workspace: a shortcut convolution on the side stream
+        # must have taken the fused-statistics path above (bf16, DMA-addressable source), which needs none
+        assert not side, "side-stream convolution fell off the fused-statistics path"
         ops.conv_forward(u.src, u.w, k, k, st, pd, out=u.x, groups=u.groups, out_hw=(u.ho, u.wo), w_frag=u.wf)
         if sync is not None:
             self._sync_finalize(u, ops.bn_stats_sums(x2, self._sync_sums(cv.cout, side), self.bn_ws), m, sync)
@@ -1107,8 +1113,6 @@ class _Plan(object):
             if self.stem_wgrad_main:
                 # last kernel of backward: on the compute stream (own split-K workspace) it runs next to the weight
                 # gradients the side stream still owes, instead of queueing behind them while the compute stream idles
-                if self.wg_ws_stem is None:
-                    self.wg_ws_stem = torch.empty(64 << 20, dtype=torch.uint8, device=self.dev)
                 ops.conv_wgrad(u.src, dx4, 4, 4, 1, 2, ldw=u.dwp.shape[1], out=u.dwp, workspace=self.wg_ws_stem)
                 ops.stem_s2d_unpack_grad(u.dwp, cv.cout, cv.cin, cv.k, S2D_CPAD, cv._g2d)
                 return

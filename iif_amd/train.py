@@ -144,6 +144,10 @@ def main(args):
         raise SystemExit("iif_amd.train needs an MI355X: the native engine has no CPU path")
     device = torch.device(args.device)
     print(args)
+    if getattr(args, "auto_augment", None):
+        import warnings
+        warnings.warn("--auto-augment %r is accepted for command-line compatibility but NOT applied: the host-side tensor "
+                      "transforms rebuild crop / flip / resize only (iif_amd/imbalanced_dataset.py)" % (args.auto_augment,))
     dataset, num_classes, data_loader, data_loader_test, train_sampler = initialisers.get_data(args)
     print("Creating model")
     model = build_model(args, num_classes)
@@ -232,7 +236,8 @@ def get_args_parser(add_help=True):
     p.add_argument("--reduction", default="mean", type=str)
     p.add_argument("--start-epoch", default=0, type=int, metavar="N")
     p.add_argument("--cache-dataset", dest="cache_dataset", action="store_true")
-    p.add_argument("--sync-bn", dest="sync_bn", action="store_true")
+    p.add_argument("--sync-bn", dest="sync_bn", action="store_true",
+                   help="cross-replica BN statistics (reference train.py:190); rehearsed over gloo and one RCCL rank only")
     p.add_argument("--test-only", dest="test_only", action="store_true")
     p.add_argument("--pretrained", dest="pretrained", default=None, type=str)
     p.add_argument("--deffered", action="store_true")

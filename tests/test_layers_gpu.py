@@ -397,6 +397,52 @@ def test_bn_reduce_and_finalize_in_one_launch_is_bit_identical(nt, c):
             assert torch.equal(a_, b_)
 
 
+def test_ticketed_single_launch_reductions_under_memory_load():
+    """The fence-free ticket protocol (bn.hip bn_reduce_finalize_kernel, iif_head.hip finish_with_ticket: partials published
+    with agent-scope atomic exchanges, s_waitcnt, relaxed ticket; the last block reads them with agent-scope atomic loads)
+    is only as good as the hardware property it rests on, and the bit-identity tests above run on an idle GPU.  Here the
+    single-launch forms run 60 times each while a second stream keeps every XCD's L2 and the HBM busy with large copies
+    and read-modify-write passes (uneven load, dirty lines in flight): every result must equal the two-launch path bit for
+    bit and the ticket words must be back at zero."""
+    from iif_amd import custom, ops
+    g = torch.Generator().manual_seed(5)
+    nt, c = 3136, 256                                      # the 28x28 / 56x56 regime: > 512 partial rows -> two-stage reduce
+    m = nt * 128
+    partial = torch.randn(nt, 2, c, generator=g).abs_().mul_(100.0)
+    partial[:, 1] += partial[:, 0] ** 2 / 128
+    partial = partial.to(DEV)
+    gamma, beta = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV)
+    tickets = torch.zeros(64, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(128 * c, device=DEV)
+
+    def finalize(tk):
+        stats = torch.full((4, c), float("nan"), device=DEV)
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        ops.bn_finalize_stats(partial.view(-1), nt, m, c, gamma, beta, rm, rv, stats, scratch=scratch, tickets=tk)
+        return stats
+    ref_stats = finalize(None)
+    B, C = 4096, 1000
+    x = torch.randn(B, C, generator=g).to(DEV)
+    y = torch.randint(0, C, (B,), generator=g).to(DEV)
+    tab = (torch.rand(1, C, generator=g) * 4 + 0.5).to(DEV)
+    loss_ref, _, _ = custom._launch_ce(x, tab, y, None, 1.0, None, None, -100, 1.0 / B, True)
+    loss_ref = loss_ref.clone()
+    torch.cuda.synchronize()
+    noise = torch.cuda.Stream()
+    big_a = torch.empty(96 << 20, dtype=torch.float32, device=DEV)          # 384 MB each: beyond the 256 MiB Infinity Cache
+    big_b = torch.empty(96 << 20, dtype=torch.float32, device=DEV)
+    with torch.cuda.stream(noise):
+        for _ in range(40):
+            big_b.copy_(big_a); big_a.add_(1.0); big_a[: 1 << 20].mul_(0.5)
+    for it in range(60):
+        st = finalize(tickets)
+        loss, _, _ = custom._launch_ce(x, tab, y, None, 1.0, None, None, -100, 1.0 / B, True)
+        assert torch.equal(st, ref_stats), it
+        assert torch.equal(loss, loss_ref), it
+    torch.cuda.synchronize()
+    assert tickets.abs().sum().item() == 0
+
+
 @pytest.mark.parametrize("shape", [(4, 64, 14, 14), (2, 2048, 2, 2), (6, 24, 5, 3)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("masked", ["bits", "ymask", "plain", "gmasked"])
