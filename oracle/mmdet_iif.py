@@ -83,13 +83,22 @@ def normed_linear(x, weight, bias=None, temperature=20.0, power=1.0, eps=1e-6, i
     return F.linear(x_, weight_, bias)
 
 
-def normed_conv2d_1x1(x, weight, bias=None, temperature=20.0, power=1.0, eps=1e-6):
-    """normed_predictor.py: NormedConv2d.forward :104-124 (norm over the channel dimension of every pixel
-    and of every filter), for the 1x1 predictor the mask head builds."""
-    weight_ = weight / (weight.norm(dim=1, keepdim=True).pow(power) + eps)
+def normed_conv2d(x, weight, bias=None, temperature=20.0, power=1.0, eps=1e-6, norm_over_kernel=False, stride=1, padding=0):
+    """normed_predictor.py: NormedConv2d.forward :104-124.  The input is normalised over the channel dimension of every
+    pixel; the filter over its channel dimension per tap (:105-108), or over the whole filter with norm_over_kernel
+    (:109-113)."""
+    if not norm_over_kernel:
+        weight_ = weight / (weight.norm(dim=1, keepdim=True).pow(power) + eps)
+    else:
+        weight_ = weight / (weight.view(weight.size(0), -1).norm(dim=1, keepdim=True).pow(power)[..., None, None] + eps)
     x_ = x / (x.norm(dim=1, keepdim=True).pow(power) + eps)
     x_ = x_ * temperature
-    return F.conv2d(x_, weight_, bias)
+    return F.conv2d(x_, weight_, bias, stride, padding)
+
+
+def normed_conv2d_1x1(x, weight, bias=None, temperature=20.0, power=1.0, eps=1e-6):
+    """The 1x1 predictor the mask head builds (both normalisations coincide)."""
+    return normed_conv2d(x, weight, bias, temperature, power, eps)
 
 
 def mask_cross_entropy(pred, target, label):

@@ -313,12 +313,13 @@ def g12_normed():
         yo.backward(gy)
         close(yo, y, 1e-6, name + " out"); close(xo.grad, xr.grad, 1e-6, name + " dx")
         close(wo.grad, m.weight.grad, 1e-6, name + " dw"); close(bo.grad, m.bias.grad, 1e-6, name + " db")
-    for name, n, cin, cout, hw, nok in K.NORMED_CONV_CASES:
-        m = NP.NormedConv2d(cin, cout, 1, tempearture=20, norm_over_kernel=nok)
+    for name, n, cin, cout, hw, nok, ks, stride, pad in K.NORMED_CONV_CASES:
+        m = NP.NormedConv2d(cin, cout, ks, stride=stride, padding=pad, tempearture=20, norm_over_kernel=nok)
         x = torch.randn(n, cin, hw, hw, generator=g)
-        gy = torch.randn(n, cout, hw, hw, generator=g)
+        ho = (hw + 2 * pad - ks) // stride + 1
+        gy = torch.randn(n, cout, ho, ho, generator=g)
         with torch.no_grad():
-            m.weight.copy_(torch.randn(cout, cin, 1, 1, generator=g) * 0.05); m.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+            m.weight.copy_(torch.randn(cout, cin, ks, ks, generator=g) * 0.05); m.bias.copy_(torch.randn(cout, generator=g) * 0.1)
         xr = x.clone().requires_grad_(True)
         y = m(xr)
         y.backward(gy)
@@ -327,7 +328,7 @@ def g12_normed():
             out["%s_%s" % (name, k)] = v.numpy()
         xo = x.clone().requires_grad_(True)
         wo = m.weight.detach().clone().requires_grad_(True); bo = m.bias.detach().clone().requires_grad_(True)
-        yo = M.normed_conv2d_1x1(xo, wo, bo, 20, 1.0, 1e-6)
+        yo = M.normed_conv2d(xo, wo, bo, 20, 1.0, 1e-6, nok, stride, pad)
         yo.backward(gy)
         close(yo, y, 1e-6, name + " out"); close(xo.grad, xr.grad, 1e-6, name + " dx"); close(wo.grad, m.weight.grad, 1e-6, name + " dw")
     return out

@@ -60,7 +60,9 @@ def boosted_score(score, label, seed):
 
 NORMED_LINEAR_CASES = (("lin81", 16, 64, 81, 20, 1.0, None), ("lin_pow2", 12, 48, 30, 8, 2.0, None),
                        ("iif1204", 32, 64, 1204, 8, 1.0, "base2_obj"), ("iif81", 9, 32, 81, 20, 1.0, "raw"))
-NORMED_CONV_CASES = (("conv80", 2, 256, 80, 7, False), ("conv_nok", 3, 32, 12, 7, True))
+# name, n, cin, cout, hw, norm_over_kernel, kernel, stride, padding (round 3: kernels beyond the 1x1 predictor)
+NORMED_CONV_CASES = (("conv80", 2, 256, 80, 7, False, 1, 1, 0), ("conv_nok", 3, 32, 12, 7, True, 1, 1, 0),
+                     ("conv3x3", 2, 32, 20, 9, False, 3, 1, 1), ("conv3x3_nok_s2", 2, 16, 12, 8, True, 3, 2, 1))
 MASK_CASES = (("lvis", 6, 1203, 14, 3.0, 31), ("coco", 16, 80, 28, 1.0, 32), ("doc", 3, 11, 2, 1000.0, 33))
 
 

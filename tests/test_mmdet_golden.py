@@ -205,13 +205,14 @@ def test_g12_normed_linear(golden, backend, case):
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", K.NORMED_CONV_CASES, ids=[c[0] for c in K.NORMED_CONV_CASES])
 def test_g12_normed_conv2d(golden, backend, case):
-    """normed_predictor.py:104-124 for the 1x1 predictor (norm_over_kernel coincides for a 1x1 kernel)."""
+    """normed_predictor.py:104-124: the 1x1 predictor (norm_over_kernel coincides for a 1x1 kernel) and, since round 3,
+    k x k kernels with stride / padding and both filter normalisations."""
     g = golden("g12_mmdet_normed")
-    name, n, cin, cout, hw, nok = case
+    name, n, cin, cout, hw, nok, ks, stride, pad = case
     x, w, b, gy = (torch.from_numpy(g["%s_%s" % (name, k)]) for k in ("x", "w", "b", "gy"))
     if backend == "hip":
         from iif_amd.mmdet_normed_predictor import NormedConv2d
-        m = NormedConv2d(cin, cout, 1, tempearture=20, norm_over_kernel=nok).to(DEV)
+        m = NormedConv2d(cin, cout, ks, stride=stride, padding=pad, tempearture=20, norm_over_kernel=nok).to(DEV)
         with torch.no_grad():
             m.weight.copy_(w); m.bias.copy_(b)
         xr = x.to(DEV).requires_grad_(True)
@@ -220,7 +221,7 @@ def test_g12_normed_conv2d(golden, backend, case):
         got = dict(out=y, dx=xr.grad, dw=m.weight.grad, db=m.bias.grad)
     else:
         xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
-        y = M.normed_conv2d_1x1(xr, wr, br, 20, 1.0, 1e-6)
+        y = M.normed_conv2d(xr, wr, br, 20, 1.0, 1e-6, nok, stride, pad)
         y.backward(gy)
         got = dict(out=y, dx=xr.grad, dw=wr.grad, db=br.grad)
     for k, v in got.items():
