@@ -435,8 +435,13 @@ typedef __attribute__((address_space(3))) void lds_void;
 // so the tap / channel-chunk displacement is a wave-uniform SCALAR (the buffer instruction's soffset) and
 // the per-lane voffset (pixel base + this lane's chunk) never changes: address generation costs ~3 VALU
 // instructions per row per step (a tap-validity bit test), instead of the general per-piece arithmetic.
-template <typename T, int BN, bool OUTF32, bool UTAP, int NW = 4, bool SHORTK = false>
-__device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned src_bytes, unsigned wgt_bytes) {
+// tap list of a launch: the arrays of ConvArgs, or (several parity classes in one launch) those of the block's class
+struct TapList { const signed char* dy; const signed char* dx; const unsigned char* w; };
+
+// (TAG: a second kernel that needs the same body instantiates it under another tag — the host pass of hipcc / ROCm 7.2 refuses
+// to substitute one specialisation of this template, with its static __shared__ array, into two different __global__ functions)
+template <typename T, int BN, bool OUTF32, bool UTAP, int NW = 4, bool SHORTK = false, int TAG = 0>
+__device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned src_bytes, unsigned wgt_bytes, TapList tl, int bofs = 0) {
     // NW waves, each 64 pixels x BN/2 channels: 128 x BN (4 waves) or 256 x 128 (8 waves).  The larger tile moves
     // 12 instead of 16 KB through the vector L1 per MFLOP: the stamps (scripts/conv_stamps.py) show the 4-wave
     // kernel spending half of every K step issuing its LDS-DMA, i.e. bound by the 64 B/clk L1 path, not by MFMA.
@@ -463,7 +468,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.x;
+    const int b = (int)blockIdx.x - bofs;
     const int xcd = b & 7, j = b >> 3;
     const int mt = (j / a.ntiles) * 8 + xcd, nt = j % a.ntiles;
     if (mt >= a.mtiles) return;
@@ -489,7 +494,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
         // most negative tap displacement, in pixels
         int dmin = 0;
         for (int t = 0; t < a.ntaps; ++t) {
-            const int dd = a.tap_dy[t] * a.Ws + a.tap_dx[t];
+            const int dd = tl.dy[t] * a.Ws + tl.dx[t];
             dmin = dd < dmin ? dd : dmin;
         }
         shiftP = -dmin * a.spitch * (int)sizeof(T);
@@ -504,7 +509,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
             vbase[i] = ((unsigned)(n * a.Hs * a.Ws + y0 * a.Ws + x0) * (unsigned)a.spitch + (unsigned)(chunk * PE)) * (unsigned)sizeof(T) + gsrc;
             unsigned mask = 0;
             for (int t = 0; t < a.ntaps; ++t) {
-                const int ys = y0 + a.tap_dy[t], xs = x0 + a.tap_dx[t];
+                const int ys = y0 + tl.dy[t], xs = x0 + tl.dx[t];
                 const bool ok = valid && (unsigned)ys < (unsigned)a.Hs && (unsigned)xs < (unsigned)a.Ws;
                 mask |= (ok ? 1u : 0u) << t;
             }
@@ -548,8 +553,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     int uc = 0, ut = 0;
     unsigned usoff = 0, uwoff = 0;
     if constexpr (UTAP) {
-        usoff = (unsigned)((a.tap_dy[0] * a.Ws + a.tap_dx[0]) * a.spitch * (int)sizeof(T) + shiftP);
-        uwoff = (unsigned)(a.tap_w[0] * a.Cs) * (unsigned)sizeof(T);
+        usoff = (unsigned)((tl.dy[0] * a.Ws + tl.dx[0]) * a.spitch * (int)sizeof(T) + shiftP);
+        uwoff = (unsigned)(tl.w[0] * a.Cs) * (unsigned)sizeof(T);
     }
 
     auto issue = [&](auto stage_c) {
@@ -599,8 +604,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
             if (uc >= a.Cs) {
                 uc = 0; ++ut;
                 const int tt = ut < a.ntaps ? ut : 0;
-                usoff = (unsigned)((a.tap_dy[tt] * a.Ws + a.tap_dx[tt]) * a.spitch * (int)sizeof(T) + shiftP);
-                uwoff = (unsigned)(a.tap_w[tt] * a.Cs) * (unsigned)sizeof(T);
+                usoff = (unsigned)((tl.dy[tt] * a.Ws + tl.dx[tt]) * a.spitch * (int)sizeof(T) + shiftP);
+                uwoff = (unsigned)(tl.w[tt] * a.Cs) * (unsigned)sizeof(T);
             }
         } else {
             e += KE;
@@ -730,18 +735,46 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
 // __global__ template whose body differs only by such a flag)
 template <typename T, int BN, bool OUTF32>
 __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
-    conv_igemm_dma_body<T, BN, OUTF32, false>(a, src_bytes, wgt_bytes);
+    conv_igemm_dma_body<T, BN, OUTF32, false>(a, src_bytes, wgt_bytes, TapList{a.tap_dy, a.tap_dx, a.tap_w});
 }
 template <typename T, int BN, bool OUTF32>
 __global__ void __launch_bounds__(256) conv_igemm_dma_utap_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
-    conv_igemm_dma_body<T, BN, OUTF32, true>(a, src_bytes, wgt_bytes);
+    conv_igemm_dma_body<T, BN, OUTF32, true>(a, src_bytes, wgt_bytes, TapList{a.tap_dy, a.tap_dx, a.tap_w});
 }
 // K <= 64 (two K steps): 4 blocks per CU (see SHORTK)
 template <int BN>
 __global__ void __launch_bounds__(256, 4) conv_igemm_dma_utap_k64_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
-    conv_igemm_dma_body<unsigned short, BN, false, true, 4, true>(a, src_bytes, wgt_bytes);
+    conv_igemm_dma_body<unsigned short, BN, false, true, 4, true>(a, src_bytes, wgt_bytes, TapList{a.tap_dy, a.tap_dx, a.tap_w});
 }
-
+// The parity classes of a stride-2 data gradient in ONE launch.  As four launches each class offered 200-400 tiles of one or
+// two K steps to 1 024 block slots (the 28x28 -> 56x56 3x3 gradient: 0.45 ms in the step for 0.46 GB = 1.0 TB/s); together
+// they fill the chip.  A block finds its class by its index, takes that class's grid, tap list, scatter offsets and partial
+// rows, and runs the ordinary body.
+struct ConvClass {
+    int Hd, Wd, M, mtiles, doy, dox, ntaps, bn_row0, bstart;
+    signed char tap_dy[16], tap_dx[16];
+    unsigned char tap_w[16];
+};
+struct ConvArgsMC { ConvArgs a; ConvClass cls[4]; int ncls; };
+template <int BN>
+__device__ __forceinline__ void conv_mc_body(const ConvArgsMC& p, unsigned src_bytes, unsigned wgt_bytes) {
+    int k = 0;
+    for (int i = 1; i < p.ncls; ++i)
+        if ((int)blockIdx.x >= p.cls[i].bstart) k = i;
+    const ConvClass& c = p.cls[k];
+    ConvArgs a = p.a;
+    a.Hd = c.Hd; a.Wd = c.Wd; a.M = c.M; a.mtiles = c.mtiles; a.doy = c.doy; a.dox = c.dox; a.ntaps = c.ntaps; a.bn_row0 = c.bn_row0;
+    TapList tl;
+    tl.dy = c.tap_dy; tl.dx = c.tap_dx; tl.w = c.tap_w;
+    conv_igemm_dma_body<unsigned short, BN, false, true, 4, true, 1>(a, src_bytes, wgt_bytes, tl, c.bstart);
+}
+// plain kernel names around the body template (see the note on conv_igemm_dma_kernel: host stubs)
+__global__ void __launch_bounds__(256, 4) conv_igemm_dma_utap_k64_mc128_kernel(ConvArgsMC p, unsigned src_bytes, unsigned wgt_bytes) {
+    conv_mc_body<128>(p, src_bytes, wgt_bytes);
+}
+__global__ void __launch_bounds__(256, 4) conv_igemm_dma_utap_k64_mc64_kernel(ConvArgsMC p, unsigned src_bytes, unsigned wgt_bytes) {
+    conv_mc_body<64>(p, src_bytes, wgt_bytes);
+}
 
 // ---------------------------------------------------------------- 3x3 / stride 1 / pad 1 with an LDS halo window
 // The tap-by-tap kernel above pulls every source pixel through the vector L1 nine times (once per tap); the stamps
@@ -1199,7 +1232,7 @@ __global__ void __launch_bounds__(256) pack_fragments_kernel(const unsigned shor
 
 template <typename T, bool OUTF32>
 __global__ void __launch_bounds__(512) conv_igemm_dma_utap256_kernel(ConvArgs a, unsigned src_bytes, unsigned wgt_bytes) {
-    conv_igemm_dma_body<T, 128, OUTF32, true, 8>(a, src_bytes, wgt_bytes);
+    conv_igemm_dma_body<T, 128, OUTF32, true, 8>(a, src_bytes, wgt_bytes, TapList{a.tap_dy, a.tap_dx, a.tap_w});
 }
 
 // ---------------------------------------------------------------- streaming 1x1 GEMM, weights resident in LDS
@@ -1523,7 +1556,7 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
 // Experiment / test switches of this file, read from the environment ONCE (they used to cost several getenv per launch on
 // the hot host path); iif_conv_reload_env() re-reads them (tests and A/B scripts flip them between calls).
 struct ConvSwitches {
-    bool no_stream, force_stream, stream_fwd_only, stream_r2, no_shortk, regstage, no_v2, no_halo, force_halo, v2_wide;
+    bool no_stream, force_stream, stream_fwd_only, stream_r2, no_shortk, regstage, no_v2, no_halo, force_halo, v2_wide, no_merge_classes;
     int force_bn64_k, twostage_k;
     static ConvSwitches read() {
         ConvSwitches c;
@@ -1541,6 +1574,7 @@ struct ConvSwitches {
         c.no_v2 = getenv("IIF_CONV_NO_V2") != nullptr;
         c.no_halo = getenv("IIF_CONV_NO_HALO") != nullptr;
         c.v2_wide = getenv("IIF_CONV_V2_WIDE") != nullptr;
+        c.no_merge_classes = getenv("IIF_CONV_NO_MERGE_CLASSES") != nullptr;
         c.force_halo = getenv("IIF_CONV_HALO_FORCE") != nullptr;
         const char* f64 = getenv("IIF_CONV_FORCE_BN64");
         c.force_bn64_k = f64 ? atoi(f64) : -1;
@@ -1777,6 +1811,8 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
     }
     // stride-2 data gradient: 4 parity classes of the destination grid
     const int H = a.Hd, W = a.Wd;
+    ConvArgs cls[4];
+    int ncls = 0;
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             ConvArgs c = a;
@@ -1798,10 +1834,49 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
             // a class without taps receives no contribution (dst += 0): skipped, unless the backward sums of the
             // upstream unit ride on this launch (every pixel of dst has to be visited once)
             if (c.ntaps == 0 && c.res == c.dst && !c.bw_x) continue;
-            if (c.rows_out) c.bn_row0 = *c.rows_out;
-            const int rc = launch_one<T, OUTF32>(c, true, src_bytes, wgt_bytes, st);
-            if (rc != IIF_OK) return rc;
+            cls[ncls++] = c;
         }
+    // all classes in one launch where each of them would take the 4-blocks-per-CU tile kernel
+    if constexpr (sizeof(T) == 2 && !OUTF32) {
+        const bool shortk = a.R * a.S * a.Cs <= g_sw.twostage_k && (a.Cd & 7) == 0 && !a.bias && !g_sw.no_shortk && !g_sw.no_merge_classes &&
+                            a.groups == 1 && ncls > 1 && !g_sw.regstage;
+        if (shortk) {
+            ConvArgsMC p{};
+            p.a = a;
+            p.a.scatter = 1; p.a.ds_shift = 1; p.a.Hfull = H; p.a.Wfull = W; p.a.in_shift = 0;
+            const bool narrow = a.Cd <= 64;
+            const int bn = narrow ? 64 : 128;
+            p.a.ntiles = (a.Cd + bn - 1) / bn;
+            p.ncls = ncls;
+            int64_t bstart = 0;
+            int row0 = a.rows_out ? *a.rows_out : a.bn_row0;
+            for (int i = 0; i < ncls; ++i) {
+                ConvClass& k = p.cls[i];
+                k.Hd = cls[i].Hd; k.Wd = cls[i].Wd; k.M = cls[i].M; k.mtiles = (cls[i].M + 127) / 128;
+                k.doy = cls[i].doy; k.dox = cls[i].dox; k.ntaps = cls[i].ntaps; k.bn_row0 = row0; k.bstart = (int)bstart;
+                for (int t = 0; t < 16; ++t) { k.tap_dy[t] = cls[i].tap_dy[t]; k.tap_dx[t] = cls[i].tap_dx[t]; k.tap_w[t] = cls[i].tap_w[t]; }
+                bstart += (int64_t)((k.mtiles + 7) / 8) * 8 * p.a.ntiles;
+                row0 += k.mtiles;
+            }
+            if (bstart <= 0x7fffffff) {
+                if (a.bn_partial) {
+                    if ((long long)row0 * 2 * a.dpitch > a.bn_cap) return IIF_EINVAL;
+                    if (a.rows_out) *a.rows_out = row0;
+                }
+                const dim3 grid((unsigned)bstart), blk(256);
+                if (narrow) hipLaunchKernelGGL(conv_igemm_dma_utap_k64_mc64_kernel, grid, blk, 0, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
+                else hipLaunchKernelGGL(conv_igemm_dma_utap_k64_mc128_kernel, grid, blk, 0, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
+                IIF_LAUNCH_CHECK();
+                return IIF_OK;
+            }
+        }
+    }
+    for (int i = 0; i < ncls; ++i) {
+        ConvArgs& c = cls[i];
+        if (c.rows_out) c.bn_row0 = *c.rows_out;
+        const int rc = launch_one<T, OUTF32>(c, true, src_bytes, wgt_bytes, st);
+        if (rc != IIF_OK) return rc;
+    }
     return IIF_OK;
 }
 
