@@ -80,5 +80,10 @@ def test_normed_conv2d_1x1():
     ref.backward(gy)
     assert rel(out, ref) <= 1e-4 and rel(xd.grad, xr.grad) <= 1e-4
     assert rel(m.weight.grad, w.grad) <= 1e-4 and rel(m.bias.grad, b.grad) <= 1e-4
+    # k x k kernels are native since round 3 (test_g12_normed_conv2d pins them); what the MFMA path cannot take still raises
+    NormedConv2d(8, 8, 3, padding=1)
+    for bad in (dict(groups=2), dict(dilation=2), dict(stride=3)):
+        with pytest.raises(NotImplementedError):
+            NormedConv2d(8, 8, 3, **bad)
     with pytest.raises(NotImplementedError):
-        NormedConv2d(8, 8, 3)
+        NormedConv2d(6, 8, 3)                      # input channels not in fours
