@@ -1085,12 +1085,19 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
     static_assert(WD == 9 || WD == 3, "ring of nine taps, or two taps ahead");
     u32x4 wb[WD][CI];
 
+#ifdef IIF_CONV_STAMPS
+    unsigned long long v_begin, v_a, v_b, v_pro = 0, v_loop = 0, v_bound = 0, v_epi = 0, v_tiles = 0;
+    IIF_STAMP(v_begin);
+#endif
     int tile = (int)blockIdx.x;
     if (!set_tile(tile)) return;
     issue_halo(0);
 #pragma unroll
     for (int t = 0; t < (WD == 9 ? 9 : 2); ++t) wload(t, 0, wb[t]);
     for (;;) {
+#ifdef IIF_CONV_STAMPS
+        IIF_STAMP(v_a);
+#endif
         f32x4 acc[CI][PJ];
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci)
@@ -1098,7 +1105,13 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
             for (int pj = 0; pj < PJ; ++pj) acc[ci][pj] = f32x4{0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // halo window of chunk 0 (and the previous tile's stores)
         __builtin_amdgcn_s_barrier();
+#ifdef IIF_CONV_STAMPS
+        IIF_STAMP(v_b); v_pro += v_b - v_a; ++v_tiles;
+#endif
         for (int c = 0; c < nchunks; ++c) {
+#ifdef IIF_CONV_STAMPS
+            IIF_STAMP(v_a);
+#endif
             // buffer (c + 1) & 1 was last read in chunk c - 1, which every wave has left (barrier at its end)
             if (c + 1 < nchunks) issue_halo(c + 1);
             const unsigned fcsb = fcs + smem_base + (unsigned)((c & 1) * ABUF);
@@ -1155,6 +1168,9 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
                     for (int q = 0; q < 4; ++q) ad[q] = adn[q];
                 }
             }
+#ifdef IIF_CONV_STAMPS
+            IIF_STAMP(v_b); v_loop += v_b - v_a;
+#endif
             // chunk boundary: the last tap's slot, then: this wave's halo pieces of chunk c + 1 have landed (everything but the
             // 9 CI loads issued after them = the next chunk's weights), its reads of buffer c & 1 are done; then all waves
             if (c + 1 < nchunks) {
@@ -1163,7 +1179,13 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
+#ifdef IIF_CONV_STAMPS
+            IIF_STAMP(v_a); v_bound += v_a - v_b;
+#endif
         }
+#ifdef IIF_CONV_STAMPS
+        IIF_STAMP(v_a);
+#endif
         // ---- epilogue: park the tile in LDS, then the shared 16-byte drain
         const int dm0 = m0, dn0 = n0, dmt = mt;
         __syncthreads();                                // every wave is done reading the last halo buffer (and the stage of the previous tile)
@@ -1190,6 +1212,13 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
         }
         __syncthreads();
         staged_drain<BN, BM, 256>(a, stage, dm0, dn0, dmt, 0);
+#ifdef IIF_CONV_STAMPS
+        IIF_STAMP(v_b); v_epi += v_b - v_a;
+        if (!more_tiles && g_stamps && blockIdx.x < 512 && lane == 0) {
+            unsigned long long* o = g_stamps + ((int64_t)blockIdx.x * 4 + wave) * 8;
+            o[0] = v_pro; o[1] = v_loop; o[2] = v_bound; o[3] = v_epi; o[4] = v_tiles; o[5] = v_b - v_begin; o[6] = (unsigned long long)(9 * nchunks); o[7] = v_begin;
+        }
+#endif
         if (!more_tiles) return;
     }
 }
