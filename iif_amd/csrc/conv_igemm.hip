@@ -1585,7 +1585,7 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
 // Experiment / test switches of this file, read from the environment ONCE (they used to cost several getenv per launch on
 // the hot host path); iif_conv_reload_env() re-reads them (tests and A/B scripts flip them between calls).
 struct ConvSwitches {
-    bool no_stream, force_stream, stream_fwd_only, stream_r2, no_shortk, regstage, no_v2, no_halo, force_halo, v2_wide, no_merge_classes;
+    bool no_stream, force_stream, stream_fwd_only, stream_r2, no_shortk, regstage, no_v2, no_halo, force_halo, v2_wide, v2_force, no_merge_classes;
     int force_bn64_k, twostage_k;
     static ConvSwitches read() {
         ConvSwitches c;
@@ -1604,6 +1604,7 @@ struct ConvSwitches {
         c.no_halo = getenv("IIF_CONV_NO_HALO") != nullptr;
         c.v2_wide = getenv("IIF_CONV_V2_WIDE") != nullptr;
         c.no_merge_classes = getenv("IIF_CONV_NO_MERGE_CLASSES") != nullptr;
+        c.v2_force = getenv("IIF_CONV_V2_FORCE") != nullptr;
         c.force_halo = getenv("IIF_CONV_HALO_FORCE") != nullptr;
         const char* f64 = getenv("IIF_CONV_FORCE_BN64");
         c.force_bn64_k = f64 ? atoi(f64) : -1;
@@ -1678,8 +1679,10 @@ inline bool v2_geometry_ok(int N, int H, int W, int Cs, int Cd) {
     // data gradient; the persistent 128-channel variant is level with or behind the halo kernel (28x28 0.078 -> 0.098,
     // 14x14 0.067 -> 0.076, 7x7 0.057 -> 0.066 ms) and stays opt-in (IIF_CONV_V2_WIDE) until its loop is as good as its plan.
     if ((Cd % 128) == 0 && !g_sw.v2_wide) return false;
-    if ((int64_t)N * H * W >= (1 << 22)) return false;                    // fdiv's exact range
+    // 256-pixel tiles: a small layer (CIFAR-size images) would leave most CUs without a block (IIF_CONV_V2_FORCE: tests)
     const int HW = H * W;
+    if (!g_sw.v2_force && ((int64_t)N * HW + 255) / 256 * (Cd / 64) < 192) return false;
+    if ((int64_t)N * H * W >= (1 << 22)) return false;                    // fdiv's exact range
     const int span = (256 + W - 1) / W + 1 + 2 * (256 / HW + 1);            // virtual rows a 256-pixel tile can touch
     return (span + 2) * (W + 2) <= 640;
 }

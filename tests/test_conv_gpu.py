@@ -355,7 +355,7 @@ def test_conv3x3_fragment_kernel(case, conv_env):
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()                                    # noqa: E731
     krsc = lambda w_: w_.permute(0, 2, 3, 1).reshape(w_.shape[0], -1).contiguous()          # noqa: E731
     xd, wd = nhwc(x).to(DEV), krsc(wt).to(DEV)
-    conv_env(IIF_CONV_V2_WIDE="1")                        # the 128-channel variant is opt-in (see v2_geometry_ok)
+    conv_env(IIF_CONV_V2_WIDE="1", IIF_CONV_V2_FORCE="1")   # the 128-channel variant is opt-in, small grids are refused (v2_geometry_ok)
     assert ops.conv3x3_frag_ok(n, h, w, cin, cout, dt) and ops.conv3x3_frag_ok(n, h, w, cout, cin, dt)
     wf = _pack_frag(wd, cout, 9, cin)
     # the layout: fragment (row tile, tap, chunk), lane (row & 15, 8 channels of (lane >> 4))
@@ -375,7 +375,7 @@ def test_conv3x3_fragment_kernel(case, conv_env):
     wtt = krsc(wt.permute(1, 0, 2, 3).contiguous()).to(DEV)
     wtf = _pack_frag(wtt, cin, 9, cout)
     for mode in ("v2", "old"):
-        conv_env(IIF_CONV_NO_V2=None if mode == "v2" else "1", IIF_CONV_HALO_FORCE="1", IIF_CONV_V2_WIDE="1")
+        conv_env(IIF_CONV_NO_V2=None if mode == "v2" else "1", IIF_CONV_HALO_FORCE="1", IIF_CONV_V2_WIDE="1", IIF_CONV_V2_FORCE="1")
         out = torch.full((n, h, w, cout), float("nan"), dtype=dt, device=DEV)
         partial = torch.full((((m + 127) // 128) * 2 * cout,), float("nan"), device=DEV)
         nt = ops.conv_forward_bnstats(xd, wd, 3, 3, 1, 1, out, partial, w_frag=wf)
