@@ -48,6 +48,13 @@ struct ConvArgs {
     // ReLU), bw_stats its (mean at [c], invstd at [Cd + c]).  bn_partial then receives per tile
     // (sum g, sum g*xhat) with g = dst * [bit] instead of the forward (sum, sum of squares).
     const unsigned char* bw_x; const unsigned char* bw_bits; const float* bw_stats;
+    // mask_store (round 3, the algebraic BN backward of the expanding 1x1 layers): dst is stored ALREADY gated by bw_bits
+    // (every later reader gates it by those bits anyway) and bn_partial receives (sum dst, 0) per tile; bw_x is not read.
+    int mask_store;
+    // second source of a 1x1 launch: K continues over src2's Cs2 channels (weights rows hold Cs + Cs2 columns):
+    // dst = [src | src2] * wgt^T.  sbias (nullable): per-output-channel fp32 added in the staged epilogue.
+    const unsigned char* src2; int Cs2;
+    const float* sbias;
     int bn_row0;           // first partial row of this launch (launches that share one partial buffer)
     int* rows_out;         // host only: receives bn_row0 + tiles of the launch (the partial rows written so far)
     long long bn_cap;      // host only: floats available behind bn_partial
@@ -346,6 +353,13 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
 #pragma unroll
         for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[n + q]; bistd[q] = a.bw_stats[a.Cd + n + q]; }
     }
+    float sb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sb[q] = 0.f;
+    if (a.sbias && n < a.Cd) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sb[q] = a.sbias[n + q];
+    }
     if (n < a.Cd) {
         // (issuing the residual / upstream-x loads of 4 rows ahead of the stores was measured 2-3 % slower end to end)
 #pragma unroll 4
@@ -354,6 +368,11 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
             if (m >= a.M) break;
             u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PITCH + chunk * 16);
             const int64_t o = (dst_row(a, m) * a.dpitch + goff + n) * 2;
+            if (a.sbias) {                          // block-uniform
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    v[q] = pack_bf16x2(bf16_bits_to_f32(v[q] & 0xffffu) + sb[2 * q], __uint_as_float(v[q] & 0xffff0000u) + sb[2 * q + 1]);
+            }
             if (a.res) {
 #ifndef IIF_NO_NT_EPILOGUE_LOADS   // the residual's last use
                 const u32x4 rr = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res + o));
@@ -368,12 +387,23 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
                     v[q] = pack_bf16x2(lo, hi);
                 }
             }
+            if (a.mask_store) {                     // block-uniform: the stored gradient is gated by the upstream ReLU bits
+                const unsigned mb = a.bw_bits[o >> 4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned lo = (mb >> (2 * q)) & 1u ? (v[q] & 0xffffu) : 0u;
+                    const unsigned hi = (mb >> (2 * q + 1)) & 1u ? (v[q] & 0xffff0000u) : 0u;
+                    v[q] = lo | hi;
+                    bs[2 * q] += bf16_bits_to_f32(lo); bs[2 * q + 1] += __uint_as_float(hi);
+                }
+            }
 #ifndef IIF_NO_NT_CONV_STORE     // the tile is next read by another XCD (BN apply): streaming it out keeps the pixel operand's lines in L2 (-0.7 % on the step)
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + o));
 #else
             *reinterpret_cast<u32x4*>(a.dst + o) = v;
 #endif
-            if (a.bw_x) {
+            if (a.mask_store) {
+            } else if (a.bw_x) {
 #ifndef IIF_NO_NT_EPILOGUE_LOADS   // streamed once by this kernel (next reader: the BN backward, from another XCD)
                 const u32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.bw_x + o));
 #else
@@ -483,7 +513,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     const int chunk = (lane & 3) ^ swz(prow);
     const int HW = a.Hd * a.Wd;
     // fast-path state
-    unsigned vbase[2], vmask[2], vwf[NBI];
+    unsigned vbase[2], vbase2[2], vmask[2], vwf[NBI];
     int shiftP = 0;                                           // bytes subtracted from the base so soffset >= 0
     // general-path state
     int by[2], bx[2], ib[2];
@@ -507,6 +537,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
             const int y = rem / a.Wd, x = rem - y * a.Wd;
             const int y0 = y << a.in_shift, x0 = x << a.in_shift;
             vbase[i] = ((unsigned)(n * a.Hs * a.Ws + y0 * a.Ws + x0) * (unsigned)a.spitch + (unsigned)(chunk * PE)) * (unsigned)sizeof(T) + gsrc;
+            // second source of a 1x1 launch (K continues over its Cs2 channels as "tap 1"): same pixel, its own pitch
+            vbase2[i] = ((unsigned)mm * (unsigned)a.Cs2 + (unsigned)(chunk * PE)) * (unsigned)sizeof(T);
             unsigned mask = 0;
             for (int t = 0; t < a.ntaps; ++t) {
                 const int ys = y0 + tl.dy[t], xs = x0 + tl.dx[t];
@@ -548,6 +580,9 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src) - shiftP, 0,
                                                           src_bytes + (unsigned)shiftP + 16u, 0x00020000);
     const auto rs_wgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wgt_g), 0, wgt_bytes, 0x00020000);
+    const bool two_src = UTAP && a.src2 != nullptr;                // wave-uniform
+    const auto rs_src2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(two_src ? a.src2 : a.src), 0,
+                                                           two_src ? (unsigned)a.M * (unsigned)a.Cs2 * (unsigned)sizeof(T) : 16u, 0x00020000);
     // wave-uniform K-step state of the uniform-tap path, kept incrementally: tap (ur, us), first channel uc,
     // tap bit index ut, source soffset usoff (bytes), weight soffset uwoff (bytes)
     int uc = 0, ut = 0;
@@ -564,10 +599,11 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
         if constexpr (UTAP) {
             const int t = ut;
             const unsigned soff = usoff, soffw = uwoff;
+            const bool second = two_src && t == 1;                 // wave-uniform: this K step reads the second source
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const unsigned off = ((vmask[i] >> t) & 1u) ? vbase[i] : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(A + (2 * wave + i) * 1024), 16, off, soff, 0, IIF_CONV_AUX_SRC);
+                const unsigned off = ((vmask[i] >> t) & 1u) ? (second ? vbase2[i] : vbase[i]) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs_src2 : rs_src, (lds_void*)(A + (2 * wave + i) * 1024), 16, off, soff, 0, IIF_CONV_AUX_SRC);
             }
 #pragma unroll
             for (int i = 0; i < NBI; ++i)
@@ -601,7 +637,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
             uwoff += KE * (unsigned)sizeof(T);
             usoff += KE * (unsigned)sizeof(T);
             uc += KE;
-            if (uc >= a.Cs) {
+            if (uc >= ((two_src && ut == 1) ? a.Cs2 : a.Cs)) {
                 uc = 0; ++ut;
                 const int tt = ut < a.ntaps ? ut : 0;
                 usoff = (unsigned)((tl.dy[tt] * a.Ws + tl.dx[tt]) * a.spitch * (int)sizeof(T) + shiftP);
@@ -620,7 +656,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
 #pragma unroll
         for (int pj = 0; pj < 4; ++pj) acc[ci][pj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = UTAP ? a.ntaps * (a.Cs / KE) : (a.K + KE - 1) / KE;
+    const int nk = UTAP ? (two_src ? (a.Cs + a.Cs2) / KE : a.ntaps * (a.Cs / KE)) : (a.K + KE - 1) / KE;
     const int fr = lane & 15, fc = lane >> 4;
     // per-lane fragment offsets inside a stage (stage bases are compile-time immediates below)
     int wofs[CI], xofs[4];
@@ -1621,7 +1657,7 @@ struct StreamPlan { int bn, kmax, slices; };
 inline bool use_stream1x1(const ConvArgs& a, bool utap, int esz, bool outf32, StreamPlan* pl) {
     const bool off_ = g_sw.no_stream, force_ = g_sw.force_stream, no_dgrad = g_sw.stream_fwd_only, old_only = g_sw.stream_r2;
     if (off_ || !utap || esz != 2 || outf32 || a.groups > 1 || a.scatter || a.in_shift != 0 || a.sshift != 0) return false;
-    if (a.R != 1 || a.S != 1 || a.pad != 0 || a.ntaps != 1 || a.bias) return false;
+    if (a.R != 1 || a.S != 1 || a.pad != 0 || a.ntaps != 1 || a.bias || a.src2 || a.sbias || a.mask_store) return false;
     if (a.Hs != a.Hd || a.Ws != a.Wd || (a.Cs % 32) || a.spitch != a.Cs || a.dpitch != a.Cd) return false;
     const int K = a.Cs, N = a.Cd;
     if (K <= 64 && N == 256) *pl = {256, 64, 1};
@@ -1829,7 +1865,7 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
     const bool dma_ok = !g_sw.regstage && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL;
     const bool utap = !no_fast && dma_ok && (a.Cs % ET<T>::KE) == 0 && a.R * a.S <= 16 && a.R <= 16 && a.S <= 16;
     a.scatter = 0; a.ds_shift = 0; a.doy = a.dox = 0; a.Hfull = a.Hd; a.Wfull = a.Wd; a.ntaps = 0; a.in_shift = 0;
-    if (!utap) return launch_one<T, OUTF32>(a, false, src_bytes, wgt_bytes, st);
+    if (!utap) return (a.src2 || a.sbias || a.mask_store) ? IIF_EUNSUPPORTED : launch_one<T, OUTF32>(a, false, src_bytes, wgt_bytes, st);
     if (!a.transposed || a.sshift == 0) {
         for (int r = 0; r < a.R; ++r)
             for (int s = 0; s < a.S; ++s) {
@@ -1839,6 +1875,10 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
                 a.tap_w[t] = (unsigned char)(r * a.S + s);
             }
         a.in_shift = a.transposed ? 0 : a.sshift;
+        if (a.src2) {                                        // K continues over the second source as "tap 1" of a 1x1 launch
+            if (a.ntaps != 1 || (a.Cs2 % ET<T>::KE) || a.sshift != 0 || a.groups > 1) return IIF_EUNSUPPORTED;
+            a.tap_dy[1] = 0; a.tap_dx[1] = 0; a.tap_w[1] = 1; a.ntaps = 2;
+        }
         return launch_one<T, OUTF32>(a, true, src_bytes, wgt_bytes, st);
     }
     // stride-2 data gradient: 4 parity classes of the destination grid
@@ -1915,10 +1955,11 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
 }  // namespace
 
 namespace {
+struct ConvExtra { int mask_store; const void* src2; int cs2; const float* sbias; };
 int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                const unsigned char* res_bits, const float* bias, float* bn_partial, int64_t bn_partial_floats,
                int32_t* n_partials, void* stream, const void* bw_x = nullptr, const unsigned char* bw_bits = nullptr,
-               const float* bw_stats = nullptr);
+               const float* bw_stats = nullptr, const ConvExtra* ex = nullptr);
 }
 
 extern "C" int iif_conv_pack_fragments(const void* src_base, const iif_pack_desc* table, int n_desc, int total_blocks,
@@ -1954,6 +1995,26 @@ extern "C" int iif_conv_igemm_dgrad_bnbwd(const iif_conv_desc* d, const void* sr
     return conv_entry(d, src, wgt, dst, res, res_bits, nullptr, partial, partial_floats, n_partials, stream, up_x, up_bits, up_stats);
 }
 
+extern "C" int iif_conv_igemm_dgrad_masksum(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                                            const unsigned char* res_bits, const unsigned char* up_bits, float* partial,
+                                            int64_t partial_floats, int32_t* n_partials, void* stream) {
+    if (!d || !up_bits || !partial || !n_partials || !d->transposed) return IIF_EINVAL;
+    if (res_bits && !res) return IIF_EINVAL;
+    const ConvExtra ex{1, nullptr, 0, nullptr};
+    return conv_entry(d, src, wgt, dst, res, res_bits, nullptr, partial, partial_floats, n_partials, stream, nullptr, up_bits, nullptr, &ex);
+}
+
+extern "C" int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* src, const void* src2, int cs2, const void* wgt,
+                                           const float* bias, void* dst, const void* up_x, const unsigned char* up_bits,
+                                           const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,
+                                           void* stream) {
+    if (!d || !src2 || !d->transposed) return IIF_EINVAL;
+    if (up_x && (!up_stats || !partial || !n_partials)) return IIF_EINVAL;
+    const ConvExtra ex{0, src2, cs2, bias};
+    return conv_entry(d, src, wgt, dst, nullptr, nullptr, nullptr, up_x ? partial : nullptr, partial_floats, n_partials, stream, up_x,
+                      up_bits, up_stats, &ex);
+}
+
 extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
                                       const void* res, const float* bias, float* bn_partial, int64_t bn_partial_floats,
                                       int32_t* n_partials, void* stream) {
@@ -1977,7 +2038,8 @@ extern "C" int iif_conv_igemm(const iif_conv_desc* d, const void* src, const voi
 namespace {
 int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                const unsigned char* res_bits, const float* bias, float* bn_partial, int64_t bn_partial_floats,
-               int32_t* n_partials, void* stream, const void* bw_x, const unsigned char* bw_bits, const float* bw_stats) {
+               int32_t* n_partials, void* stream, const void* bw_x, const unsigned char* bw_bits, const float* bw_stats,
+               const ConvExtra* ex) {
     if (!d || !src || !wgt || !dst) return IIF_EINVAL;
     if (d->n <= 0 || d->hs <= 0 || d->ws <= 0 || d->cs <= 0 || d->hd <= 0 || d->wd <= 0 || d->cd <= 0 ||
         d->r <= 0 || d->s <= 0 || d->pad < 0)
@@ -1986,7 +2048,15 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
     if (d->dtype != IIF_F32 && d->dtype != IIF_BF16) return IIF_EINVAL;
     if (d->dst_dtype != d->dtype && d->dst_dtype != IIF_F32) return IIF_EINVAL;
     const int pe = d->dtype == IIF_F32 ? 4 : 8;
-    if (d->cs % pe != 0 || d->ldw % pe != 0 || d->ldw < d->r * d->s * d->cs) return IIF_EUNSUPPORTED;
+    if (d->cs % pe != 0 || d->ldw % pe != 0 || d->ldw < d->r * d->s * d->cs + (ex && ex->src2 ? ex->cs2 : 0)) return IIF_EUNSUPPORTED;
+    if (ex && (ex->src2 || ex->sbias || ex->mask_store)) {
+        // round-3 epilogue / operand options: bf16 1x1 stride-1 launches on the LDS-staged epilogue only
+        if (d->dtype != IIF_BF16 || d->dst_dtype != IIF_BF16 || d->r != 1 || d->s != 1 || d->stride != 1 || d->pad != 0 || d->groups > 1 ||
+            (d->cd % 8) || bias || (d->cs % 32))
+            return IIF_EUNSUPPORTED;
+        if (ex->src2 && ((ex->cs2 % 32) || ex->cs2 <= 0 || (reinterpret_cast<uintptr_t>(ex->src2) & 15))) return IIF_EUNSUPPORTED;
+        if (ex->mask_store && (!bw_bits || !bn_partial)) return IIF_EINVAL;
+    }
     if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(wgt) | reinterpret_cast<uintptr_t>(dst) |
          reinterpret_cast<uintptr_t>(res)) & 15)
         return IIF_EUNSUPPORTED;
@@ -2004,7 +2074,7 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
         // fused statistics (forward) / backward sums of the upstream unit need the LDS-staged bf16 epilogue of the
         // pipelined kernels; one partial row per pixel tile, counted where the tile height is chosen (launch_one)
         const int64_t esz0 = 2;
-        const bool ok = d->dtype == IIF_BF16 && d->dst_dtype == IIF_BF16 && (d->cd % 8) == 0 && !bias && (bw_x || !res) &&
+        const bool ok = d->dtype == IIF_BF16 && d->dst_dtype == IIF_BF16 && (d->cd % 8) == 0 && !bias && (bw_x || (ex && ex->mask_store) || !res) &&
                         (!bw_x || d->groups <= 1) && !g_sw.regstage &&
                         (int64_t)d->n * d->hs * d->ws * d->cs * (d->groups > 1 ? d->groups : 1) * esz0 < 0x7f000000LL;
         if (!ok) return IIF_EUNSUPPORTED;
@@ -2012,6 +2082,9 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
         a.bn_cap = bn_partial_floats;
         a.rows_out = &rows;
         a.bw_x = (const unsigned char*)bw_x; a.bw_bits = bw_bits; a.bw_stats = bw_stats;
+    }
+    if (ex) {
+        a.mask_store = ex->mask_store; a.src2 = (const unsigned char*)ex->src2; a.Cs2 = ex->cs2; a.sbias = ex->sbias;
     }
     a.N = d->n; a.Hs = d->hs; a.Ws = d->ws; a.Cs = d->cs; a.Hd = d->hd; a.Wd = d->wd; a.Cd = d->cd;
     a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.transposed = d->transposed ? 1 : 0;

@@ -429,6 +429,56 @@ def conv_dgrad_bnbwd(dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits, up_st
     return nt.value
 
 
+# ------------------------------------------------------------ BN backward through the expanding 1x1 layer, by algebra
+def conv_dgrad_masksum(dy, wt, in_hw, out, up_bits, partial, res=None, res_bits=None):
+    """1x1 / stride-1 conv_dgrad whose result is stored gated by ``up_bits`` (the ReLU decisions of the block output it is the
+    gradient of) and whose per-tile column sums go to ``partial`` (second half of every row zero); returns the row count."""
+    require_gpu(dy, wt, res, out)
+    n, ho, wo, cout = dy.shape
+    cin, ldw = wt.shape
+    h, w_ = in_hw
+    d = _desc(n, ho, wo, cout, h, w_, cin, 1, 1, 1, 0, 1, ldw, dtype_code(dy), dtype_code(out), 1)
+    nt = ctypes.c_int32(0)
+    check(lib().iif_conv_igemm_dgrad_masksum(ctypes.byref(d), ptr(dy), ptr(wt), ptr(out), ptr(res), ptr(res_bits), ptr(up_bits),
+                                             ptr(partial), partial.numel(), ctypes.byref(nt), stream_ptr()),
+          "iif_conv_igemm_dgrad_masksum")
+    return nt.value
+
+
+def conv_dgrad2_bnbwd(src, src2, wt, bias, out, up_x=None, up_bits=None, up_stats=None, partial=None):
+    """out[m, j] = sum_k [src | src2][m, k] * wt[j, k] + bias[j]  (1x1, bf16); with up_x: the upstream BN-backward sums too."""
+    require_gpu(src, src2, wt, out, up_x)
+    n, h, w_, c1 = src.shape
+    c2 = src2.shape[3]
+    cout, ldw = wt.shape
+    d = _desc(n, h, w_, c1, h, w_, cout, 1, 1, 1, 0, 1, ldw, dtype_code(src), dtype_code(out), 1)
+    nt = ctypes.c_int32(0)
+    check(lib().iif_conv_igemm_dgrad2_bnbwd(ctypes.byref(d), ptr(src), ptr(src2), c2, ptr(wt), ptr(bias), ptr(out), ptr(up_x),
+                                            ptr(up_bits), ptr(up_stats), ptr(partial), 0 if partial is None else partial.numel(),
+                                            ctypes.byref(nt), stream_ptr()), "iif_conv_igemm_dgrad2_bnbwd")
+    return nt.value
+
+
+def bn3_algebra_coef(P, w_bf16, c, sum_g, stats, gamma, m, coef, dgamma, dbeta, wt):
+    """P [C, ldp] fp32, w_bf16 [C, ldw] (c valid columns) -> coef [3, C], dgamma, dbeta, wt[:, :C] (stacked bf16 weights [c, ldwt])."""
+    C = P.shape[0]
+    check(lib().iif_bn3_algebra_coef(ptr(P), P.stride(0), ptr(w_bf16), w_bf16.stride(0), ptr(sum_g), ptr(stats), ptr(gamma), C, c,
+                                     int(m), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(wt), wt.stride(0), stream_ptr()),
+          "iif_bn3_algebra_coef")
+
+
+def bn3_algebra_gm(w_bf16, c, coef, wt, bias):
+    C = w_bf16.shape[0]
+    check(lib().iif_bn3_algebra_gm(ptr(w_bf16), w_bf16.stride(0), ptr(coef), C, c, ptr(wt), wt.stride(0), ptr(bias), stream_ptr()),
+          "iif_bn3_algebra_gm")
+
+
+def bn3_algebra_dw(P, w_bf16, c, gram, csum, coef, dW):
+    C = P.shape[0]
+    check(lib().iif_bn3_algebra_dw(ptr(P), P.stride(0), ptr(w_bf16), w_bf16.stride(0), ptr(gram), gram.stride(0), ptr(csum), ptr(coef),
+                                   C, c, ptr(dW), dW.stride(0), stream_ptr()), "iif_bn3_algebra_dw")
+
+
 def bn_backward_partials(gy, relu_bits, x2d, stats, gamma, partial, n_partials, dgamma, dbeta, dx, ws, tickets=None):
     m, c = x2d.shape
     check(lib().iif_bn_backward_partials_fused(ptr(gy), ptr(relu_bits), ptr(x2d), dtype_code(x2d), m, c, ptr(stats), ptr(gamma),

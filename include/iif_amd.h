@@ -387,6 +387,36 @@ int iif_conv_pack_fragments(const void* src_base, const iif_pack_desc* table, in
                             void* stream);
 int iif_conv3x3_frag_ok(const iif_conv_desc* d);
 
+/* Batch-norm backward through the expanding 1x1 convolution of a bottleneck (conv3 -> bn3 -> += identity -> relu,
+ * classification/resnet_pytorch.py:160-167) WITHOUT re-reading the convolution's output y = a2 W^T.  BN backward is affine per
+ * channel in (g~, y), dy = A o g~ + B o y + D, with g~ the block-output gradient already gated by the block's ReLU bits, so
+ * with P = g~^T a2 (iif_conv_wgrad), Gram = a2^T a2 (iif_conv_wgrad of a2 with itself) and csum = colsum(a2) (iif_bn_stats_sums):
+ *   sum g~ y = rowdot(P, W);  dW = diag(A) P + diag(B) W Gram + D (x) csum;  da2 = [g~ | a2] [A o W ; W^T diag(B) W]^T + D W.
+ *   iif_conv_igemm_dgrad_masksum  the data gradient that PRODUCES the block-output gradient stores it gated by up_bits and
+ *                                 emits (sum dst, 0) per tile into `partial` (no read of y);
+ *   iif_bn3_algebra_coef          sum_g [C] (iif_bn_partial_sums of those rows), P, W (the bf16 copy the forward used) ->
+ *                                 coef [3][C] = (A, B, D), dgamma, dbeta, and the g~ half of the stacked bf16 weights
+ *                                 wt [c][ldwt >= C + c]:  wt[j][ch] = A[ch] W[ch][j];
+ *   iif_bn3_algebra_gm            the a2 half: wt[j][C + i] = sum_ch W[ch][j] B[ch] W[ch][i], and bias[j] = sum_ch D[ch] W[ch][j];
+ *   iif_conv_igemm_dgrad2_bnbwd   dst = [src | src2] wgt^T + bias (1x1, stride 1, bf16; K runs over src's cs then src2's cs2
+ *                                 channels), optionally with the upstream BN-backward sums of iif_conv_igemm_dgrad_bnbwd;
+ *   iif_bn3_algebra_dw            dW [C][lddw] from P, W, Gram, csum, coef.
+ * c <= 256 (the 56x56 ... 14x14 stages of the ImageNet networks).  Everything sums in a fixed order. */
+int iif_conv_igemm_dgrad_masksum(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                                 const unsigned char* res_bits, const unsigned char* up_bits, float* partial,
+                                 int64_t partial_floats, int32_t* n_partials, void* stream);
+int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* src, const void* src2, int cs2, const void* wgt,
+                                const float* bias, void* dst, const void* up_x, const unsigned char* up_bits,
+                                const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,
+                                void* stream);
+int iif_bn3_algebra_coef(const float* P, int ldp, const void* w_bf16, int ldw, const float* sum_g, const float* stats,
+                         const float* gamma, int C, int c, int64_t m, float* coef, float* dgamma, float* dbeta, void* wt,
+                         int ldwt, void* stream);
+int iif_bn3_algebra_gm(const void* w_bf16, int ldw, const float* coef, int C, int c, void* wt, int ldwt, float* bias,
+                       void* stream);
+int iif_bn3_algebra_dw(const float* P, int ldp, const void* w_bf16, int ldw, const float* gram, int ldg, const float* csum,
+                       const float* coef, int C, int c, float* dW, int lddw, void* stream);
+
 /* The convolution library reads its experiment / test switches (IIF_CONV_NO_STREAM1X1, IIF_CONV_STREAM1X1_FORCE,
  * IIF_CONV_NO_SHORTK, IIF_CONV_TWOSTAGE_K, IIF_CONV_FORCE_BN64, IIF_CONV_REGSTAGE, IIF_CONV_NO_V2) from the environment once, when it is
  * loaded: nothing on the launch path calls getenv.  A harness that changes one of them afterwards calls this to have them

@@ -605,3 +605,90 @@ def test_stream1x1_forward_stats_and_dgrad_epilogues(case, conv_env):
     assert not torch.isnan(ps).any() and nt == (m + 127) // 128
     assert (ps[0] - s1).abs().max().item() <= 2e-6 * max(1.0, s1.abs().max().item()) * 8
     assert (ps[1] - s2).abs().max().item() <= 2e-6 * max(1.0, s2.abs().max().item()) * 8
+
+
+# ------------------------------------------------------------------- BN backward through the expanding 1x1 layer, by algebra
+@pytest.mark.parametrize("case", [(2, 14, 64, 256), (3, 9, 128, 512), (1, 20, 64, 256), (2, 7, 256, 1024)],
+                         ids=lambda c: "%dx%dx%d_%d_%d" % (c[0], c[1], c[1], c[2], c[3]))
+def test_bn3_backward_by_algebra(case):
+    """conv3 -> bn3 backward without re-reading conv3's output (csrc/bn3_algebra.hip): the weight gradient, the BN
+    parameter gradients and the data gradient from P = g~^T a2, Gram = a2^T a2, colsum(a2) and the stacked-weights GEMM over
+    [g~ | a2] — against the textbook BN + convolution backward evaluated in float64 on the same bf16 operands."""
+    from iif_amd import ops
+    n, hw, c, C = case
+    m = n * hw * hw
+    g = torch.Generator().manual_seed(c + C + hw)
+    dt = torch.bfloat16
+    a2 = torch.relu(torch.randn(m, c, generator=g)).to(dt)
+    W = (torch.randn(C, c, generator=g) / c ** 0.5).to(dt)
+    y = a2.float() @ W.float().t()                                   # what conv3 accumulates (fp32 from bf16 operands)
+    mu, var = y.mean(0), y.var(0, unbiased=False)
+    invstd = torch.rsqrt(var + 1e-5)
+    gamma = torch.rand(C, generator=g) + 0.5
+    gt = (torch.randn(m, C, generator=g) * (torch.rand(m, C, generator=g) > 0.4)).to(dt)      # already ReLU-gated
+    # float64 reference
+    yd, gd = y.double(), gt.double()
+    xhat = (yd - mu.double()) * invstd.double()
+    s = gamma.double() * invstd.double()
+    dy = s * (gd - gd.mean(0) - xhat * (gd * xhat).mean(0))
+    ref_dw, ref_da = dy.t() @ a2.double(), dy @ W.double()
+    ref_dgamma, ref_dbeta = (gd * xhat).sum(0), gd.sum(0)
+    # HIP chain
+    d = lambda t: t.to(DEV)                                          # noqa: E731
+    a2d, gtd = d(a2).view(n, hw, hw, c), d(gt).view(n, hw, hw, C)
+    ldw = (c + 15) // 16 * 16
+    Wd = torch.zeros(C, ldw, dtype=dt, device=DEV); Wd[:, :c] = d(W)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    P = ops.conv_wgrad(a2d, gtd, 1, 1, 1, 0, ldw=ldw, workspace=ws)                       # [C, ldw]
+    gram = ops.conv_wgrad(a2d, a2d, 1, 1, 1, 0, ldw=ldw, workspace=ws)                    # [c, ldw]
+    sums = torch.empty(2, c, device=DEV)
+    ops.bn_stats_sums(a2d.view(m, c), sums, ops.bn_workspace(m, c, DEV))
+    sg = d(gt.float().sum(0)).contiguous()
+    stats = torch.zeros(4, C, device=DEV); stats[0] = d(mu); stats[1] = d(invstd)
+    coef = torch.empty(3, C, device=DEV)
+    dgam, dbet = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    wt = torch.zeros(c, C + c, dtype=dt, device=DEV)
+    bias = torch.empty(c, device=DEV)
+    ops.bn3_algebra_coef(P, Wd, c, sg, stats, d(gamma), m, coef, dgam, dbet, wt)
+    ops.bn3_algebra_gm(Wd, c, coef, wt, bias)
+    da = torch.full((n, hw, hw, c), float("nan"), dtype=dt, device=DEV)
+    ops.conv_dgrad2_bnbwd(gtd, a2d, wt, bias, da)
+    dW = torch.zeros(C, ldw, device=DEV)
+    ops.bn3_algebra_dw(P, Wd, c, gram, sums[0].contiguous(), coef, dW)
+    rel = lambda a_, b_: (a_.cpu().double() - b_).norm().item() / b_.norm().item()         # noqa: E731
+    assert rel(dgam, ref_dgamma) <= 2e-4 and rel(dbet, ref_dbeta) <= 1e-5
+    assert rel(dW[:, :c], ref_dw) <= 2e-3                    # P and Gram carry fp32 sums over m bf16 products
+    assert not dW[:, c:].any()
+    got = da.float().cpu().view(m, c).double()
+    assert (got - ref_da).abs().max().item() <= 2.0 ** -6 * ref_da.abs().max().item()          # bf16 weights + bf16 result
+    assert rel(da.view(m, c), ref_da) <= 1e-2
+
+
+@pytest.mark.parametrize("case", [(2, 14, 64, 256), (3, 11, 128, 512)], ids=lambda c: "%dx%dx%d_%d_%d" % (c[0], c[1], c[1], c[2], c[3]))
+def test_dgrad_masked_store_and_column_sums(case):
+    """iif_conv_igemm_dgrad_masksum: the conv1 data gradient (+ ReLU-gated residual) stored already gated by the upstream
+    block's ReLU bits, per-tile column sums of the stored tensor in the partial rows; bit-identical to the plain data gradient
+    followed by the gate."""
+    from iif_amd import ops
+    n, hw, c, C = case
+    m = n * hw * hw
+    g = torch.Generator().manual_seed(7 * c + hw)
+    dt = torch.bfloat16
+    dy1 = torch.randn(n, hw, hw, c, generator=g).to(dt).to(DEV)
+    w1 = (torch.randn(c, C, generator=g) / C ** 0.5).to(dt)            # conv1: C -> c; its data gradient: c -> C
+    wtt = torch.zeros(C, (c + 15) // 16 * 16, dtype=dt, device=DEV)
+    ops.weight_transpose(w1.float().to(DEV), c, C, 1, wtt)
+    res = torch.randn(n, hw, hw, C, generator=g).to(dt).to(DEV)
+    rbits = torch.randint(0, 256, (m * C // 8,), dtype=torch.uint8, generator=g).to(DEV)
+    ubits = torch.randint(0, 256, (m * C // 8,), dtype=torch.uint8, generator=g).to(DEV)
+    plain = ops.conv_dgrad(dy1, wtt, 1, 1, 1, 0, (hw, hw), res=res, res_bits=rbits)
+    out = torch.full((n, hw, hw, C), float("nan"), dtype=dt, device=DEV)
+    partial = torch.full(((m + 127) // 128 + 8, 2, C), float("nan"), device=DEV)
+    nt = ops.conv_dgrad_masksum(dy1, wtt, (hw, hw), out, ubits, partial.view(-1), res=res, res_bits=rbits)
+    mask = ((ubits.cpu().view(-1, 1).int() >> torch.arange(8).view(1, 8)) & 1).view(m, C).bool()
+    expect = torch.where(mask, plain.cpu().view(m, C), torch.zeros((), dtype=dt))
+    assert torch.equal(out.cpu().view(m, C), expect)
+    ps = partial[:nt].sum(0).cpu()
+    assert nt >= 1 and not torch.isnan(ps).any() and not ps[1].any()
+    ref = expect.float().sum(0)
+    assert (ps[0] - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item()) * 8
