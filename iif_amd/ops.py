@@ -92,6 +92,8 @@ def conv_wgrad(x, dy, r, s, stride, pad, ldw=None, out=None, workspace=None, spl
     ldw = ldw or k
     if out is None:
         out = torch.zeros((cout, ldw), dtype=torch.float32, device=x.device)
+    elif not out.is_contiguous() or out.numel() < cout * ldw:
+        raise ValueError("conv_wgrad: out must be a contiguous float32 [Cout, ldw] tensor (rows are written with pitch ldw)")
     d = _desc(n, h, w_, cin // groups, ho, wo, cout // groups, r, s, stride, pad, 0, ldw, dtype_code(x), _lib.IIF_F32, groups)
     wsb = 0 if workspace is None else workspace.numel() * workspace.element_size()
     check(lib().iif_conv_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), ptr(workspace), wsb, splits, stream_ptr()),
@@ -459,18 +461,23 @@ def conv_dgrad2_bnbwd(src, src2, wt, bias, out, up_x=None, up_bits=None, up_stat
     return nt.value
 
 
-def bn3_algebra_coef(P, w_bf16, c, sum_g, stats, gamma, m, coef, dgamma, dbeta, wt):
-    """P [C, ldp] fp32, w_bf16 [C, ldw] (c valid columns) -> coef [3, C], dgamma, dbeta, wt[:, :C] (stacked bf16 weights [c, ldwt])."""
+def bn3_algebra_coef(P, w_bf16, c, partial, n_partials, stats, gamma, m, coef, dgamma, dbeta, wt, bw, scratch):
+    """P [C, ldp] fp32, w_bf16 [C, ldw] (c valid columns), the producer's partial rows -> coef [3, C], dgamma, dbeta,
+    wt[:, :C] (stacked bf16 weights [c, ldwt]) and bw [C, c] = bf16(B o W)."""
     C = P.shape[0]
-    check(lib().iif_bn3_algebra_coef(ptr(P), P.stride(0), ptr(w_bf16), w_bf16.stride(0), ptr(sum_g), ptr(stats), ptr(gamma), C, c,
-                                     int(m), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(wt), wt.stride(0), stream_ptr()),
-          "iif_bn3_algebra_coef")
+    check(lib().iif_bn3_algebra_coef(ptr(P), P.stride(0), ptr(w_bf16), w_bf16.stride(0), ptr(partial), n_partials, ptr(stats),
+                                     ptr(gamma), C, c, int(m), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(wt), wt.stride(0), ptr(bw),
+                                     ptr(scratch), scratch.numel(), stream_ptr()), "iif_bn3_algebra_coef")
 
 
-def bn3_algebra_gm(w_bf16, c, coef, wt, bias):
+def bn3_algebra_gm_scratch(C, c, device):
+    return torch.empty(lib().iif_bn3_algebra_gm_scratch_floats(C, c), dtype=torch.float32, device=device)
+
+
+def bn3_algebra_gm(w_bf16, c, bw, coef, wt, bias, scratch):
     C = w_bf16.shape[0]
-    check(lib().iif_bn3_algebra_gm(ptr(w_bf16), w_bf16.stride(0), ptr(coef), C, c, ptr(wt), wt.stride(0), ptr(bias), stream_ptr()),
-          "iif_bn3_algebra_gm")
+    check(lib().iif_bn3_algebra_gm(ptr(w_bf16), w_bf16.stride(0), ptr(bw), ptr(coef), C, c, ptr(wt), wt.stride(0), ptr(bias),
+                                   ptr(scratch), scratch.numel(), stream_ptr()), "iif_bn3_algebra_gm")
 
 
 def bn3_algebra_dw(P, w_bf16, c, gram, csum, coef, dW):

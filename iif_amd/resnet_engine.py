@@ -753,6 +753,41 @@ class _Plan(object):
                                       dtype=torch.float32, device=dev)
         self.fuse_bwd = dt == torch.bfloat16 and not os.environ.get("IIF_NO_BWD_FUSE")
         self._bw_ready = None
+        # BN backward through the expanding 1x1 layer of a bottleneck by algebra (csrc/bn3_algebra.hip): the block-output
+        # gradient arrives already gated by the block's ReLU (the producing data gradient stores it so), and conv3's output is
+        # never read in backward.  Units: the last conv+BN of every plain bottleneck with <= 256 input channels whose output
+        # has >= 1.5e8 elements: the route saves about 3.5 passes over that tensor and costs about 0.2 ms of small launches
+        # and an exposed P = g~^T a2 product on the compute stream (measured), so it pays for the 56 x 56 stage of
+        # the 224-pixel / batch-256 configuration and not for the later ones.
+        self.alg3_units = set()
+        a3_maxc = min(256, int(os.environ.get("IIF_BN3_ALGEBRA_MAXC", "256")))
+        a3_min = float(os.environ.get("IIF_BN3_ALGEBRA_MIN_ELEMS", "1.5e8"))
+        if self.fuse_bwd and net._sync_bn is None and not os.environ.get("IIF_NO_BN3_ALGEBRA"):
+            for b in self.blocks:
+                if "se" in b or "sc" in b or len(b["units"]) != 3:
+                    continue
+                u3 = b["units"][-1]
+                cv3 = u3.conv
+                if (cv3.k == 1 and cv3.stride == 1 and cv3.groups == 1 and cv3.cin % 32 == 0 and cv3.cin <= a3_maxc and cv3.cout % 64 == 0
+                        and _dma_ok(u3.x) and u3.n * u3.ho * u3.wo < (1 << 30) and u3.n * u3.ho * u3.wo * cv3.cout >= a3_min):
+                    self.alg3_units.add(u3)
+        self.a3 = None
+        if self.alg3_units:
+            cm = max(u.conv.cin for u in self.alg3_units)
+            Cm = max(u.conv.cout for u in self.alg3_units)
+            ldm = max(u.conv.ldw for u in self.alg3_units)
+            F = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)   # noqa: E731
+            # per-block scratch rotates over 2 slots (the weight-gradient stream finishes block b before block b - 2 starts:
+            # _wgrad_fence); Gram / colsum are issued one block AHEAD on another stream, so they rotate over 3
+            self.a3 = [{"P": F(Cm, ldm), "scr": F(64 * Cm), "coef": F(3, Cm), "bias": F(cm),
+                        "wt": torch.zeros(cm * (Cm + cm), dtype=dt, device=dev),
+                        "bw": torch.zeros(Cm * cm, dtype=dt, device=dev),
+                        "gms": torch.empty(max(ops.lib().iif_bn3_algebra_gm_scratch_floats(u.conv.cout, u.conv.cin)
+                                               for u in self.alg3_units), dtype=torch.float32, device=dev)} for _ in range(2)]
+            self.a3g = [{"gram": F(cm, ldm), "csum": F(2, cm), "ws_gram": torch.empty(64 << 20, dtype=torch.uint8, device=dev),
+                         "ws_sum": ops.bn_workspace(max(u.n * u.ho * u.wo for u in self.alg3_units), cm, dev), "ev": None}
+                        for _ in range(3)]
+            self.a3_ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)          # split-K slabs of P on the compute stream
         wmax = max(max(u.conv.cout * (u.dwp.shape[1] if u.dwp is not None else u.conv.ldw) for u in self.units),
                    head.out_padded * head.in_features)
         self.wg_ws = torch.empty(min(16 * wmax * 4, 512 << 20), dtype=torch.uint8, device=dev)
@@ -1165,6 +1200,8 @@ class _Plan(object):
             ops.bn_backward_apply_sums(g2, None if (mask is None or bits is not None) else mask.view(m, cv.cout), u.x.view(m, cv.cout),
                                        u.stats, bn.weight, local, total, float(m) * world, bn._dgamma, bn._dbeta, dx, coef,
                                        gmasked=None if gmasked is None else gmasked.view(m, cv.cout), relu_bits=bits)
+        elif ready is not None and ready[0] is u and len(ready) == 3:
+            return self._bn3_algebra(u, gy, ready[1], par, self._cur_block, dgrad_out, fuse_up)
         elif ready is not None and ready[0] is u and gmasked is None:
             # the data gradient that wrote gy already reduced (sum g, sum g*xhat) per tile: no reduction pass
             dx = self._gbuf((dxkey, m, cv.cout, par), (m, cv.cout)) if keep_gy else g2
@@ -1197,12 +1234,79 @@ class _Plan(object):
             return None
         if fuse_up is not None and self.fuse_bwd and u.groups == 1 and dgrad_out is not None and _dma_ok(dx4):
             up, up_bits = fuse_up
+            if up in self.alg3_units and cv.k == 1 and cv.stride == 1 and up_bits is not None:
+                # the upstream unit's BN backward runs by algebra: store the gradient gated by its block's ReLU, emit its
+                # column sums only (conv3's output is not read)
+                nt = ops.conv_dgrad_masksum(dx4, u.wt, (u.hi, u.wi), dgrad_out, up_bits, self.bw_partial, res=dgrad_res,
+                                            res_bits=dgrad_res_bits)
+                self._bw_ready = (up, nt, True)
+                return dgrad_out
             nt = ops.conv_dgrad_bnbwd(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), dgrad_out, up.x, up_bits, up.stats,
                                       self.bw_partial, res=dgrad_res, res_bits=dgrad_res_bits, w_frag=u.wtf)
             self._bw_ready = (up, nt)
             return dgrad_out
         return ops.conv_dgrad(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), out=dgrad_out, res=dgrad_res,
                               groups=u.groups, res_bits=dgrad_res_bits, w_frag=u.wtf)
+
+    def _bn3_gram_async(self, u, bi):
+        """Gram = a2^T a2 and colsum(a2) of an algebra unit's input: forward data only, so it is issued a block ahead on the
+        shortcut stream (idle outside the four downsample blocks) and never waited for in practice."""
+        A = self.a3g[bi % 3]
+        cv = u.conv
+        a2 = u.src
+
+        def work():
+            ops.conv_wgrad(a2, a2, 1, 1, 1, 0, ldw=cv.ldw, out=A["gram"].view(-1)[:cv.cin * cv.ldw].view(cv.cin, cv.ldw),
+                           workspace=A["ws_gram"])
+            ops.bn_stats_sums(a2.view(-1, cv.cin), A["csum"][:, :cv.cin], A["ws_sum"])
+        st = self.ds_stream if self.ds_stream is not None else self.wg_stream
+        if st is None:
+            work()
+            A["ev"] = None
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(st):
+            st.wait_event(ev)
+            work()
+            done = torch.cuda.Event()
+            done.record()
+        A["ev"] = done
+
+    def _bn3_algebra(self, u, gt, nt, par, bi, dgrad_out, fuse_up):
+        """Backward of conv3 + bn3 from the gated block-output gradient ``gt`` without reading conv3's output
+        (csrc/bn3_algebra.hip).  Returns the gradient w.r.t. the unit's source (a2)."""
+        cv, bn = u.conv, u.bn
+        A, Ag = self.a3[par % 2], self.a3g[bi % 3]
+        C, c = cv.cout, cv.cin
+        m = u.n * u.ho * u.wo
+        g4 = gt.view(u.n, u.ho, u.wo, C)
+        wb = u.w                                                   # the bf16 weights the forward multiplied with, [C, ldw]
+        P = A["P"].view(-1)[:C * cv.ldw].view(C, cv.ldw)          # contiguous [C, ldw]: conv_wgrad writes with pitch ldw
+        ops.conv_wgrad(u.src, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=self.a3_ws)
+        wt = A["wt"][:c * (C + c)].view(c, C + c)
+        coef = A["coef"][:, :C]
+        ops.bn3_algebra_coef(P, wb, c, self.bw_partial, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt, A["bw"], A["scr"])
+        ops.bn3_algebra_gm(wb, c, A["bw"], coef, wt, A["bias"][:c], A["gms"])
+        # the weight gradient needs Gram / colsum (issued a block ahead) and nothing on the critical path needs it
+        gram_ev = Ag["ev"]
+
+        def finish_dw():
+            ops.bn3_algebra_dw(P, wb, c, Ag["gram"].view(-1)[:c * cv.ldw].view(c, cv.ldw), Ag["csum"][0, :c], coef, cv._g2d)
+        if self.wg_stream is None:
+            finish_dw()
+        else:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.wg_stream):
+                self.wg_stream.wait_event(ev)
+                if gram_ev is not None:
+                    self.wg_stream.wait_event(gram_ev)
+                finish_dw()
+        up, up_bits = fuse_up
+        nt2 = ops.conv_dgrad2_bnbwd(g4, u.src, wt, A["bias"][:c], dgrad_out, up.x, up_bits, up.stats, self.bw_partial)
+        self._bw_ready = (up, nt2)
+        return dgrad_out
 
     def backward(self, reducer=None):
         net = self.net
@@ -1279,6 +1383,9 @@ class _Plan(object):
             # gradient (the residual-branch gradient) and dx of the last conv has been consumed.
             par = bi % self.wg_lag
             self._wgrad_fence(bi)
+            self._cur_block = bi
+            if bi > 0 and self.blocks[bi - 1]["units"][-1] in self.alg3_units:
+                self._bn3_gram_async(self.blocks[bi - 1]["units"][-1], bi - 1)
             gin = self._gbuf(("gin", tuple(inp.shape), bi % (self.wg_lag + 1)), inp.shape)
             dkey = ("d", tuple(last.src.shape), len(units) - 1, par)
             # The block's ReLU gates g on both paths.  With a convolutional shortcut or a plain identity no masked

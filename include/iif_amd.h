@@ -394,10 +394,11 @@ int iif_conv3x3_frag_ok(const iif_conv_desc* d);
  *   sum g~ y = rowdot(P, W);  dW = diag(A) P + diag(B) W Gram + D (x) csum;  da2 = [g~ | a2] [A o W ; W^T diag(B) W]^T + D W.
  *   iif_conv_igemm_dgrad_masksum  the data gradient that PRODUCES the block-output gradient stores it gated by up_bits and
  *                                 emits (sum dst, 0) per tile into `partial` (no read of y);
- *   iif_bn3_algebra_coef          sum_g [C] (iif_bn_partial_sums of those rows), P, W (the bf16 copy the forward used) ->
- *                                 coef [3][C] = (A, B, D), dgamma, dbeta, and the g~ half of the stacked bf16 weights
- *                                 wt [c][ldwt >= C + c]:  wt[j][ch] = A[ch] W[ch][j];
- *   iif_bn3_algebra_gm            the a2 half: wt[j][C + i] = sum_ch W[ch][j] B[ch] W[ch][i], and bias[j] = sum_ch D[ch] W[ch][j];
+ *   iif_bn3_algebra_coef          those partial rows (their column sums are sum g~; scratch >= 64 C floats), P, W (the bf16 copy
+ *                                 the forward used) -> coef [3][C] = (A, B, D), dgamma, dbeta, the g~ half of the stacked bf16
+ *                                 weights wt [c][ldwt >= C + c]: wt[j][ch] = A[ch] W[ch][j], and bw [C][c] = bf16(B[ch] W[ch][j]);
+ *   iif_bn3_algebra_gm            the a2 half: wt[j][C + i] = sum_ch bw[ch][j] W[ch][i], and bias[j] = sum_ch D[ch] W[ch][j]
+ *                                 (scratch: iif_bn3_algebra_gm_scratch_floats(C, c) floats of channel-slice slabs);
  *   iif_conv_igemm_dgrad2_bnbwd   dst = [src | src2] wgt^T + bias (1x1, stride 1, bf16; K runs over src's cs then src2's cs2
  *                                 channels), optionally with the upstream BN-backward sums of iif_conv_igemm_dgrad_bnbwd;
  *   iif_bn3_algebra_dw            dW [C][lddw] from P, W, Gram, csum, coef.
@@ -409,11 +410,12 @@ int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* src, const v
                                 const float* bias, void* dst, const void* up_x, const unsigned char* up_bits,
                                 const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,
                                 void* stream);
-int iif_bn3_algebra_coef(const float* P, int ldp, const void* w_bf16, int ldw, const float* sum_g, const float* stats,
-                         const float* gamma, int C, int c, int64_t m, float* coef, float* dgamma, float* dbeta, void* wt,
-                         int ldwt, void* stream);
-int iif_bn3_algebra_gm(const void* w_bf16, int ldw, const float* coef, int C, int c, void* wt, int ldwt, float* bias,
-                       void* stream);
+int iif_bn3_algebra_coef(const float* P, int ldp, const void* w_bf16, int ldw, const float* partial, int n_partials,
+                         const float* stats, const float* gamma, int C, int c, int64_t m, float* coef, float* dgamma, float* dbeta,
+                         void* wt, int ldwt, void* bw, float* scratch, int64_t scratch_floats, void* stream);
+int64_t iif_bn3_algebra_gm_scratch_floats(int C, int c);
+int iif_bn3_algebra_gm(const void* w_bf16, int ldw, const void* bw, const float* coef, int C, int c, void* wt, int ldwt, float* bias,
+                       float* scratch, int64_t scratch_floats, void* stream);
 int iif_bn3_algebra_dw(const float* P, int ldp, const void* w_bf16, int ldw, const float* gram, int ldg, const float* csum,
                        const float* coef, int C, int c, float* dW, int lddw, void* stream);
 

@@ -41,3 +41,8 @@ for t, d in ev:
         anybusy += t - last
     cur += d; last = t
 print("GPU busy with at least one kernel: %.3f ms of %.3f ms" % (anybusy / 1e6, (t1 - t0) / 1e6))
+if len(sys.argv) > 3:
+    # full listing of the step, every queue, in start order:  +ms  queue  duration  name
+    with open(sys.argv[3], "w") as f:
+        for r in step:
+            f.write("%8.3f q%-2s %7.1f us  %s\n" % ((r[1] - t0) / 1e6, r[3], (r[2] - r[1]) / 1e3, r[0][:110].replace("(anonymous namespace)::", "")))

@@ -643,14 +643,20 @@ def test_bn3_backward_by_algebra(case):
     gram = ops.conv_wgrad(a2d, a2d, 1, 1, 1, 0, ldw=ldw, workspace=ws)                    # [c, ldw]
     sums = torch.empty(2, c, device=DEV)
     ops.bn_stats_sums(a2d.view(m, c), sums, ops.bn_workspace(m, c, DEV))
-    sg = d(gt.float().sum(0)).contiguous()
+    npart = 70                                                       # > 64: slices of more than one partial row
+    part = torch.zeros(npart, 2, C)
+    for r in range(npart):
+        part[r, 0] = gt[r::npart].float().sum(0)
+    part[:, 1] = float("nan")                                        # the second half of a row is never read here
+    part = d(part)
     stats = torch.zeros(4, C, device=DEV); stats[0] = d(mu); stats[1] = d(invstd)
     coef = torch.empty(3, C, device=DEV)
     dgam, dbet = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     wt = torch.zeros(c, C + c, dtype=dt, device=DEV)
     bias = torch.empty(c, device=DEV)
-    ops.bn3_algebra_coef(P, Wd, c, sg, stats, d(gamma), m, coef, dgam, dbet, wt)
-    ops.bn3_algebra_gm(Wd, c, coef, wt, bias)
+    bw = torch.empty(C, c, dtype=dt, device=DEV)
+    ops.bn3_algebra_coef(P, Wd, c, part, npart, stats, d(gamma), m, coef, dgam, dbet, wt, bw, torch.empty(64 * C, device=DEV))
+    ops.bn3_algebra_gm(Wd, c, bw, coef, wt, bias, ops.bn3_algebra_gm_scratch(C, c, DEV))
     da = torch.full((n, hw, hw, c), float("nan"), dtype=dt, device=DEV)
     ops.conv_dgrad2_bnbwd(gtd, a2d, wt, bias, da)
     dW = torch.zeros(C, ldw, device=DEV)
