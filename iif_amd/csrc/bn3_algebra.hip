@@ -37,16 +37,20 @@ __global__ void __launch_bounds__(256) bn3_coef_kernel(const float* P, int ldp, 
     {
         const int lc = threadIdx.x >> 3, sub = threadIdx.x & 7;
         const int ch = ch0 + lc;
-        float acc = 0.f, s1 = 0.f;
+        float acc = 0.f, s1 = 0.f, sq = 0.f;
         if (ch < C) {
-            for (int j = sub; j < c; j += 8) acc += P[(int64_t)ch * ldp + j] * bf16_bits_to_f32(W[(int64_t)ch * ldw + j]);
-            for (int r = sub; r < slices; r += 8) s1 += sg_slices[(int64_t)r * sg_pitch + ch];
+            if (P)
+                for (int j = sub; j < c; j += 8) acc += P[(int64_t)ch * ldp + j] * bf16_bits_to_f32(W[(int64_t)ch * ldw + j]);
+            for (int r = sub; r < slices; r += 8) {
+                s1 += sg_slices[(int64_t)r * sg_pitch + ch];
+                sq += sg_slices[(int64_t)r * sg_pitch + C + ch];
+            }
         }
 #pragma unroll
-        for (int o = 4; o > 0; o >>= 1) { acc += __shfl_xor(acc, o, 64); s1 += __shfl_xor(s1, o, 64); }
+        for (int o = 4; o > 0; o >>= 1) { acc += __shfl_xor(acc, o, 64); s1 += __shfl_xor(s1, o, 64); sq += __shfl_xor(sq, o, 64); }
         if (sub == 0 && ch < C) {
             const float mu = stats[ch], invstd = stats[C + ch];
-            const float s2 = invstd * (acc - mu * s1);        // sum g~ xhat
+            const float s2 = P ? invstd * (acc - mu * s1) : sq;        // sum g~ xhat
             dbeta[ch] = s1;
             dgamma[ch] = s2;
             const float A = gamma[ch] * invstd;
@@ -200,23 +204,23 @@ __global__ void __launch_bounds__(256) bn3_dw_kernel(const float* P, int ldp, co
     }
 }
 
-// stage 1 of the column sums of many partial rows: slice blockIdx.y of the rows, 32 channels per block, first half of every
-// row ([2][C] rows: only the sums of the stored gradient are used here) -> out[slice][C]
-__global__ void __launch_bounds__(256) bn3_slice_sums_kernel(const float* partial, int nrows, int C, int rows_per_slice, float* out) {
+// stage 1 of the column sums of many partial rows ([2][C] each): slice blockIdx.y of the rows, 32 of the 2 C columns per
+// block -> out[slice][2 C]
+__global__ void __launch_bounds__(256) bn3_slice_sums_kernel(const float* partial, int nrows, int C2, int rows_per_slice, float* out) {
     __shared__ float sh[256];
     const int cl = threadIdx.x & 31, ln = threadIdx.x >> 5;
     const int ch = blockIdx.x * 32 + cl;
     const int r0 = blockIdx.y * rows_per_slice;
     int r1 = r0 + rows_per_slice; if (r1 > nrows) r1 = nrows;
     float a = 0.f;
-    if (ch < C)
-        for (int r = r0 + ln; r < r1; r += 8) a += partial[(int64_t)r * 2 * C + ch];
+    if (ch < C2)
+        for (int r = r0 + ln; r < r1; r += 8) a += partial[(int64_t)r * C2 + ch];
     sh[ln * 32 + cl] = a;
     __syncthreads();
-    if (ln == 0 && ch < C) {
+    if (ln == 0 && ch < C2) {
         float s = 0.f;
         for (int q = 0; q < 8; ++q) s += sh[q * 32 + cl];
-        out[(int64_t)blockIdx.y * C + ch] = s;
+        out[(int64_t)blockIdx.y * C2 + ch] = s;
     }
 }
 
@@ -227,17 +231,17 @@ extern "C" {
 int iif_bn3_algebra_coef(const float* P, int ldp, const void* w_bf16, int ldw, const float* partial, int n_partials,
                          const float* stats, const float* gamma, int C, int c, int64_t m, float* coef, float* dgamma, float* dbeta,
                          void* wt, int ldwt, void* bw, float* scratch, int64_t scratch_floats, void* stream) {
-    if (!P || !w_bf16 || !partial || !stats || !gamma || !coef || !dgamma || !dbeta || !wt || !bw || !scratch || C <= 0 || c <= 0 ||
+    if (!w_bf16 || !partial || !stats || !gamma || !coef || !dgamma || !dbeta || !wt || !bw || !scratch || C <= 0 || c <= 0 ||
         m <= 0 || n_partials <= 0)
         return IIF_EINVAL;
-    if (c > 256 || (c % 32) || ldp < c || ldw < c || ldwt < C + c) return IIF_EUNSUPPORTED;
+    if (c > 256 || (c % 32) || (P && ldp < c) || ldw < c || ldwt < C + c) return IIF_EUNSUPPORTED;
     const int slices = n_partials < 64 ? n_partials : 64;
-    if ((int64_t)slices * C > scratch_floats) return IIF_EINVAL;
+    if ((int64_t)slices * 2 * C > scratch_floats) return IIF_EINVAL;
     const int rps = (n_partials + slices - 1) / slices;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(bn3_slice_sums_kernel, dim3((C + 31) / 32, slices), dim3(256), 0, st, partial, n_partials, C, rps, scratch);
+    hipLaunchKernelGGL(bn3_slice_sums_kernel, dim3((2 * C + 31) / 32, slices), dim3(256), 0, st, partial, n_partials, 2 * C, rps, scratch);
     IIF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn3_coef_kernel, dim3((C + 31) / 32), dim3(256), 0, st, P, ldp, (const unsigned short*)w_bf16, ldw, scratch, slices, C,
+    hipLaunchKernelGGL(bn3_coef_kernel, dim3((C + 31) / 32), dim3(256), 0, st, P, ldp, (const unsigned short*)w_bf16, ldw, scratch, slices, 2 * C,
                        stats, gamma, C, c, (double)m, coef, dgamma, dbeta, (unsigned short*)wt, ldwt, (unsigned short*)bw);
     IIF_LAUNCH_CHECK();
     return IIF_OK;

@@ -394,7 +394,7 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
                     const unsigned lo = (mb >> (2 * q)) & 1u ? (v[q] & 0xffffu) : 0u;
                     const unsigned hi = (mb >> (2 * q + 1)) & 1u ? (v[q] & 0xffff0000u) : 0u;
                     v[q] = lo | hi;
-                    bs[2 * q] += bf16_bits_to_f32(lo); bs[2 * q + 1] += __uint_as_float(hi);
+                    if (!a.bw_x) { bs[2 * q] += bf16_bits_to_f32(lo); bs[2 * q + 1] += __uint_as_float(hi); }
                 }
             }
 #ifndef IIF_NO_NT_CONV_STORE     // the tile is next read by another XCD (BN apply): streaming it out keeps the pixel operand's lines in L2 (-0.7 % on the step)
@@ -402,8 +402,7 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
 #else
             *reinterpret_cast<u32x4*>(a.dst + o) = v;
 #endif
-            if (a.mask_store) {
-            } else if (a.bw_x) {
+            if (a.bw_x) {                           // (with mask_store v is gated already; gating it again below changes nothing)
 #ifndef IIF_NO_NT_EPILOGUE_LOADS   // streamed once by this kernel (next reader: the BN backward, from another XCD)
                 const u32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.bw_x + o));
 #else
@@ -419,6 +418,7 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
                     bs[2 * q] += glo; bq[2 * q] += glo * xlo;
                     bs[2 * q + 1] += ghi; bq[2 * q + 1] += ghi * xhi;
                 }
+            } else if (a.mask_store) {              // column sums only, accumulated with the gate above
             } else if (a.bn_partial) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1996,12 +1996,15 @@ extern "C" int iif_conv_igemm_dgrad_bnbwd(const iif_conv_desc* d, const void* sr
 }
 
 extern "C" int iif_conv_igemm_dgrad_masksum(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
-                                            const unsigned char* res_bits, const unsigned char* up_bits, float* partial,
-                                            int64_t partial_floats, int32_t* n_partials, void* stream) {
+                                            const unsigned char* res_bits, const void* up_x, const unsigned char* up_bits,
+                                            const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,
+                                            void* stream) {
     if (!d || !up_bits || !partial || !n_partials || !d->transposed) return IIF_EINVAL;
     if (res_bits && !res) return IIF_EINVAL;
+    if (up_x && !up_stats) return IIF_EINVAL;
     const ConvExtra ex{1, nullptr, 0, nullptr};
-    return conv_entry(d, src, wgt, dst, res, res_bits, nullptr, partial, partial_floats, n_partials, stream, nullptr, up_bits, nullptr, &ex);
+    return conv_entry(d, src, wgt, dst, res, res_bits, nullptr, partial, partial_floats, n_partials, stream, up_x, up_bits,
+                      up_x ? up_stats : nullptr, &ex);
 }
 
 extern "C" int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* src, const void* src2, int cs2, const void* wgt,

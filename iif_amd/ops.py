@@ -432,17 +432,19 @@ def conv_dgrad_bnbwd(dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits, up_st
 
 
 # ------------------------------------------------------------ BN backward through the expanding 1x1 layer, by algebra
-def conv_dgrad_masksum(dy, wt, in_hw, out, up_bits, partial, res=None, res_bits=None):
+def conv_dgrad_masksum(dy, wt, in_hw, out, up_bits, partial, res=None, res_bits=None, up_x=None, up_stats=None):
     """1x1 / stride-1 conv_dgrad whose result is stored gated by ``up_bits`` (the ReLU decisions of the block output it is the
-    gradient of) and whose per-tile column sums go to ``partial`` (second half of every row zero); returns the row count."""
-    require_gpu(dy, wt, res, out)
+    gradient of) and whose per-tile column sums go to ``partial`` (second half of every row: zero, or with ``up_x`` /
+    ``up_stats`` the sums of gradient * xhat); returns the row count."""
+    require_gpu(dy, wt, res, out, up_x)
     n, ho, wo, cout = dy.shape
     cin, ldw = wt.shape
     h, w_ = in_hw
     d = _desc(n, ho, wo, cout, h, w_, cin, 1, 1, 1, 0, 1, ldw, dtype_code(dy), dtype_code(out), 1)
     nt = ctypes.c_int32(0)
-    check(lib().iif_conv_igemm_dgrad_masksum(ctypes.byref(d), ptr(dy), ptr(wt), ptr(out), ptr(res), ptr(res_bits), ptr(up_bits),
-                                             ptr(partial), partial.numel(), ctypes.byref(nt), stream_ptr()),
+    check(lib().iif_conv_igemm_dgrad_masksum(ctypes.byref(d), ptr(dy), ptr(wt), ptr(out), ptr(res), ptr(res_bits), ptr(up_x),
+                                             ptr(up_bits), ptr(up_stats), ptr(partial), partial.numel(), ctypes.byref(nt),
+                                             stream_ptr()),
           "iif_conv_igemm_dgrad_masksum")
     return nt.value
 
@@ -462,10 +464,11 @@ def conv_dgrad2_bnbwd(src, src2, wt, bias, out, up_x=None, up_bits=None, up_stat
 
 
 def bn3_algebra_coef(P, w_bf16, c, partial, n_partials, stats, gamma, m, coef, dgamma, dbeta, wt, bw, scratch):
-    """P [C, ldp] fp32, w_bf16 [C, ldw] (c valid columns), the producer's partial rows -> coef [3, C], dgamma, dbeta,
-    wt[:, :C] (stacked bf16 weights [c, ldwt]) and bw [C, c] = bf16(B o W)."""
-    C = P.shape[0]
-    check(lib().iif_bn3_algebra_coef(ptr(P), P.stride(0), ptr(w_bf16), w_bf16.stride(0), ptr(partial), n_partials, ptr(stats),
+    """P [C, ldp] fp32 (or None: sum g~ xhat comes from the second half of the partial rows), w_bf16 [C, ldw] (c valid
+    columns), the producer's partial rows -> coef [3, C], dgamma, dbeta, wt[:, :C] (stacked bf16 weights [c, ldwt]) and
+    bw [C, c] = bf16(B o W)."""
+    C = w_bf16.shape[0]
+    check(lib().iif_bn3_algebra_coef(ptr(P), 0 if P is None else P.stride(0), ptr(w_bf16), w_bf16.stride(0), ptr(partial), n_partials, ptr(stats),
                                      ptr(gamma), C, c, int(m), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(wt), wt.stride(0), ptr(bw),
                                      ptr(scratch), scratch.numel(), stream_ptr()), "iif_bn3_algebra_coef")
 

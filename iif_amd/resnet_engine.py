@@ -755,13 +755,15 @@ class _Plan(object):
         self._bw_ready = None
         # BN backward through the expanding 1x1 layer of a bottleneck by algebra (csrc/bn3_algebra.hip): the block-output
         # gradient arrives already gated by the block's ReLU (the producing data gradient stores it so), and conv3's output is
-        # never read in backward.  Units: the last conv+BN of every plain bottleneck with <= 256 input channels whose output
-        # has >= 1.5e8 elements: the route saves about 3.5 passes over that tensor and costs about 0.2 ms of small launches
-        # and an exposed P = g~^T a2 product on the compute stream (measured), so it pays for the 56 x 56 stage of
-        # the 224-pixel / batch-256 configuration and not for the later ones.
+        # never re-read by a BN-backward pass.  Units: the last conv+BN of every bottleneck with <= 256 input channels.
+        # Two variants (measured): "pure" takes sum g~ y from P = g~^T a2 (conv3's output is not read at all in
+        # backward, 4 passes over that tensor saved, but P sits on the compute stream before the data gradient) - it wins
+        # where the tensor is large (>= 1.5e8 elements: the 56 x 56 stage at batch 256); otherwise the producing data gradient
+        # still reads conv3's output once for sum g~ xhat (3 passes saved) and P moves to the weight-gradient stream.
         self.alg3_units = set()
         a3_maxc = min(256, int(os.environ.get("IIF_BN3_ALGEBRA_MAXC", "256")))
-        a3_min = float(os.environ.get("IIF_BN3_ALGEBRA_MIN_ELEMS", "1.5e8"))
+        a3_min = float(os.environ.get("IIF_BN3_ALGEBRA_MIN_ELEMS", "0"))
+        self.a3_pure_min = float(os.environ.get("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "1.5e8"))
         if self.fuse_bwd and net._sync_bn is None and not os.environ.get("IIF_NO_BN3_ALGEBRA"):
             for b in self.blocks:
                 if "se" in b or "sc" in b or len(b["units"]) != 3:
@@ -779,7 +781,7 @@ class _Plan(object):
             F = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)   # noqa: E731
             # per-block scratch rotates over 2 slots (the weight-gradient stream finishes block b before block b - 2 starts:
             # _wgrad_fence); Gram / colsum are issued one block AHEAD on another stream, so they rotate over 3
-            self.a3 = [{"P": F(Cm, ldm), "scr": F(64 * Cm), "coef": F(3, Cm), "bias": F(cm),
+            self.a3 = [{"P": F(Cm, ldm), "scr": F(128 * Cm), "coef": F(3, Cm), "bias": F(cm),
                         "wt": torch.zeros(cm * (Cm + cm), dtype=dt, device=dev),
                         "bw": torch.zeros(Cm * cm, dtype=dt, device=dev),
                         "gms": torch.empty(max(ops.lib().iif_bn3_algebra_gm_scratch_floats(u.conv.cout, u.conv.cin)
@@ -1238,7 +1240,8 @@ class _Plan(object):
                 # the upstream unit's BN backward runs by algebra: store the gradient gated by its block's ReLU, emit its
                 # column sums only (conv3's output is not read)
                 nt = ops.conv_dgrad_masksum(dx4, u.wt, (u.hi, u.wi), dgrad_out, up_bits, self.bw_partial, res=dgrad_res,
-                                            res_bits=dgrad_res_bits)
+                                            res_bits=dgrad_res_bits, up_x=None if self._a3_is_pure(up) else up.x,
+                                            up_stats=None if self._a3_is_pure(up) else up.stats)
                 self._bw_ready = (up, nt, True)
                 return dgrad_out
             nt = ops.conv_dgrad_bnbwd(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), dgrad_out, up.x, up_bits, up.stats,
@@ -1247,6 +1250,9 @@ class _Plan(object):
             return dgrad_out
         return ops.conv_dgrad(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), out=dgrad_out, res=dgrad_res,
                               groups=u.groups, res_bits=dgrad_res_bits, w_frag=u.wtf)
+
+    def _a3_is_pure(self, u):
+        return u.n * u.ho * u.wo * u.conv.cout >= self.a3_pure_min
 
     def _bn3_gram_async(self, u, bi):
         """Gram = a2^T a2 and colsum(a2) of an algebra unit's input: forward data only, so it is issued a block ahead on the
@@ -1283,15 +1289,19 @@ class _Plan(object):
         g4 = gt.view(u.n, u.ho, u.wo, C)
         wb = u.w                                                   # the bf16 weights the forward multiplied with, [C, ldw]
         P = A["P"].view(-1)[:C * cv.ldw].view(C, cv.ldw)          # contiguous [C, ldw]: conv_wgrad writes with pitch ldw
-        ops.conv_wgrad(u.src, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=self.a3_ws)
+        pure = self._a3_is_pure(u)
+        if pure:
+            ops.conv_wgrad(u.src, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=self.a3_ws)
         wt = A["wt"][:c * (C + c)].view(c, C + c)
         coef = A["coef"][:, :C]
-        ops.bn3_algebra_coef(P, wb, c, self.bw_partial, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt, A["bw"], A["scr"])
+        ops.bn3_algebra_coef(P if pure else None, wb, c, self.bw_partial, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt, A["bw"], A["scr"])
         ops.bn3_algebra_gm(wb, c, A["bw"], coef, wt, A["bias"][:c], A["gms"])
         # the weight gradient needs Gram / colsum (issued a block ahead) and nothing on the critical path needs it
         gram_ev = Ag["ev"]
 
         def finish_dw():
+            if not pure:
+                ops.conv_wgrad(u.src, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=self.wg_ws if self.wg_stream is not None else self.a3_ws)
             ops.bn3_algebra_dw(P, wb, c, Ag["gram"].view(-1)[:c * cv.ldw].view(c, cv.ldw), Ag["csum"][0, :c], coef, cv._g2d)
         if self.wg_stream is None:
             finish_dw()

@@ -393,10 +393,14 @@ int iif_conv3x3_frag_ok(const iif_conv_desc* d);
  * with P = g~^T a2 (iif_conv_wgrad), Gram = a2^T a2 (iif_conv_wgrad of a2 with itself) and csum = colsum(a2) (iif_bn_stats_sums):
  *   sum g~ y = rowdot(P, W);  dW = diag(A) P + diag(B) W Gram + D (x) csum;  da2 = [g~ | a2] [A o W ; W^T diag(B) W]^T + D W.
  *   iif_conv_igemm_dgrad_masksum  the data gradient that PRODUCES the block-output gradient stores it gated by up_bits and
- *                                 emits (sum dst, 0) per tile into `partial` (no read of y);
- *   iif_bn3_algebra_coef          those partial rows (their column sums are sum g~; scratch >= 64 C floats), P, W (the bf16 copy
- *                                 the forward used) -> coef [3][C] = (A, B, D), dgamma, dbeta, the g~ half of the stacked bf16
- *                                 weights wt [c][ldwt >= C + c]: wt[j][ch] = A[ch] W[ch][j], and bw [C][c] = bf16(B[ch] W[ch][j]);
+ *                                 emits per tile into `partial` either (sum dst, 0) (up_x NULL: no read of y) or, with up_x /
+ *                                 up_stats (y and its batch statistics), (sum dst, sum dst * xhat) as iif_conv_igemm_dgrad_bnbwd;
+ *   iif_bn3_algebra_coef          those partial rows (scratch >= 128 C floats), W (the bf16 copy the forward used) and EITHER
+ *                                 P (sum g~ y = rowdot(P, W): y is never read, but P is needed before the data gradient) OR
+ *                                 P = NULL (sum g~ xhat from the second half of the rows: y is read once by the producer and
+ *                                 P is only needed for dW, off the critical path) -> coef [3][C] = (A, B, D), dgamma, dbeta,
+ *                                 the g~ half of the stacked bf16 weights wt [c][ldwt >= C + c]: wt[j][ch] = A[ch] W[ch][j],
+ *                                 and bw [C][c] = bf16(B[ch] W[ch][j]);
  *   iif_bn3_algebra_gm            the a2 half: wt[j][C + i] = sum_ch bw[ch][j] W[ch][i], and bias[j] = sum_ch D[ch] W[ch][j]
  *                                 (scratch: iif_bn3_algebra_gm_scratch_floats(C, c) floats of channel-slice slabs);
  *   iif_conv_igemm_dgrad2_bnbwd   dst = [src | src2] wgt^T + bias (1x1, stride 1, bf16; K runs over src's cs then src2's cs2
@@ -404,8 +408,9 @@ int iif_conv3x3_frag_ok(const iif_conv_desc* d);
  *   iif_bn3_algebra_dw            dW [C][lddw] from P, W, Gram, csum, coef.
  * c <= 256 (the 56x56 ... 14x14 stages of the ImageNet networks).  Everything sums in a fixed order. */
 int iif_conv_igemm_dgrad_masksum(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
-                                 const unsigned char* res_bits, const unsigned char* up_bits, float* partial,
-                                 int64_t partial_floats, int32_t* n_partials, void* stream);
+                                 const unsigned char* res_bits, const void* up_x, const unsigned char* up_bits,
+                                 const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,
+                                 void* stream);
 int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* src, const void* src2, int cs2, const void* wgt,
                                 const float* bias, void* dst, const void* up_x, const unsigned char* up_bits,
                                 const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,

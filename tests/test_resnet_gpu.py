@@ -343,12 +343,14 @@ def test_bf16_fused_bn_backward_sums_match_the_reduction_pass(arch, C, B, hw):
         assert e <= (1e-1 if m_ is net.bn1 else 6e-2), (type(m_).__name__, attr, e)
 
 
-def test_bn3_backward_by_algebra_inside_the_step(monkeypatch):
-    """The algebraic conv3 + bn3 backward (csrc/bn3_algebra.hip; by default only for outputs of >= 1.5e8 elements, here forced
-    for every eligible bottleneck) against the standard route on the same step: the two differ by bf16 roundings only, which
-    the 50 layers amplify to ~1e-2 (same size as the fused-sums route's distance from the reduction pass, see above)."""
+@pytest.mark.parametrize("pure", [False, True], ids=["sums_from_producer", "sums_from_P"])
+def test_bn3_backward_by_algebra_inside_the_step(monkeypatch, pure):
+    """The algebraic conv3 + bn3 backward (csrc/bn3_algebra.hip; both variants: sum g~ xhat from the producing data gradient,
+    the default below 1.5e8 elements, and sum g~ y from P = g~^T a2, the default above) against the standard route on the
+    same step: they differ by bf16 roundings only, which the 50 layers amplify to ~1e-2 (same size as the fused-sums route's
+    distance from the reduction pass, see above)."""
     from iif_amd.custom import IIFLoss
-    monkeypatch.setenv("IIF_BN3_ALGEBRA_MIN_ELEMS", "0")
+    monkeypatch.setenv("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "0" if pure else "1e30")
     arch, C, B, hw = "resnet50", 1000, 32, 64
     counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
     net, sd = _build(arch, C, torch.bfloat16)
@@ -383,7 +385,7 @@ def test_bf16_step_is_bit_reproducible(arch, C, B, hw, alg3, monkeypatch):
     (alg3: with the algebraic BN3 backward forced on for every eligible bottleneck)."""
     from iif_amd.custom import IIFLoss
     if alg3:
-        monkeypatch.setenv("IIF_BN3_ALGEBRA_MIN_ELEMS", "0")
+        monkeypatch.setenv("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "0")          # sums from P everywhere (the default is mixed)
     counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
     net, sd = _build(arch, C, torch.bfloat16)
     x, y = _data(B, hw, counts, seed=33)
