@@ -69,7 +69,7 @@ class ConvTimer(object):
     def wrap(self, ops):
         timer = self
         orig = {k: getattr(ops, k) for k in ("conv_forward", "conv_dgrad", "conv_wgrad", "conv_forward_bnstats",
-                                             "conv_dgrad_bnbwd")}
+                                             "conv_dgrad_bnbwd", "conv_dgrad_masksum", "conv_dgrad2_bnbwd")}
 
         def alg_k(r, s, stride, pad, cin):
             # algorithmic K of one output: the space-to-depth stem (4x4/1 pad 2 on 16 padded channels) is charged
@@ -103,6 +103,8 @@ class ConvTimer(object):
         def conv_wgrad(x, dy, r, s, stride, pad, **kw):
             n, ho, wo, cout = dy.shape
             fl = 2.0 * n * ho * wo * cout * alg_k(r, s, stride, pad, x.shape[3]) / kw.get("groups", 1)
+            if x.data_ptr() == dy.data_ptr():
+                fl = 0.0           # a2^T a2 of the algebraic BN3 backward: work this design adds, not algorithmic
             by = nbytes(x, dy) + 4.0 * cout * r * s * x.shape[3] / kw.get("groups", 1)
             return timer._timed("wgrad", fl, by, orig["conv_wgrad"], x, dy, r, s, stride, pad, **kw)
 
@@ -117,7 +119,22 @@ class ConvTimer(object):
             return timer._timed("dgrad", fl, by, orig["conv_dgrad_bnbwd"], dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits,
                                 up_stats, partial, **kw)
 
+        def conv_dgrad_masksum(dy, wt, in_hw, out, up_bits, partial, **kw):
+            n, ho, wo, cout = dy.shape
+            fl = 2.0 * n * ho * wo * cout * wt.shape[0]
+            by = nbytes(dy, wt, kw.get("res"), kw.get("up_x"), out)
+            return timer._timed("dgrad", fl, by, orig["conv_dgrad_masksum"], dy, wt, in_hw, out, up_bits, partial, **kw)
+
+        def conv_dgrad2_bnbwd(src, src2, wt, bias, out, *a, **kw):
+            # the data gradient of conv3 with BN3's backward folded into the weights: charged the FLOPs of the plain
+            # data gradient (K = src's channels); the second K source is overhead of the design, its bytes are counted
+            n, h, wd, c1 = src.shape
+            fl = 2.0 * n * h * wd * c1 * wt.shape[0]
+            by = nbytes(src, src2, wt, out, a[0] if a else kw.get("up_x"))
+            return timer._timed("dgrad", fl, by, orig["conv_dgrad2_bnbwd"], src, src2, wt, bias, out, *a, **kw)
+
         ops.conv_forward, ops.conv_dgrad, ops.conv_wgrad = conv_forward, conv_dgrad, conv_wgrad
+        ops.conv_dgrad_masksum, ops.conv_dgrad2_bnbwd = conv_dgrad_masksum, conv_dgrad2_bnbwd
         ops.conv_forward_bnstats = conv_forward_bnstats
         ops.conv_dgrad_bnbwd = conv_dgrad_bnbwd
         self._orig, self._ops = orig, ops
@@ -129,7 +146,8 @@ class ConvTimer(object):
     def _timed(self, kind, flops, ideal_bytes, fn, *a, **kw):
         if not self.active:
             return fn(*a, **kw)
-        self.shapes.append("%s %s x %s k%s s%s" % (kind, tuple(a[0].shape), tuple(a[1].shape), a[2], a[4]))
+        self.shapes.append("%s %s x %s k%s s%s" % (kind, tuple(a[0].shape), tuple(a[1].shape), a[2] if isinstance(a[2], int) else 1,
+                                                   a[4] if len(a) > 4 and isinstance(a[4], int) else 1))
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -161,7 +179,9 @@ def streaming_pass_bytes(net, batch, image):
     """Algorithmic HBM bytes per step of everything that is NOT a convolution launch, for the dataflow this design
     cannot go below: per conv+BN unit with an output of E elements (s = element size)
         forward  normalise (+ReLU):   read y, write a                     2 s E   (batch statistics ride on the conv epilogue: 0)
-        backward normalise:           read g, read y, write dy            3 s E   (the two BN-backward sums ride on the dgrad epilogue: 0)
+        backward normalise:           read g, read y, write dy            3 s E   (the two BN-backward sums ride on the dgrad epilogue: 0;
+                                                                                   units routed through the algebraic BN3 backward: 0 + a column-sum
+                                                                                   pass over the unit's input)
         block outputs:                + read the residual                  1 s E
     plus the stem's max-pool (forward: the stem's activation is never stored, only the pooled tensor is written; backward:
     read pooled gradient, write stem gradient), the global average pool, SGD = 20 B / parameter (read p, g, m; write p, m)
@@ -170,9 +190,14 @@ def streaming_pass_bytes(net, batch, image):
     plan = net._plan(batch, image, image)
     s = 2 if plan.dt == torch.bfloat16 else 4
     total = 0.0
+    alg3 = getattr(plan, "alg3_units", set())
     for u in plan.units:
         e = float(u.n * u.ho * u.wo * u.conv.cout)
         total += (2 + 3) * s * e + 2 * e / 8.0
+        if u in alg3:
+            # BN3 backward by algebra: no backward normalise pass; one column-sum pass over the unit's input
+            # (its Gram matrix and the second K source of the data gradient are convolution launches, counted there)
+            total += -3 * s * e + s * float(u.n * u.ho * u.wo * u.conv.cin)
     for b in plan.blocks:
         last = b["units"][-1]
         total += s * float(last.n * last.ho * last.wo * last.conv.cout)        # residual read of the block-end normalise
