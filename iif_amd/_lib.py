@@ -71,6 +71,8 @@ SIGNATURES = {
     "iif_weight_transpose_batched": [_P, _P, _I, _I, _I, _P, _P],
     "iif_conv_igemm_masked_res": [_P, _P, _P, _P, _P, _P, _P],
     "iif_conv_reload_env": [],
+    "iif_conv_igemm_stats_only": [_P, _P, _P, _P, _L, _P, _P],
+    "iif_conv_igemm_bn_relu": [_P, _P, _P, _P, _P, _P, _P, _P],
     "iif_conv_igemm_dgrad_masksum": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "iif_conv_igemm_dgrad2_bnbwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "iif_bn3_algebra_coef": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _P, _L, _P],

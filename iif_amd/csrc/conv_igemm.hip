@@ -55,6 +55,13 @@ struct ConvArgs {
     // dst = [src | src2] * wgt^T.  sbias (nullable): per-output-channel fp32 added in the staged epilogue.
     const unsigned char* src2; int Cs2;
     const float* sbias;
+    // the two-pass forward of a conv + BN unit whose raw output is never stored (round 3):
+    //   no_store: the tile is rounded to bf16 and summed into bn_partial exactly as if it were stored, and dropped;
+    //   aff (stats base: a at [2 Cd + c], b at [3 Cd + c]): dst = relu(fmaf(a, bf16(conv), b) + res) with the arithmetic of
+    //   bn_apply_kernel, relu_out one byte of ReLU decisions per 16-byte vector (as bn_apply writes them).
+    int no_store;
+    const float* aff;
+    unsigned char* relu_out;
     int bn_row0;           // first partial row of this launch (launches that share one partial buffer)
     int* rows_out;         // host only: receives bn_row0 + tiles of the launch (the partial rows written so far)
     long long bn_cap;      // host only: floats available behind bn_partial
@@ -353,6 +360,10 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
 #pragma unroll
         for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[n + q]; bistd[q] = a.bw_stats[a.Cd + n + q]; }
     }
+    if (a.aff && n < a.Cd) {                        // never together with bw_x: the same registers carry (a, b)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bmean[q] = a.aff[2 * a.Cd + n + q]; bistd[q] = a.aff[3 * a.Cd + n + q]; }
+    }
     float sb[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) sb[q] = 0.f;
@@ -373,7 +384,21 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
                 for (int q = 0; q < 4; ++q)
                     v[q] = pack_bf16x2(bf16_bits_to_f32(v[q] & 0xffffu) + sb[2 * q], __uint_as_float(v[q] & 0xffff0000u) + sb[2 * q + 1]);
             }
-            if (a.res) {
+            if (a.aff) {                            // block-uniform: BN affine + identity + ReLU of the block output
+                u32x4 rr = {0u, 0u, 0u, 0u};
+                if (a.res) rr = *reinterpret_cast<const u32x4*>(a.res + o);     // the block input: read again by the next conv1's data gradient... keep it cached
+                unsigned bits = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float lo = fmaf(bmean[2 * q], bf16_bits_to_f32(v[q] & 0xffffu), bistd[2 * q]);
+                    float hi = fmaf(bmean[2 * q + 1], __uint_as_float(v[q] & 0xffff0000u), bistd[2 * q + 1]);
+                    if (a.res) { lo += bf16_bits_to_f32(rr[q] & 0xffffu); hi += __uint_as_float(rr[q] & 0xffff0000u); }
+                    bits |= (lo > 0.f ? 1u : 0u) << (2 * q);
+                    bits |= (hi > 0.f ? 1u : 0u) << (2 * q + 1);
+                    v[q] = pack_bf16x2(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
+                }
+                if (a.relu_out) a.relu_out[o >> 4] = (unsigned char)bits;
+            } else if (a.res) {
 #ifndef IIF_NO_NT_EPILOGUE_LOADS   // the residual's last use
                 const u32x4 rr = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res + o));
 #else
@@ -397,11 +422,13 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
                     if (!a.bw_x) { bs[2 * q] += bf16_bits_to_f32(lo); bs[2 * q + 1] += __uint_as_float(hi); }
                 }
             }
+            if (!a.no_store) {
 #ifndef IIF_NO_NT_CONV_STORE     // the tile is next read by another XCD (BN apply): streaming it out keeps the pixel operand's lines in L2 (-0.7 % on the step)
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + o));
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + o));
 #else
-            *reinterpret_cast<u32x4*>(a.dst + o) = v;
+                *reinterpret_cast<u32x4*>(a.dst + o) = v;
 #endif
+            }
             if (a.bw_x) {                           // (with mask_store v is gated already; gating it again below changes nothing)
 #ifndef IIF_NO_NT_EPILOGUE_LOADS   // streamed once by this kernel (next reader: the BN backward, from another XCD)
                 const u32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.bw_x + o));
@@ -1485,6 +1512,10 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
 #pragma unroll
         for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[n + q]; bistd[q] = a.bw_stats[a.Cd + n + q]; }
     }
+    if (a.aff && col_ok) {                                // two-pass forward, pass 2 (never with bw_x): (a, b) of the BN affine
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bmean[q] = a.aff[2 * a.Cd + n + q]; bistd[q] = a.aff[3 * a.Cd + n + q]; }
+    }
     // combine the store waves' sums of tile `mt` (already in scratch) into its partial row
     auto emit_partial = [&](int mt) {
         if (ts < BN && n0 + ts < a.Cd) {
@@ -1549,7 +1580,20 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
             for (int i = 0; i < NR; ++i, sp += RPP * PITCH, o += ostep) {
                 if (m0 + r0 + i * RPP >= a.M) break;                          // only the last tile is short
                 u32x4 v = *reinterpret_cast<const u32x4*>(sp);
-                if (has_res) {
+                if (a.aff) {                              // block-uniform; the arithmetic of bn_apply_kernel
+                    const u32x4 rr = pres[i];             // zeros without a residual
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float lo = fmaf(bmean[2 * q], bf16_bits_to_f32(v[q] & 0xffffu), bistd[2 * q]);
+                        float hi = fmaf(bmean[2 * q + 1], __uint_as_float(v[q] & 0xffff0000u), bistd[2 * q + 1]);
+                        if (has_res) { lo += bf16_bits_to_f32(rr[q] & 0xffffu); hi += __uint_as_float(rr[q] & 0xffff0000u); }
+                        bits |= (lo > 0.f ? 1u : 0u) << (2 * q);
+                        bits |= (hi > 0.f ? 1u : 0u) << (2 * q + 1);
+                        v[q] = pack_bf16x2(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
+                    }
+                    if (a.relu_out) a.relu_out[o >> 4] = (unsigned char)bits;
+                } else if (has_res) {
                     const u32x4 rr = pres[i];
                     const unsigned rb = pbit[i] & 0xffu;
 #pragma unroll
@@ -1559,11 +1603,13 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
                         v[q] = pack_bf16x2(lo, hi);
                     }
                 }
+                if (!a.no_store) {
 #ifndef IIF_NO_NT_CONV_STORE     // the tile is next read by another XCD (BN apply): streaming it out keeps the pixel operand's lines in L2 (-0.7 % on the step)
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + o));
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + o));
 #else
-                *reinterpret_cast<u32x4*>(a.dst + o) = v;
+                    *reinterpret_cast<u32x4*>(a.dst + o) = v;
 #endif
+                }
                 if (has_up) {
                     const u32x4 xv = pupx[i];
                     const unsigned mb = pbit[i] >> 8;
@@ -1621,7 +1667,7 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
 // Experiment / test switches of this file, read from the environment ONCE (they used to cost several getenv per launch on
 // the hot host path); iif_conv_reload_env() re-reads them (tests and A/B scripts flip them between calls).
 struct ConvSwitches {
-    bool no_stream, force_stream, stream_fwd_only, stream_r2, no_shortk, regstage, no_v2, no_halo, force_halo, v2_wide, v2_force, no_merge_classes;
+    bool no_stream, force_stream, stream_fwd_only, stream_r2, no_shortk, regstage, no_v2, no_halo, force_halo, v2_wide, v2_force, no_merge_classes, stream_twopass;
     int force_bn64_k, twostage_k;
     static ConvSwitches read() {
         ConvSwitches c;
@@ -1634,6 +1680,7 @@ struct ConvSwitches {
         // 4-blocks-per-CU tile kernel (weighted 5.16 against 5.05 ms per step alone, 21.28 against 21.19 ms in the step):
         // IIF_CONV_STREAM1X1_ALL opts in.
         c.stream_r2 = getenv("IIF_CONV_STREAM1X1_ALL") == nullptr;
+        c.stream_twopass = getenv("IIF_CONV_STREAM_TWOPASS") != nullptr;     // two-pass epilogue options on the streaming kernel
         c.no_shortk = getenv("IIF_CONV_NO_SHORTK") != nullptr;
         c.regstage = getenv("IIF_CONV_REGSTAGE") != nullptr;
         c.no_v2 = getenv("IIF_CONV_NO_V2") != nullptr;
@@ -1658,6 +1705,7 @@ inline bool use_stream1x1(const ConvArgs& a, bool utap, int esz, bool outf32, St
     const bool off_ = g_sw.no_stream, force_ = g_sw.force_stream, no_dgrad = g_sw.stream_fwd_only, old_only = g_sw.stream_r2;
     if (off_ || !utap || esz != 2 || outf32 || a.groups > 1 || a.scatter || a.in_shift != 0 || a.sshift != 0) return false;
     if (a.R != 1 || a.S != 1 || a.pad != 0 || a.ntaps != 1 || a.bias || a.src2 || a.sbias || a.mask_store) return false;
+    if ((a.no_store || a.aff) && !g_sw.stream_twopass) return false;
     if (a.Hs != a.Hd || a.Ws != a.Wd || (a.Cs % 32) || a.spitch != a.Cs || a.dpitch != a.Cd) return false;
     const int K = a.Cs, N = a.Cd;
     if (K <= 64 && N == 256) *pl = {256, 64, 1};
@@ -1865,7 +1913,7 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
     const bool dma_ok = !g_sw.regstage && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL;
     const bool utap = !no_fast && dma_ok && (a.Cs % ET<T>::KE) == 0 && a.R * a.S <= 16 && a.R <= 16 && a.S <= 16;
     a.scatter = 0; a.ds_shift = 0; a.doy = a.dox = 0; a.Hfull = a.Hd; a.Wfull = a.Wd; a.ntaps = 0; a.in_shift = 0;
-    if (!utap) return (a.src2 || a.sbias || a.mask_store) ? IIF_EUNSUPPORTED : launch_one<T, OUTF32>(a, false, src_bytes, wgt_bytes, st);
+    if (!utap) return (a.src2 || a.sbias || a.mask_store || a.no_store || a.aff) ? IIF_EUNSUPPORTED : launch_one<T, OUTF32>(a, false, src_bytes, wgt_bytes, st);
     if (!a.transposed || a.sshift == 0) {
         for (int r = 0; r < a.R; ++r)
             for (int s = 0; s < a.S; ++s) {
@@ -1955,7 +2003,7 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
 }  // namespace
 
 namespace {
-struct ConvExtra { int mask_store; const void* src2; int cs2; const float* sbias; };
+struct ConvExtra { int mask_store; const void* src2; int cs2; const float* sbias; int no_store; const float* aff; unsigned char* relu_out; };
 int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                const unsigned char* res_bits, const float* bias, float* bn_partial, int64_t bn_partial_floats,
                int32_t* n_partials, void* stream, const void* bw_x = nullptr, const unsigned char* bw_bits = nullptr,
@@ -2002,7 +2050,7 @@ extern "C" int iif_conv_igemm_dgrad_masksum(const iif_conv_desc* d, const void* 
     if (!d || !up_bits || !partial || !n_partials || !d->transposed) return IIF_EINVAL;
     if (res_bits && !res) return IIF_EINVAL;
     if (up_x && !up_stats) return IIF_EINVAL;
-    const ConvExtra ex{1, nullptr, 0, nullptr};
+    const ConvExtra ex{1, nullptr, 0, nullptr, 0, nullptr, nullptr};
     return conv_entry(d, src, wgt, dst, res, res_bits, nullptr, partial, partial_floats, n_partials, stream, up_x, up_bits,
                       up_x ? up_stats : nullptr, &ex);
 }
@@ -2013,9 +2061,25 @@ extern "C" int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* s
                                            void* stream) {
     if (!d || !src2 || !d->transposed) return IIF_EINVAL;
     if (up_x && (!up_stats || !partial || !n_partials)) return IIF_EINVAL;
-    const ConvExtra ex{0, src2, cs2, bias};
+    const ConvExtra ex{0, src2, cs2, bias, 0, nullptr, nullptr};
     return conv_entry(d, src, wgt, dst, nullptr, nullptr, nullptr, up_x ? partial : nullptr, partial_floats, n_partials, stream, up_x,
                       up_bits, up_stats, &ex);
+}
+
+extern "C" int iif_conv_igemm_stats_only(const iif_conv_desc* d, const void* src, const void* wgt, float* bn_partial,
+                                         int64_t bn_partial_floats, int32_t* n_partials, void* stream) {
+    if (!d || !bn_partial || !n_partials || d->transposed) return IIF_EINVAL;
+    const ConvExtra ex{0, nullptr, 0, nullptr, 1, nullptr, nullptr};
+    // dst is never written; the source pointer stands in for the non-null / alignment checks
+    return conv_entry(d, src, wgt, const_cast<void*>(src), nullptr, nullptr, nullptr, bn_partial, bn_partial_floats, n_partials, stream,
+                      nullptr, nullptr, nullptr, &ex);
+}
+
+extern "C" int iif_conv_igemm_bn_relu(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                                      const float* stats, unsigned char* relu_bits, void* stream) {
+    if (!d || !stats || d->transposed) return IIF_EINVAL;
+    const ConvExtra ex{0, nullptr, 0, nullptr, 0, stats, relu_bits};
+    return conv_entry(d, src, wgt, dst, res, nullptr, nullptr, nullptr, 0, nullptr, stream, nullptr, nullptr, nullptr, &ex);
 }
 
 extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
@@ -2052,13 +2116,15 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
     if (d->dst_dtype != d->dtype && d->dst_dtype != IIF_F32) return IIF_EINVAL;
     const int pe = d->dtype == IIF_F32 ? 4 : 8;
     if (d->cs % pe != 0 || d->ldw % pe != 0 || d->ldw < d->r * d->s * d->cs + (ex && ex->src2 ? ex->cs2 : 0)) return IIF_EUNSUPPORTED;
-    if (ex && (ex->src2 || ex->sbias || ex->mask_store)) {
+    if (ex && (ex->src2 || ex->sbias || ex->mask_store || ex->no_store || ex->aff)) {
         // round-3 epilogue / operand options: bf16 1x1 stride-1 launches on the LDS-staged epilogue only
         if (d->dtype != IIF_BF16 || d->dst_dtype != IIF_BF16 || d->r != 1 || d->s != 1 || d->stride != 1 || d->pad != 0 || d->groups > 1 ||
             (d->cd % 8) || bias || (d->cs % 32))
             return IIF_EUNSUPPORTED;
         if (ex->src2 && ((ex->cs2 % 32) || ex->cs2 <= 0 || (reinterpret_cast<uintptr_t>(ex->src2) & 15))) return IIF_EUNSUPPORTED;
         if (ex->mask_store && (!bw_bits || !bn_partial)) return IIF_EINVAL;
+        if (ex->no_store && (!bn_partial || res || bw_x)) return IIF_EINVAL;
+        if (ex->aff && (bn_partial || res_bits || bw_x || ex->no_store)) return IIF_EINVAL;
     }
     if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(wgt) | reinterpret_cast<uintptr_t>(dst) |
          reinterpret_cast<uintptr_t>(res)) & 15)
@@ -2088,6 +2154,7 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
     }
     if (ex) {
         a.mask_store = ex->mask_store; a.src2 = (const unsigned char*)ex->src2; a.Cs2 = ex->cs2; a.sbias = ex->sbias;
+        a.no_store = ex->no_store; a.aff = ex->aff; a.relu_out = ex->relu_out;
     }
     a.N = d->n; a.Hs = d->hs; a.Ws = d->ws; a.Cs = d->cs; a.Hd = d->hd; a.Wd = d->wd; a.Cd = d->cd;
     a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.transposed = d->transposed ? 1 : 0;

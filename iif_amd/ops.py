@@ -432,6 +432,29 @@ def conv_dgrad_bnbwd(dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits, up_st
 
 
 # ------------------------------------------------------------ BN backward through the expanding 1x1 layer, by algebra
+def conv_forward_stats_only(x, w, partial):
+    """Pass 1 of the two-pass conv + BN forward (1x1 / stride 1, bf16): the partial rows of conv_forward_bnstats, no output."""
+    require_gpu(x, w, partial)
+    n, h, w_, cin = x.shape
+    cout, ldw = w.shape
+    d = _desc(n, h, w_, cin, h, w_, cout, 1, 1, 1, 0, 0, ldw, dtype_code(x), dtype_code(x), 1)
+    nt = ctypes.c_int32(0)
+    check(lib().iif_conv_igemm_stats_only(ctypes.byref(d), ptr(x), ptr(w), ptr(partial), partial.numel(), ctypes.byref(nt),
+                                          stream_ptr()), "iif_conv_igemm_stats_only")
+    return nt.value
+
+
+def conv_forward_bn_relu(x, w, out, stats, res=None, relu_bits=None):
+    """Pass 2: out = relu(stats[2] * bf16(conv) + stats[3] + res), ReLU decisions into relu_bits (1x1 / stride 1, bf16)."""
+    require_gpu(x, w, out, res, stats)
+    n, h, w_, cin = x.shape
+    cout, ldw = w.shape
+    d = _desc(n, h, w_, cin, h, w_, cout, 1, 1, 1, 0, 0, ldw, dtype_code(x), dtype_code(out), 1)
+    check(lib().iif_conv_igemm_bn_relu(ctypes.byref(d), ptr(x), ptr(w), ptr(out), ptr(res), ptr(stats), ptr(relu_bits),
+                                       stream_ptr()), "iif_conv_igemm_bn_relu")
+    return out
+
+
 def conv_dgrad_masksum(dy, wt, in_hw, out, up_bits, partial, res=None, res_bits=None, up_x=None, up_stats=None):
     """1x1 / stride-1 conv_dgrad whose result is stored gated by ``up_bits`` (the ReLU decisions of the block output it is the
     gradient of) and whose per-tile column sums go to ``partial`` (second half of every row: zero, or with ``up_x`` /

@@ -407,6 +407,17 @@ int iif_conv3x3_frag_ok(const iif_conv_desc* d);
  *                                 channels), optionally with the upstream BN-backward sums of iif_conv_igemm_dgrad_bnbwd;
  *   iif_bn3_algebra_dw            dW [C][lddw] from P, W, Gram, csum, coef.
  * c <= 256 (the 56x56 ... 14x14 stages of the ImageNet networks).  Everything sums in a fixed order. */
+/* Two-pass forward of conv + BN (+ identity) + ReLU for the expanding 1x1 layer of a bottleneck (resnet_pytorch.py:160-167),
+ * bf16, 1x1 / stride 1: the raw convolution output is never stored.
+ *   iif_conv_igemm_stats_only   pass 1: the per-tile (sum, sum of squares) partial rows of iif_conv_igemm_bnstats — same
+ *                               bf16 rounding of the tile, same sums — without the store;
+ *   iif_conv_igemm_bn_relu      pass 2 (after iif_bn_finalize_stats): dst = relu(fma(a, bf16(conv), b) + res), a / b at
+ *                               stats[2 Cd + c] / stats[3 Cd + c], one byte of ReLU decisions per 8 channels into relu_bits
+ *                               (nullable): bit-identical to iif_conv_igemm followed by iif_bn_apply with that residual. */
+int iif_conv_igemm_stats_only(const iif_conv_desc* d, const void* src, const void* wgt, float* bn_partial,
+                              int64_t bn_partial_floats, int32_t* n_partials, void* stream);
+int iif_conv_igemm_bn_relu(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                           const float* stats, unsigned char* relu_bits, void* stream);
 int iif_conv_igemm_dgrad_masksum(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                                  const unsigned char* res_bits, const void* up_x, const unsigned char* up_bits,
                                  const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,

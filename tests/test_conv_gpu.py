@@ -719,3 +719,45 @@ def test_dgrad_masked_store_and_column_sums(case):
     ref2 = (expect.float() * xhat).sum(0)
     assert (ps2[0] - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item()) * 8
     assert (ps2[1] - ref2).abs().max().item() <= 2e-6 * max(1.0, ref2.abs().max().item()) * 8
+
+
+# ------------------------------------------------------------------- two-pass forward of conv + BN + identity + ReLU
+@pytest.mark.parametrize("case", [(2, 14, 64, 256), (3, 11, 128, 512), (1, 30, 64, 256), (2, 7, 256, 1024)],
+                         ids=lambda c: "%dx%dx%d_%d_%d" % (c[0], c[1], c[1], c[2], c[3]))
+@pytest.mark.parametrize("stream", [False, True], ids=["tile", "streaming"])
+def test_two_pass_forward_is_bit_identical_to_conv_then_bn_apply(case, stream, conv_env):
+    """iif_conv_igemm_stats_only + iif_conv_igemm_bn_relu against iif_conv_igemm_bnstats + iif_bn_apply (residual, ReLU,
+    ReLU bits): the partial rows, the activation and the bit bytes are bit-identical — the raw convolution output is rounded
+    to bf16 in the staging tile exactly as the stored one is."""
+    from iif_amd import ops
+    if stream:      # the persistent streaming kernel (it shares the staged drain): allowed for these options and forced onto small grids
+        conv_env(IIF_CONV_STREAM_TWOPASS="1", IIF_CONV_STREAM1X1_FORCE="1", IIF_CONV_STREAM1X1_ALL="1")
+    n, hw, c, C = case
+    m = n * hw * hw
+    g = torch.Generator().manual_seed(11 * c + hw)
+    dt = torch.bfloat16
+    x = torch.relu(torch.randn(n, hw, hw, c, generator=g)).to(dt).to(DEV)
+    w = (torch.randn(C, c, generator=g) / c ** 0.5).to(dt).to(DEV)
+    res = torch.randn(n, hw, hw, C, generator=g).to(dt).to(DEV)
+    rows = (m + 127) // 128 + 8
+    y = torch.empty(n, hw, hw, C, dtype=dt, device=DEV)
+    p1 = torch.full((rows, 2, C), float("nan"), device=DEV)
+    nt1 = ops.conv_forward_bnstats(x, w, 1, 1, 1, 0, y, p1.view(-1))
+    p2 = torch.full((rows, 2, C), float("nan"), device=DEV)
+    nt2 = ops.conv_forward_stats_only(x, w, p2.view(-1))
+    assert nt1 == nt2 and torch.equal(p1[:nt1], p2[:nt2])
+    gamma, beta = torch.rand(C, generator=g).to(DEV) + 0.5, torch.randn(C, generator=g).to(DEV) * 0.1
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    stats = torch.zeros(4, C, device=DEV)
+    ops.bn_finalize_stats(p1.view(-1), nt1, m, C, gamma, beta, rm, rv, stats, 1e-5, 0.1)
+    a_ref = torch.empty_like(y)
+    bits_ref = torch.zeros(m * C // 8, dtype=torch.uint8, device=DEV)
+    ops.bn_apply(y.view(m, C), stats, a_ref.view(m, C), relu=True, residual=res.view(m, C), relu_bits=bits_ref)
+    a_two = torch.full_like(y, float("nan"))
+    bits_two = torch.zeros_like(bits_ref)
+    ops.conv_forward_bn_relu(x, w, a_two, stats, res=res, relu_bits=bits_two)
+    assert torch.equal(a_two, a_ref) and torch.equal(bits_two, bits_ref)
+    # without the identity
+    ops.bn_apply(y.view(m, C), stats, a_ref.view(m, C), relu=True, relu_bits=bits_ref)
+    ops.conv_forward_bn_relu(x, w, a_two, stats, relu_bits=bits_two)
+    assert torch.equal(a_two, a_ref) and torch.equal(bits_two, bits_ref)

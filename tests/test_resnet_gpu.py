@@ -351,6 +351,7 @@ def test_bn3_backward_by_algebra_inside_the_step(monkeypatch, pure):
     distance from the reduction pass, see above)."""
     from iif_amd.custom import IIFLoss
     monkeypatch.setenv("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "0" if pure else "1e30")
+    monkeypatch.setenv("IIF_TWOPASS", "1")                  # with sums from P: conv3's output is not even stored in forward
     arch, C, B, hw = "resnet50", 1000, 32, 64
     counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
     net, sd = _build(arch, C, torch.bfloat16)
@@ -363,11 +364,13 @@ def test_bn3_backward_by_algebra_inside_the_step(monkeypatch, pure):
     plan = net._saved
     assert len(plan.alg3_units) == 13                       # layer1..layer3 (conv3 input channels <= 256)
     alg = net._grad_arena.clone()
-    keep, plan.alg3_units = plan.alg3_units, set()
-    net.loss_and_backward(xd, yd, crit)
+    assert len(plan.twopass_units) == (10 if pure else 0)   # the identity blocks of layer1..layer3 (2 + 3 + 5)
+    keep, plan.alg3_units, keep2, plan.twopass_units = plan.alg3_units, set(), plan.twopass_units, set()
+    loss_std, _ = net.loss_and_backward(xd, yd, crit)
     std = net._grad_arena.clone()
-    plan.alg3_units = keep
-    net.loss_and_backward(xd, yd, crit)
+    plan.alg3_units, plan.twopass_units = keep, keep2
+    loss_alg, _ = net.loss_and_backward(xd, yd, crit)
+    assert loss_alg.item() == loss_std.item()               # the two-pass forward is bit-identical to conv + bn_apply
     assert torch.equal(net._grad_arena, alg)                # fixed summation orders, event-ordered hand-overs
     assert (alg - std).norm().item() / std.norm().item() <= 3e-2
     for (m_, attr, rows, pitch) in net._param_specs():
