@@ -114,7 +114,7 @@ class ConvTimer(object):
 
         def conv_dgrad_bnbwd(dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits, up_stats, partial, **kw):
             n, ho, wo, cout = dy.shape
-            fl = 2.0 * n * ho * wo * cout * r * s * wt.shape[0]
+            fl = 2.0 * n * ho * wo * cout * r * s * wt.shape[0] / kw.get("groups", 1)
             by = nbytes(dy, wt, kw.get("res"), up_x) + out.numel() * out.element_size()
             return timer._timed("dgrad", fl, by, orig["conv_dgrad_bnbwd"], dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits,
                                 up_stats, partial, **kw)

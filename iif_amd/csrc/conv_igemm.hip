@@ -356,9 +356,9 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
     float bs[8], bq[8], bmean[8], bistd[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { bs[q] = 0.f; bq[q] = 0.f; bmean[q] = 0.f; bistd[q] = 0.f; }
-    if (a.bw_x && n < a.Cd) {
+    if (a.bw_x && n < a.Cd) {                       // (grouped: channel goff + n of the dpitch-wide upstream tensor)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[n + q]; bistd[q] = a.bw_stats[a.Cd + n + q]; }
+        for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[goff + n + q]; bistd[q] = a.bw_stats[a.dpitch + goff + n + q]; }
     }
     if (a.aff && n < a.Cd) {                        // never together with bw_x: the same registers carry (a, b)
 #pragma unroll
@@ -2144,7 +2144,7 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
         // pipelined kernels; one partial row per pixel tile, counted where the tile height is chosen (launch_one)
         const int64_t esz0 = 2;
         const bool ok = d->dtype == IIF_BF16 && d->dst_dtype == IIF_BF16 && (d->cd % 8) == 0 && !bias && (bw_x || (ex && ex->mask_store) || !res) &&
-                        (!bw_x || d->groups <= 1) && !g_sw.regstage &&
+                        !g_sw.regstage &&
                         (int64_t)d->n * d->hs * d->ws * d->cs * (d->groups > 1 ? d->groups : 1) * esz0 < 0x7f000000LL;
         if (!ok) return IIF_EUNSUPPORTED;
         a.bn_partial = bn_partial;

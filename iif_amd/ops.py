@@ -417,13 +417,14 @@ def weight_transpose_batched(arena, table, n_desc, total_blocks, out):
 
 # ------------------------------------------------------------ BN backward sums fused into the producing dgrad
 def conv_dgrad_bnbwd(dy, wt, r, s, stride, pad, in_hw, out, up_x, up_bits, up_stats, partial, res=None, res_bits=None,
-                     w_frag=None):
+                     w_frag=None, groups=1):
     """conv_dgrad that also writes the upstream unit's BN-backward partial sums; returns the partial row count."""
     require_gpu(dy, wt, res, up_x)
     n, ho, wo, cout = dy.shape
     cin, ldw = wt.shape
     h, w_ = in_hw
-    d = _desc(n, ho, wo, cout, h, w_, cin, r, s, stride, pad, 1, ldw, dtype_code(dy), dtype_code(out), 1, w_frag)
+    d = _desc(n, ho, wo, cout // groups, h, w_, cin // groups, r, s, stride, pad, 1, ldw, dtype_code(dy), dtype_code(out), groups,
+              w_frag)
     nt = ctypes.c_int32(0)
     check(lib().iif_conv_igemm_dgrad_bnbwd(ctypes.byref(d), ptr(dy), ptr(wt), ptr(out), ptr(res), ptr(res_bits), ptr(up_x),
                                            ptr(up_bits), ptr(up_stats), ptr(partial), partial.numel(), ctypes.byref(nt),

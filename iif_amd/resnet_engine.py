@@ -1259,7 +1259,8 @@ class _Plan(object):
                                                      workspace=self.wg_ws))
         if not need_dgrad:
             return None
-        if fuse_up is not None and self.fuse_bwd and u.groups == 1 and dgrad_out is not None and _dma_ok(dx4):
+        if (fuse_up is not None and self.fuse_bwd and (u.groups == 1 or cv.stride == 1) and dgrad_out is not None
+                and _dma_ok(dx4)):
             up, up_bits = fuse_up
             if up in self.alg3_units and cv.k == 1 and cv.stride == 1 and up_bits is not None:
                 # the upstream unit's BN backward runs by algebra: store the gradient gated by its block's ReLU, emit its
@@ -1270,7 +1271,7 @@ class _Plan(object):
                 self._bw_ready = (up, nt, True)
                 return dgrad_out
             nt = ops.conv_dgrad_bnbwd(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), dgrad_out, up.x, up_bits, up.stats,
-                                      self.bw_partial, res=dgrad_res, res_bits=dgrad_res_bits, w_frag=u.wtf)
+                                      self.bw_partial, res=dgrad_res, res_bits=dgrad_res_bits, w_frag=u.wtf, groups=u.groups)
             self._bw_ready = (up, nt)
             return dgrad_out
         return ops.conv_dgrad(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), out=dgrad_out, res=dgrad_res,

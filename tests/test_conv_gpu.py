@@ -464,6 +464,44 @@ def test_dgrad_emits_upstream_bn_backward_sums(case):
     assert (ps[1] - s2).abs().max().item() <= 2e-6 * max(1.0, s2.abs().max().item())
 
 
+@pytest.mark.parametrize("case", [(4, 4, 64, 14, 14, True), (3, 2, 64, 9, 11, False), (2, 8, 64, 28, 28, True)],
+                         ids=lambda c: "n%d_g%dx%d_%dx%d" % (c[0], c[1], c[2], c[3], c[4]))
+def test_grouped_dgrad_emits_upstream_bn_backward_sums(case):
+    """The same epilogue on a grouped 3x3 / stride-1 data gradient (ResNeXt's conv2, block-diagonal chunks of 64 channels,
+    blockIdx.y = chunk): the stored gradient is bit-identical to the plain grouped data gradient, the partial rows hold
+    (sum g, sum g*xhat) of the chunk-offset channels of the upstream unit."""
+    from iif_amd import ops
+    n, G, cg, h, w, use_bits = case
+    C = G * cg
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(G * 100 + h)
+    k, pad = 3, 1
+    ldw = k * k * cg
+    wtt = (torch.randn(C, ldw, generator=g) / ldw ** 0.5).to(dt).to(DEV)        # per chunk: [cg rows, 9 * cg] transposed weights
+    dy = torch.randn(n, h, w, C, generator=g).to(dt).to(DEV)
+    upx = torch.randn(n, h, w, C, generator=g).to(dt).to(DEV)
+    bits = torch.randint(0, 256, (n * h * w * C // 8,), dtype=torch.uint8, generator=g).to(DEV)
+    stats = torch.zeros(4, C)
+    stats[0] = torch.randn(C, generator=g) * 0.1
+    stats[1] = torch.rand(C, generator=g) + 0.5
+    plain = ops.conv_dgrad(dy, wtt, k, k, 1, pad, (h, w), groups=G)
+    out = torch.full((n, h, w, C), float("nan"), dtype=dt, device=DEV)
+    m = n * h * w
+    partial = torch.full(((m + 127) // 128 + 8, 2, C), float("nan"), device=DEV)
+    nt = ops.conv_dgrad_bnbwd(dy, wtt, k, k, 1, pad, (h, w), out, upx, bits if use_bits else None, stats.to(DEV), partial.view(-1),
+                              groups=G)
+    assert torch.equal(out, plain)
+    gq = plain.float().cpu().view(m, C)
+    if use_bits:
+        gq = gq * ((bits.cpu().view(-1, 1).int() >> torch.arange(8).view(1, 8)) & 1).view(m, C)
+    xhat = (upx.float().cpu().view(m, C) - stats[0]) * stats[1]
+    s1, s2 = gq.sum(0), (gq * xhat).sum(0)
+    ps = partial[:nt].sum(0).cpu()
+    assert nt == (m + 127) // 128 and not torch.isnan(ps).any()
+    assert (ps[0] - s1).abs().max().item() <= 2e-6 * max(1.0, s1.abs().max().item()) * 8
+    assert (ps[1] - s2).abs().max().item() <= 2e-6 * max(1.0, s2.abs().max().item()) * 8
+
+
 @pytest.mark.parametrize("n,h,w", [(8, 32, 32), (3, 112, 112), (2, 17, 23), (5, 1, 3), (1, 40, 120)])
 def test_stem_s2d_weight_gradient_all_taps_per_block(n, h, w):
     """4x4 / stride 1 / pad 2 (top-left) over the 16-channel space-to-depth image with output size = input size:
