@@ -458,8 +458,10 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
 // registers, 18 + 8 transposing LDS reads per step.  Output: the same split-K slabs as above.
 struct WgHaloArgs {
     const unsigned char* x; const unsigned char* dy; float* out;
-    int N, H, W, Cs, Cd, ldw;
+    int N, H, W, Cs, Cd, ldw;       // Cs / Cd: channels per pixel of the x / dy TENSORS
     int ci_tiles, co_tiles, steps_per_split, nsteps, nsplits, HB;     // HB: ring lead in rows (32 | 64)
+    int grouped;                    // grouped convolution in 64-channel chunks: tile t = chunk t (x channels 64 t .., dy channels 64 t ..),
+                                    // dW rows 64 t .., columns tap * 64 + ci (the packed block-diagonal layout of the chunk matrices)
     int64_t slab;
 };
 
@@ -481,7 +483,7 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, u
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int split = (jj / tiles) * 8 + xcd, tile = jj % tiles;
     if (split >= a.nsplits) return;
-    const int ci0 = (tile % a.ci_tiles) * 64, co0 = (tile / a.ci_tiles) * 64;
+    const int ci0 = a.grouped ? tile * 64 : (tile % a.ci_tiles) * 64, co0 = a.grouped ? tile * 64 : (tile / a.ci_tiles) * 64;
     const int step0 = split * a.steps_per_split;
     int step1 = step0 + a.steps_per_split;
     if (step1 > a.nsteps) step1 = a.nsteps;
@@ -597,7 +599,7 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, u
         const int k = co0 + kj * 16 + li;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int n = tap * a.Cs + ci0 + wave * 16 + g * 4;
+            const int n = a.grouped ? tap * 64 + wave * 16 + g * 4 : tap * a.Cs + ci0 + wave * 16 + g * 4;
             *reinterpret_cast<f32x4*>(out + (int64_t)k * a.ldw + n) = acc[tap][kj];
         }
     }
@@ -786,8 +788,9 @@ inline int reduce_slabs(float* ws, int64_t ws_bytes, int splits, int64_t slab, i
 inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_bytes, int splits_req, int64_t x_bytes,
                              int64_t dy_bytes, hipStream_t st) {
     WgHaloArgs h{};
-    h.x = a.x; h.dy = a.dy; h.N = a.N; h.H = a.Hd; h.W = a.Wd; h.Cs = a.Cs; h.Cd = a.Cd; h.ldw = a.ldw;
-    h.ci_tiles = a.Cs / 64; h.co_tiles = a.Cd / 64;
+    h.x = a.x; h.dy = a.dy; h.N = a.N; h.H = a.Hd; h.W = a.Wd; h.Cs = a.xpitch; h.Cd = a.ypitch; h.ldw = a.ldw;
+    h.grouped = a.groups > 1;
+    h.ci_tiles = h.grouped ? a.groups : a.Cs / 64; h.co_tiles = h.grouped ? 1 : a.Cd / 64;
     h.HB = a.Wd + 3 <= 32 ? 32 : 64;
     const int64_t vt = (int64_t)a.N * (a.Hd + 2) * (a.Wd + 2);
     if (vt > 0x7fff0000LL) return -100;            // beyond the 32-bit virtual index: caller falls back
@@ -801,7 +804,7 @@ inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_b
         const int max_by_work = h.nsteps / 8 > 0 ? h.nsteps / 8 : 1;
         if (splits > max_by_work) splits = max_by_work;
     }
-    const int64_t slab = (int64_t)a.Cd * a.ldw;
+    const int64_t slab = (int64_t)a.groups * a.Cd * a.ldw;
     const int64_t fit = ws ? ws_bytes / (slab * 4) : 0;
     if (splits > fit) splits = (int)fit;
     if (splits < 1) splits = 1;
@@ -818,7 +821,7 @@ inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_b
     // bound by the DMA path, not by latency.
     hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<8, 4, 2>), grid, dim3(256), 0, st, h, (unsigned)x_bytes, (unsigned)dy_bytes);
     IIF_LAUNCH_CHECK();
-    if (splits > 1) return reduce_slabs(ws, ws_bytes, splits, slab, a.Cd, a.ldw, a.K, dw, st);
+    if (splits > 1) return reduce_slabs(ws, ws_bytes, splits, slab, a.groups * a.Cd, a.ldw, a.K, dw, st);
     return IIF_OK;
 }
 
@@ -868,9 +871,12 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     const bool dma_ok = getenv("IIF_CONV_REGSTAGE") == nullptr && x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL;
     if constexpr (sizeof(T) == 2) {
         static const char* halo_env = getenv("IIF_WGRAD_HALO");          // "0": keep the tap-per-tile kernel
-        const bool halo = dma_ok && a.groups == 1 && a.R == 3 && a.S == 3 && a.sshift == 0 && a.pad == 1 && a.Hs == a.Hd &&
-                          a.Ws == a.Wd && a.Cs % 64 == 0 && a.Cd % 64 == 0 && a.Wd + 3 <= 64 && a.xpitch == a.Cs &&
-                          a.ypitch == a.Cd && !(halo_env && atoi(halo_env) == 0);
+        static const bool no_grouped_halo = getenv("IIF_WGRAD_NO_GROUPED_HALO") != nullptr;
+        // dense: channels in 64s; grouped: 64-channel chunks (the nine-tap tile IS a chunk)
+        const bool shape = a.groups == 1 ? (a.Cs % 64 == 0 && a.Cd % 64 == 0 && a.xpitch == a.Cs && a.ypitch == a.Cd)
+                                         : (a.Cs == 64 && a.Cd == 64 && a.ldw >= 576 && !no_grouped_halo);
+        const bool halo = dma_ok && shape && a.R == 3 && a.S == 3 && a.sshift == 0 && a.pad == 1 && a.Hs == a.Hd &&
+                          a.Ws == a.Wd && a.Wd + 3 <= 64 && !(halo_env && atoi(halo_env) == 0);
         if (halo) {
             const int rc = launch_wgrad_halo(a, dw, ws, ws_bytes, splits_req, x_bytes, dy_bytes, st);
             if (rc != -100) return rc;
