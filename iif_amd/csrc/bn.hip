@@ -423,6 +423,13 @@ __global__ void __launch_bounds__(256) bn_reduce_finalize_kernel(const float* pa
     }
 }
 
+// slices of the first reduction stage: 64, or 256 for very many partial rows (the stem of the 224-pixel networks: 25 088 rows
+// -> 392 rows per slice took 105 us in two blocks' worth of lanes) when the scratch rows are there.  Both the one-launch
+// and the two-launch path use this, so they stay bit-identical to each other.
+inline int stage1_slices(int n_partials, int c, int64_t scratch_floats) {
+    return (n_partials > 8192 && scratch_floats >= (int64_t)256 * 2 * c) ? 256 : 64;
+}
+
 // partial rows above which the sums are pre-reduced into 64 slices by a separate launch
 inline int two_stage_rows() {
     static const int v = getenv("IIF_BN_TWO_STAGE_ROWS") ? atoi(getenv("IIF_BN_TWO_STAGE_ROWS")) : 512;
@@ -642,7 +649,7 @@ int iif_bn_finalize_stats(const float* partial, int n_partials, int64_t m, int c
     if (!partial || !gamma || !beta || !stats || n_partials <= 0 || m <= 0 || c <= 0) return IIF_EINVAL;
     hipStream_t st = as_stream(stream);
     if (n_partials > two_stage_rows() && scratch && scratch_floats >= (int64_t)64 * 2 * c) {
-        const int slices = 64, rps = (n_partials + slices - 1) / slices;
+        const int slices = stage1_slices(n_partials, c, scratch_floats), rps = (n_partials + slices - 1) / slices;
         hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((c + 31) / 32, slices), dim3(256), 0, st, partial, n_partials, c,
                            rps, scratch);
         IIF_LAUNCH_CHECK();
@@ -660,7 +667,7 @@ int iif_bn_finalize_stats_fused(const float* partial, int n_partials, int64_t m,
     if (!tickets || n_partials <= two_stage_rows() || !scratch || scratch_floats < (int64_t)64 * 2 * c || (c + 31) / 32 > 64)
         return iif_bn_finalize_stats(partial, n_partials, m, c, gamma, beta, eps, momentum, running_mean, running_var, stats,
                                      scratch, scratch_floats, stream);
-    const int slices = 64, rps = (n_partials + slices - 1) / slices;
+    const int slices = stage1_slices(n_partials, c, scratch_floats), rps = (n_partials + slices - 1) / slices;
     hipLaunchKernelGGL(bn_reduce_finalize_kernel<0>, dim3((c + 31) / 32, slices), dim3(256), 0, as_stream(stream), partial,
                        n_partials, c, rps, scratch, tickets, (double)m, gamma, beta, eps, momentum, stats, running_mean, running_var);
     IIF_LAUNCH_CHECK();
