@@ -901,7 +901,14 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     if (splits <= 0) {
         // one full co-resident round: 256 CUs x (3 | 4) workgroups (LDS 48 | 36 KB each), so every
         // workgroup gets the same number of steps and there is no tail round
-        const int slots = 256 * (bc == 64 ? 4 : (bc == 256 ? 2 : 3));
+        // blocks per CU: 4 (64-channel tile), 3 (128), and ONE 8-wave block for the 256-channel tile: two per CU write twice
+        // the split-K slabs for nothing (step 20.67 -> 20.62 ms at one; 0.75 / 1.25 per CU leave a tail round: 21.2 / 20.8;
+        // scripts/ab_wgrad_slots.sh).  IIF_WGRAD_SLOT_PCT[_256|_128|_64]: experiment knobs, per cent of these.
+        static const int slot_pct = getenv("IIF_WGRAD_SLOT_PCT") ? atoi(getenv("IIF_WGRAD_SLOT_PCT")) : 100;
+        static const int pct256 = getenv("IIF_WGRAD_SLOT_PCT_256") ? atoi(getenv("IIF_WGRAD_SLOT_PCT_256")) : slot_pct;
+        static const int pct128 = getenv("IIF_WGRAD_SLOT_PCT_128") ? atoi(getenv("IIF_WGRAD_SLOT_PCT_128")) : slot_pct;
+        static const int pct64 = getenv("IIF_WGRAD_SLOT_PCT_64") ? atoi(getenv("IIF_WGRAD_SLOT_PCT_64")) : slot_pct;
+        const int slots = 256 * (bc == 64 ? 4 : (bc == 256 ? 1 : 3)) * (bc == 64 ? pct64 : (bc == 256 ? pct256 : pct128)) / 100;
         splits = slots / (tiles * a.groups);
         if (splits < 1) splits = 1;
         const int max_by_work = a.nsteps / 8 > 0 ? a.nsteps / 8 : 1;
