@@ -136,8 +136,16 @@ def lib():
     return _lib
 
 
-def check(rc, what):
+def check(rc, what, tickets=None):
+    """Raise on a non-zero status.  ``tickets``: the ticket words of a single-launch reduction this call was given — a
+    launch that failed part-way may leave them non-zero, and a non-zero ticket would silently stop every later
+    finalisation, so they are re-zeroed before the error propagates."""
     if rc != 0:
+        if tickets is not None:
+            try:
+                tickets.zero_()
+            except Exception:       # the device itself may be gone; the original error is the one to report
+                pass
         raise IIFNativeError("%s failed: %s" % (what, _ERR.get(rc, rc)))
 
 

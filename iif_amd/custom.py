@@ -66,7 +66,7 @@ def _launch_ce(pred, table, ta, tb, lam, row_weight, class_weight, ignore_index,
         _lib.ptr(pred), _lib.dtype_code(pred), pred.stride(0) if B else C, _lib.ptr(tab), _lib.ptr(ta),
         _lib.ptr(tb), float(lam), _lib.ptr(rw), _lib.ptr(cw), int(ignore_index), float(scale), B, C,
         _lib.ptr(rows), _lib.ptr(loss), _lib.ptr(dlogits), C, _lib.ptr(status), _lib.ptr(ticket), _lib.stream_ptr())
-    _lib.check(rc, "iif_ce_fwd_bwd")
+    _lib.check(rc, "iif_ce_fwd_bwd", ticket[:1])
     return loss, rows, dlogits
 
 

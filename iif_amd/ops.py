@@ -55,7 +55,7 @@ def bn_finalize_stats(partial, n_partials, m, c, gamma, beta, running_mean, runn
         check(lib().iif_bn_finalize_stats_fused(ptr(partial), n_partials, m, c, ptr(gamma), ptr(beta), eps, momentum,
                                                 ptr(running_mean), ptr(running_var), ptr(stats), ptr(scratch),
                                                 0 if scratch is None else scratch.numel(), ptr(tickets), stream_ptr()),
-              "iif_bn_finalize_stats_fused")
+              "iif_bn_finalize_stats_fused", tickets)
         return stats
     check(lib().iif_bn_finalize_stats(ptr(partial), n_partials, m, c, ptr(gamma), ptr(beta), eps, momentum,
                                       ptr(running_mean), ptr(running_var), ptr(stats), ptr(scratch),
@@ -517,5 +517,5 @@ def bn_backward_partials(gy, relu_bits, x2d, stats, gamma, partial, n_partials, 
     m, c = x2d.shape
     check(lib().iif_bn_backward_partials_fused(ptr(gy), ptr(relu_bits), ptr(x2d), dtype_code(x2d), m, c, ptr(stats), ptr(gamma),
                                                ptr(partial), n_partials, ptr(dgamma), ptr(dbeta), ptr(dx), ptr(ws), ws.numel(),
-                                               ptr(tickets), stream_ptr()), "iif_bn_backward_partials_fused")
+                                               ptr(tickets), stream_ptr()), "iif_bn_backward_partials_fused", tickets)
     return dx

@@ -573,7 +573,7 @@ class NativeResNet(nn.Module):
             _lib.ptr(targets_b), float(lam), 0, _lib.ptr(cw), -100, scale, B, C, _lib.ptr(plan.loss_rows),
             _lib.ptr(plan.loss), _lib.ptr(plan.dlogits), plan.dlogits.stride(0), _lib.ptr(plan.label_status),
             _lib.ptr(plan.loss_ticket), _lib.stream_ptr())
-        _lib.check(rc, "iif_ce_fwd_bwd")
+        _lib.check(rc, "iif_ce_fwd_bwd", plan.loss_ticket[:1])
         if den is not None:
             # plain CE with class weights, 'mean': the launch above used 1/B; rescale loss and dlogits by B / sum w[t]
             plan.loss_rescale.copy_((float(B) / den).reshape(1))

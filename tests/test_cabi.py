@@ -122,3 +122,55 @@ def test_c_oracle_matches_golden(golden):
                     ref_l, ref_d = float(g[key + "_loss"]), g[key + "_dpred"]
                     assert abs(loss - ref_l) <= 2e-6 * max(1.0, abs(ref_l)), key
                     assert np.abs(d - ref_d).max() <= 2e-6 * max(1.0, np.abs(ref_d).max()), key
+
+
+def _kernel_bodies(asm, name_part):
+    """{mangled name: [instruction lines]} of the functions whose mangled name contains ``name_part``."""
+    out, cur = {}, None
+    for line in asm.splitlines():
+        t = line.strip()
+        if line and not line[0].isspace() and t.startswith("_Z") and ":" in t and name_part in t.split(":")[0]:
+            cur = t.split(":")[0]
+            out[cur] = []
+        elif cur is not None:
+            if t.startswith("s_endpgm"):
+                cur = None
+            elif t and not t.startswith((".", ";")):
+                out[cur].append(t)
+    return out
+
+
+@pytest.mark.parametrize("src,kernel", [("bn.hip", "bn_reduce_finalize_kernel"), ("iif_head.hip", "row_reg_kernel")])
+def test_ticket_protocol_isa(tmp_path, src, kernel):
+    """The single-launch reductions (BN statistics / BN-backward sums, the IIF loss) publish partials with returning
+    agent-scope atomic exchanges, wait for them (`s_waitcnt vmcnt(0)`), take a ticket with an atomic add, and the last
+    block reads the partials back with scope-qualified loads.  The HIP memory model does not promise that order for relaxed
+    atomics; the hardware does, PROVIDED the compiler emits exactly this sequence.  This test pins the emitted gfx950 ISA:
+      swap ... sc0 (returning)  ->  s_waitcnt vmcnt(0)  ->  global_atomic_add ... sc0  ->  global_load ... sc1
+    (cross-compiles the one file to assembly: no GPU needed)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(ROOT, "iif_amd", "csrc")
+    asm_path = tmp_path / "k.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + csrc, "--offload-device-only",
+                    "-S", "-o", str(asm_path), os.path.join(csrc, src)], check=True, stderr=subprocess.DEVNULL)
+    bodies = _kernel_bodies(asm_path.read_text(), kernel)
+    assert bodies, "kernel %s not found in the assembly of %s" % (kernel, src)
+    checked = 0
+    for name, ins in bodies.items():
+        # the publishing exchanges and the ticket are the RETURNING forms (sc0); a non-returning swap is something else
+        # (the loss kernel's bad-target status flag)
+        swaps = [i for i, t in enumerate(ins) if t.startswith("global_atomic_swap") and " sc0" in t]
+        adds = [i for i, t in enumerate(ins) if t.startswith("global_atomic_add") and " sc0" in t]
+        if not swaps and not adds:
+            continue                                    # an instantiation without the ticket (e.g. no scalar reduction)
+        assert swaps and adds, name
+        ticket = adds[0]
+        assert max(swaps) < ticket, name
+        between = ins[max(swaps) + 1:ticket]
+        assert any(t.startswith("s_waitcnt") and "vmcnt(0)" in t for t in between), (name, between[:8])
+        loads_after = [t for t in ins[ticket:] if t.startswith("global_load")]
+        assert any(" sc1" in t for t in loads_after), (name, loads_after[:4])
+        checked += 1
+    assert checked >= 1
