@@ -760,6 +760,7 @@ class _Plan(object):
         # backward, 4 passes over that tensor saved, but P sits on the compute stream before the data gradient) - it wins
         # where the tensor is large (>= 1.5e8 elements: the 56 x 56 stage at batch 256); otherwise the producing data gradient
         # still reads conv3's output once for sum g~ xhat (3 passes saved) and P moves to the weight-gradient stream.
+        self.wg_lag = max(2, int(os.environ.get("IIF_WGRAD_LAG", "2")))       # (explained where the side streams are created)
         self.alg3_units = set()
         a3_maxc = min(256, int(os.environ.get("IIF_BN3_ALGEBRA_MAXC", "256")))
         a3_min = float(os.environ.get("IIF_BN3_ALGEBRA_MIN_ELEMS", "0"))
@@ -793,16 +794,17 @@ class _Plan(object):
             Cm = max(u.conv.cout for u in self.alg3_units)
             ldm = max(u.conv.ldw for u in self.alg3_units)
             F = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)   # noqa: E731
-            # per-block scratch rotates over 2 slots (the weight-gradient stream finishes block b before block b - 2 starts:
-            # _wgrad_fence); Gram / colsum are issued one block AHEAD on another stream, so they rotate over 3
+            # per-block scratch rotates over wg_lag slots (the weight-gradient stream finishes block b before block b - wg_lag
+            # starts: _wgrad_fence); Gram / colsum are issued one block AHEAD on another stream, so they rotate over wg_lag + 1
             self.a3 = [{"P": F(Cm, ldm), "scr": F(128 * Cm), "coef": F(3, Cm), "bias": F(cm),
                         "wt": torch.zeros(cm * (Cm + cm), dtype=dt, device=dev),
                         "bw": torch.zeros(Cm * cm, dtype=dt, device=dev),
                         "gms": torch.empty(max(ops.lib().iif_bn3_algebra_gm_scratch_floats(u.conv.cout, u.conv.cin)
-                                               for u in self.alg3_units), dtype=torch.float32, device=dev)} for _ in range(2)]
+                                               for u in self.alg3_units), dtype=torch.float32, device=dev)}
+                       for _ in range(self.wg_lag)]
             self.a3g = [{"gram": F(cm, ldm), "csum": F(2, cm), "ws_gram": torch.empty(64 << 20, dtype=torch.uint8, device=dev),
                          "ws_sum": ops.bn_workspace(max(u.n * u.ho * u.wo for u in self.alg3_units), cm, dev), "ev": None}
-                        for _ in range(3)]
+                        for _ in range(self.wg_lag + 1)]
             self.a3_ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)          # split-K slabs of P on the compute stream
         wmax = max(max(u.conv.cout * (u.dwp.shape[1] if u.dwp is not None else u.conv.ldw) for u in self.units),
                    head.out_padded * head.in_features)
@@ -821,7 +823,7 @@ class _Plan(object):
                            if (self.stem_wgrad_main and self.stem_s2d) else None)
         # blocks the weight-gradient stream may lag behind the compute stream: dx buffers rotate over `wg_lag` slots,
         # block-input gradients over wg_lag + 1, and block b waits for the weight gradients of the blocks >= b + wg_lag
-        self.wg_lag = max(2, int(os.environ.get("IIF_WGRAD_LAG", "2")))
+        assert self.wg_lag == max(2, int(os.environ.get("IIF_WGRAD_LAG", "2")))
         # backward of the convolutional shortcut (BN backward + dgrad + wgrad of 4 blocks) on a third stream
         self.ds_stream = None
         if self.wg_stream is not None and ds_units and dt == torch.bfloat16 and not os.environ.get("IIF_NO_BWD_SIDE"):
@@ -1283,7 +1285,7 @@ class _Plan(object):
     def _bn3_gram_async(self, u, bi):
         """Gram = a2^T a2 and colsum(a2) of an algebra unit's input: forward data only, so it is issued a block ahead on the
         shortcut stream (idle outside the four downsample blocks) and never waited for in practice."""
-        A = self.a3g[bi % 3]
+        A = self.a3g[bi % (self.wg_lag + 1)]
         cv = u.conv
         a2 = u.src
 
@@ -1309,7 +1311,7 @@ class _Plan(object):
         """Backward of conv3 + bn3 from the gated block-output gradient ``gt`` without reading conv3's output
         (csrc/bn3_algebra.hip).  Returns the gradient w.r.t. the unit's source (a2)."""
         cv, bn = u.conv, u.bn
-        A, Ag = self.a3[par % 2], self.a3g[bi % 3]
+        A, Ag = self.a3[par % self.wg_lag], self.a3g[bi % (self.wg_lag + 1)]
         C, c = cv.cout, cv.cin
         m = u.n * u.ho * u.wo
         g4 = gt.view(u.n, u.ho, u.wo, C)
