@@ -24,16 +24,19 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
-// Block = 32 channels.  Phase 1 (8 threads per channel): sum_g from the `slices` rows of column sums, sgy = sum_j P[ch][j] W[ch][j],
-// the coefficients, dgamma / dbeta.  Phase 2: the g~ half of the stacked data-gradient weights, wt[j][ch] = bf16(A[ch] W[ch][j]),
-// transposed through LDS in 32 x 32 tiles, and BW[ch][j] = bf16(B[ch] W[ch][j]) (the scaled operand of the Gm product).
+// Block = 32 channels x 32 columns (grid C/32 x c/32).  Phase 1 (8 threads per channel, every block of a channel group
+// repeats it: a lone block walking all c / 32 column tiles was a chain of dependent round trips, 26-40 us inside the step):
+// sum_g from the `slices` rows of column sums, sum g~ xhat from their second half or, with P, from
+// sgy = sum_j P[ch][j] W[ch][j]; the coefficients; the blocks of column tile 0 write coef / dgamma / dbeta.
+// Phase 2: this block's tile of the g~ half of the stacked data-gradient weights, wt[j][ch] = bf16(A[ch] W[ch][j]),
+// transposed through LDS, and of BW[ch][j] = bf16(B[ch] W[ch][j]) (the scaled operand of the Gm product).
 __global__ void __launch_bounds__(256) bn3_coef_kernel(const float* P, int ldp, const unsigned short* W, int ldw, const float* sg_slices,
                                                        int slices, int sg_pitch, const float* stats, const float* gamma, int C, int c,
                                                        double count, float* coef, float* dgamma, float* dbeta, unsigned short* wt,
                                                        int ldwt, unsigned short* BW) {
     __shared__ float cA[32], cB[32];
     __shared__ float tile[32][33];
-    const int ch0 = blockIdx.x * 32;
+    const int ch0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
     {
         const int lc = threadIdx.x >> 3, sub = threadIdx.x & 7;
         const int ch = ch0 + lc;
@@ -51,35 +54,34 @@ __global__ void __launch_bounds__(256) bn3_coef_kernel(const float* P, int ldp, 
         if (sub == 0 && ch < C) {
             const float mu = stats[ch], invstd = stats[C + ch];
             const float s2 = P ? invstd * (acc - mu * s1) : sq;        // sum g~ xhat
-            dbeta[ch] = s1;
-            dgamma[ch] = s2;
             const float A = gamma[ch] * invstd;
             const float B = -A * (float)((double)s2 / count) * invstd;
             const float D = -A * (float)((double)s1 / count) - B * mu;
-            coef[ch] = A; coef[C + ch] = B; coef[2 * C + ch] = D;
+            if (blockIdx.y == 0) {
+                dbeta[ch] = s1;
+                dgamma[ch] = s2;
+                coef[ch] = A; coef[C + ch] = B; coef[2 * C + ch] = D;
+            }
             cA[lc] = A; cB[lc] = B;
         }
     }
     __syncthreads();
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
-    for (int j0 = 0; j0 < c; j0 += 32) {
 #pragma unroll
-        for (int r = ty; r < 32; r += 8) {
-            const int ch = ch0 + r, j = j0 + tx;
-            float w = 0.f;
-            if (ch < C && j < c) {
-                w = bf16_bits_to_f32(W[(int64_t)ch * ldw + j]);
-                BW[(int64_t)ch * c + j] = f32_to_bf16_bits(cB[r] * w);
-            }
-            tile[r][tx] = (ch < C) ? cA[r] * w : 0.f;
+    for (int r = ty; r < 32; r += 8) {
+        const int ch = ch0 + r, j = j0 + tx;
+        float w = 0.f;
+        if (ch < C && j < c) {
+            w = bf16_bits_to_f32(W[(int64_t)ch * ldw + j]);
+            BW[(int64_t)ch * c + j] = f32_to_bf16_bits(cB[r] * w);
         }
-        __syncthreads();
+        tile[r][tx] = (ch < C) ? cA[r] * w : 0.f;
+    }
+    __syncthreads();
 #pragma unroll
-        for (int r = ty; r < 32; r += 8) {
-            const int j = j0 + r, ch = ch0 + tx;
-            if (j < c && ch < C) wt[(int64_t)j * ldwt + ch] = f32_to_bf16_bits(tile[tx][r]);
-        }
-        __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r, ch = ch0 + tx;
+        if (j < c && ch < C) wt[(int64_t)j * ldwt + ch] = f32_to_bf16_bits(tile[tx][r]);
     }
 }
 
@@ -95,33 +97,41 @@ __device__ __forceinline__ void tile_gemm64(int kbeg, int K, LF lf, RF rf, EF ea
     for (int a_ = 0; a_ < 4; ++a_)
 #pragma unroll
         for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] = 0.f;
-    for (int k0 = kbeg; k0 < K; k0 += 32) {
-        float lv[8], rv[8];
+    for (int k0 = kbeg; k0 < K; k0 += 64) {
+        // TWO chunks' loads in flight before the first LDS write: on a loaded memory system a round trip costs 3-5 us and the
+        // arithmetic of a chunk 0.5 us, so the depth of the dependent chain is what a launch takes
+        float lv[2][8], rv[2][8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {                   // all 16 loads of a thread in flight before the first LDS write
-            const int q = threadIdx.x + t * 256;
-            lv[t] = lf(q & 63, k0 + (q >> 6));
-            rv[t] = rf(k0 + (q >> 6), q & 63);
-        }
-        __syncthreads();                                 // the previous chunk has been consumed
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int q = threadIdx.x + t * 256;
-            ls[q >> 6][q & 63] = lv[t];
-            rs[q >> 6][q & 63] = rv[t];
-        }
-        __syncthreads();
+            for (int t = 0; t < 8; ++t) {
+                const int q = threadIdx.x + t * 256;
+                lv[h][t] = lf(q & 63, k0 + 32 * h + (q >> 6));      // (lf / rf return 0 past K)
+                rv[h][t] = rf(k0 + 32 * h + (q >> 6), q & 63);
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (k0 + 32 * h >= K) break;
+            __syncthreads();                             // the previous chunk has been consumed
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int q = threadIdx.x + t * 256;
+                ls[q >> 6][q & 63] = lv[h][t];
+                rs[q >> 6][q & 63] = rv[h][t];
+            }
+            __syncthreads();
 #pragma unroll 8
-        for (int r = 0; r < 32; ++r) {
-            const float4 l4 = *reinterpret_cast<const float4*>(&ls[r][tj]);
-            const float4 r4 = *reinterpret_cast<const float4*>(&rs[r][ti]);
-            const float l_[4] = {l4.x, l4.y, l4.z, l4.w}, r_[4] = {r4.x, r4.y, r4.z, r4.w};
+            for (int r = 0; r < 32; ++r) {
+                const float4 l4 = *reinterpret_cast<const float4*>(&ls[r][tj]);
+                const float4 r4 = *reinterpret_cast<const float4*>(&rs[r][ti]);
+                const float l_[4] = {l4.x, l4.y, l4.z, l4.w}, r_[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
-            for (int a_ = 0; a_ < 4; ++a_)
+                for (int a_ = 0; a_ < 4; ++a_)
 #pragma unroll
-                for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] += l_[a_] * r_[b_];
+                    for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] += l_[a_] * r_[b_];
+            }
+            each(k0 + 32 * h);
         }
-        each(k0);
     }
 }
 
@@ -241,7 +251,7 @@ int iif_bn3_algebra_coef(const float* P, int ldp, const void* w_bf16, int ldw, c
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(bn3_slice_sums_kernel, dim3((2 * C + 31) / 32, slices), dim3(256), 0, st, partial, n_partials, 2 * C, rps, scratch);
     IIF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn3_coef_kernel, dim3((C + 31) / 32), dim3(256), 0, st, P, ldp, (const unsigned short*)w_bf16, ldw, scratch, slices, 2 * C,
+    hipLaunchKernelGGL(bn3_coef_kernel, dim3((C + 31) / 32, (c + 31) / 32), dim3(256), 0, st, P, ldp, (const unsigned short*)w_bf16, ldw, scratch, slices, 2 * C,
                        stats, gamma, C, c, (double)m, coef, dgamma, dbeta, (unsigned short*)wt, ldwt, (unsigned short*)bw);
     IIF_LAUNCH_CHECK();
     return IIF_OK;
