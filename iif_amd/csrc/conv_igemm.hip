@@ -1062,9 +1062,14 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
     const float rHW = 1.0f / (float)HW, rW = 1.0f / (float)W, rW2 = 1.0f / (float)W2, rH2 = 1.0f / (float)H2;
     const int fr = lane & 15, fc = lane >> 4;
     const int nchunks = a.Cs / 32;
+    // grouped launch (64-channel chunks, non-persistent variant): blockIdx.y = chunk; its source / destination channels start
+    // at grp * Cs / grp * Cd of the spitch / dpitch wide tensors, its fragments follow those of the chunks before it
+    const int grp = PERSIST ? 0 : (int)blockIdx.y;
+    const unsigned gsrc = (unsigned)(grp * a.Cs) * 2u;
     const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src), 0, src_bytes, 0x00020000);
     // (buffer loads: ONE address register per lane = lane * 16, the fragment is selected by the scalar offset)
-    const auto rs_wf = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wfrag), 0, (unsigned)a.Cd * 9u * (unsigned)a.Cs * 2u, 0x00020000);
+    const auto rs_wf = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wfrag), 0,
+                                                         (unsigned)a.groups * (unsigned)a.Cd * 9u * (unsigned)a.Cs * 2u, 0x00020000);
     const unsigned wv = (unsigned)lane * 16u;
     const unsigned ci_stride = 9u * (unsigned)nchunks * 1024u;
     int toff[9];
@@ -1112,14 +1117,14 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
             if (pj & 1) hrow_pk[pj >> 1] |= hrw << 16; else hrow_pk[pj >> 1] = hrw;
         }
         // weight fragments of this wave: channel tiles (n0 + wn * 64) / 16 + ci; fragment (ci, tap slot, chunk) is 1 KB
-        wbase = (unsigned)((n0 + wn * 64) >> 4) * 9u * (unsigned)nchunks * 1024u;
+        wbase = (unsigned)((grp * a.Cd + n0 + wn * 64) >> 4) * 9u * (unsigned)nchunks * 1024u;
         return true;
     };
     auto issue_halo = [&](int c) {
         unsigned char* dst = smem + (c & 1) * ABUF;
 #pragma unroll
         for (int i = 0; i < NAP; ++i)                         // pieces beyond the window in use are out-of-range lanes: zeros, no traffic
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(dst + (wave + NWV * i) * 1024), 16, avoff[i], (unsigned)(c * 64), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(dst + (wave + NWV * i) * 1024), 16, avoff[i], (unsigned)(c * 64) + gsrc, 0, 0);
     };
     auto wload = [&](int t, int c, u32x4 (&wf)[CI]) {
         const unsigned so = wbase + ((unsigned)a.tap_w[t] * (unsigned)nchunks + (unsigned)c) * 1024u;
@@ -1274,7 +1279,7 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
             }
         }
         __syncthreads();
-        staged_drain<BN, BM, 256>(a, stage, dm0, dn0, dmt, 0);
+        staged_drain<BN, BM, 256>(a, stage, dm0, dn0, dmt, grp * a.Cd);
 #ifdef IIF_CONV_STAMPS
         IIF_STAMP(v_b); v_epi += v_b - v_a;
         if (!more_tiles && g_stamps && blockIdx.x < 512 && lane == 0) {
@@ -1667,7 +1672,7 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
 // Experiment / test switches of this file, read from the environment ONCE (they used to cost several getenv per launch on
 // the hot host path); iif_conv_reload_env() re-reads them (tests and A/B scripts flip them between calls).
 struct ConvSwitches {
-    bool no_stream, force_stream, stream_fwd_only, stream_r2, no_shortk, regstage, no_v2, no_halo, force_halo, v2_wide, v2_force, no_merge_classes, stream_twopass;
+    bool no_stream, force_stream, stream_fwd_only, stream_r2, no_shortk, regstage, no_v2, no_halo, force_halo, v2_wide, v2_force, no_merge_classes, stream_twopass, no_v2_grouped;
     int force_bn64_k, twostage_k;
     static ConvSwitches read() {
         ConvSwitches c;
@@ -1680,7 +1685,8 @@ struct ConvSwitches {
         // 4-blocks-per-CU tile kernel (weighted 5.16 against 5.05 ms per step alone, 21.28 against 21.19 ms in the step):
         // IIF_CONV_STREAM1X1_ALL opts in.
         c.stream_r2 = getenv("IIF_CONV_STREAM1X1_ALL") == nullptr;
-        c.stream_twopass = getenv("IIF_CONV_STREAM_TWOPASS") != nullptr;     // two-pass epilogue options on the streaming kernel
+        c.stream_twopass = getenv("IIF_CONV_STREAM_TWOPASS") != nullptr;
+        c.no_v2_grouped = getenv("IIF_CONV_NO_V2_GROUPED") != nullptr;     // two-pass epilogue options on the streaming kernel
         c.no_shortk = getenv("IIF_CONV_NO_SHORTK") != nullptr;
         c.regstage = getenv("IIF_CONV_REGSTAGE") != nullptr;
         c.no_v2 = getenv("IIF_CONV_NO_V2") != nullptr;
@@ -1757,7 +1763,7 @@ inline bool use_halo(const ConvArgs& a, bool utap, int esz, bool outf32) {
 
 // generation-2 3x3: fragment-packed weights supplied, bf16, stride 1 / pad 1, dense, channels in 32s / 64s, halo of a
 // 256-pixel tile within 640 rows
-inline bool v2_geometry_ok(int N, int H, int W, int Cs, int Cd) {
+inline bool v2_geometry_ok(int N, int H, int W, int Cs, int Cd, int groups = 1) {
     if ((Cs % 32) || (Cd % 64) || H <= 0 || W <= 0 || W > 1022) return false;
     // Measured alone (scripts/bm_conv3x3.py, bs 256): the 64-channel variant (56x56) 0.132 -> 0.102 ms forward, 0.171 -> 0.134
     // data gradient; the persistent 128-channel variant is level with or behind the halo kernel (28x28 0.078 -> 0.098,
@@ -1765,16 +1771,20 @@ inline bool v2_geometry_ok(int N, int H, int W, int Cs, int Cd) {
     if ((Cd % 128) == 0 && !g_sw.v2_wide) return false;
     // 256-pixel tiles: a small layer (CIFAR-size images) would leave most CUs without a block (IIF_CONV_V2_FORCE: tests)
     const int HW = H * W;
-    if (!g_sw.v2_force && ((int64_t)N * HW + 255) / 256 * (Cd / 64) < 192) return false;
+    if (!g_sw.v2_force && ((int64_t)N * HW + 255) / 256 * (Cd / 64) * groups < 192) return false;
     if ((int64_t)N * H * W >= (1 << 22)) return false;                    // fdiv's exact range
     const int span = (256 + W - 1) / W + 1 + 2 * (256 / HW + 1);            // virtual rows a 256-pixel tile can touch
     return (span + 2) * (W + 2) <= 640;
 }
 inline bool use_v2(const ConvArgs& a, bool utap, int esz, bool outf32) {
-    if (!a.wfrag || g_sw.no_v2 || !utap || esz != 2 || outf32 || a.groups > 1 || a.scatter || a.in_shift != 0) return false;
+    if (!a.wfrag || g_sw.no_v2 || !utap || esz != 2 || outf32 || a.scatter || a.in_shift != 0) return false;
     if (a.ntaps != 9 || a.R != 3 || a.S != 3 || a.pad != 1 || a.Hs != a.Hd || a.Ws != a.Wd || a.bias) return false;
-    if (a.spitch != a.Cs || a.dpitch != a.Cd) return false;
-    return v2_geometry_ok(a.N, a.Hd, a.Wd, a.Cs, a.Cd);
+    if (a.groups > 1) {                 // grouped: 64-channel chunks on the 64-channel variant, blockIdx.y = chunk
+        if (a.Cs != 64 || a.Cd != 64 || a.groups > 65535 || g_sw.no_v2_grouped) return false;
+    } else if (a.spitch != a.Cs || a.dpitch != a.Cd) {
+        return false;
+    }
+    return v2_geometry_ok(a.N, a.Hd, a.Wd, a.Cs, a.Cd, a.groups);
 }
 
 template <typename T, bool OUTF32>
@@ -1798,7 +1808,7 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
         const unsigned pgrid = (unsigned)(blocks2 < cus2 ? blocks2 : cus2);
         if (wide && window <= 512) hipLaunchKernelGGL(conv3x3_v2_kernel, dim3(pgrid), dim3(256), 0, st, a, (unsigned)src_bytes);
         else if (wide) hipLaunchKernelGGL(conv3x3_v2big_kernel, dim3(pgrid), dim3(256), 0, st, a, (unsigned)src_bytes);
-        else hipLaunchKernelGGL(conv3x3_v2n64_kernel, dim3((unsigned)blocks2), dim3(256), 0, st, a, (unsigned)src_bytes);
+        else hipLaunchKernelGGL(conv3x3_v2n64_kernel, dim3((unsigned)blocks2, (unsigned)a.groups), dim3(256), 0, st, a, (unsigned)src_bytes);
         IIF_LAUNCH_CHECK();
         return IIF_OK;
     }
@@ -2022,10 +2032,12 @@ extern "C" int iif_conv_pack_fragments(const void* src_base, const iif_pack_desc
 
 extern "C" int iif_conv3x3_frag_ok(const iif_conv_desc* d) {
     if (!d || g_sw.no_v2 || g_sw.regstage) return 0;
-    if (d->dtype != IIF_BF16 || d->dst_dtype != IIF_BF16 || d->groups > 1 || d->r != 3 || d->s != 3 || d->stride != 1 || d->pad != 1) return 0;
+    if (d->dtype != IIF_BF16 || d->dst_dtype != IIF_BF16 || d->r != 3 || d->s != 3 || d->stride != 1 || d->pad != 1) return 0;
     if (d->hs != d->hd || d->ws != d->wd) return 0;
-    if ((int64_t)d->n * d->hs * d->ws * d->cs * 2 >= 0x7f000000LL) return 0;
-    return v2_geometry_ok(d->n, d->hd, d->wd, d->cs, d->cd) ? 1 : 0;
+    const int g = d->groups > 1 ? d->groups : 1;
+    if (g > 1 && (d->cs != 64 || d->cd != 64 || g_sw.no_v2_grouped)) return 0;
+    if ((int64_t)d->n * d->hs * d->ws * d->cs * g * 2 >= 0x7f000000LL) return 0;
+    return v2_geometry_ok(d->n, d->hd, d->wd, d->cs, d->cd, g) ? 1 : 0;
 }
 
 extern "C" int iif_conv_reload_env(void) {

@@ -384,10 +384,11 @@ def wt_table(entries, device):
     return t, start
 
 
-def conv3x3_frag_ok(n, h, w, cin, cout, dtype):
-    """True when a dense 3x3 / stride-1 / pad-1 convolution of this geometry runs on the fragment-weights kernel."""
+def conv3x3_frag_ok(n, h, w, cin, cout, dtype, groups=1):
+    """True when a 3x3 / stride-1 / pad-1 convolution of this geometry (cin / cout per group) runs on the fragment-weights
+    kernel."""
     d = _desc(n, h, w, cin, h, w, cout, 3, 3, 1, 1, 0, 9 * cin, _lib.IIF_BF16 if dtype == torch.bfloat16 else _lib.IIF_F32,
-              _lib.IIF_BF16 if dtype == torch.bfloat16 else _lib.IIF_F32, 1)
+              _lib.IIF_BF16 if dtype == torch.bfloat16 else _lib.IIF_F32, groups)
     return bool(lib().iif_conv3x3_frag_ok(ctypes.byref(d)))
 
 

@@ -887,6 +887,33 @@ class _Plan(object):
                     self.frag_fwd = ops.pack_table(fwd, self.dev) + (len(fwd),)
                 if bwd:
                     self.frag_bwd = ops.pack_table(bwd, self.dev) + (len(bwd),)
+        # grouped 3x3 / stride-1 layers (ResNeXt): the block-diagonal chunk matrices move into ONE arena so that one more pack
+        # launch per step turns them into fragments too; the fragment kernel then takes blockIdx.y as the chunk
+        self.gfrag = None
+        gunits = [u for u in self.units if u.groups > 1]
+        if gunits and self.dt == torch.bfloat16 and not os.environ.get("IIF_CONV_NO_V2"):
+            gw = torch.empty(sum(u.w.numel() + u.wt.numel() for u in gunits), dtype=self.dt, device=self.dev)
+            entries, off, foff = [], 0, 0
+            for u in gunits:
+                cv = u.conv
+                nw = u.w.numel()
+                ow, owt = off, off + nw
+                u.w = gw[ow:ow + nw].view(u.w.shape)
+                u.wt = gw[owt:owt + nw].view(u.wt.shape)
+                off += 2 * nw
+                ok = cv.k == 3 and cv.stride == 1 and cv.pad == 1 and cv.chunk == 64 and cv.cin == cv.cout
+                if ok and ops.conv3x3_frag_ok(u.n, u.hi, u.wi, 64, 64, self.dt, groups=u.groups):
+                    entries.append((ow, foff, cv.cout, 9, 64, u.w.shape[1]))
+                    entries.append((owt, foff + nw, cv.cin, 9, 64, u.wt.shape[1]))
+                    u.wf, u.wtf = foff, foff + nw
+                    foff += 2 * nw
+            self.gw_arena = gw
+            if entries:
+                self.gfrag_arena = torch.empty(foff, dtype=self.dt, device=self.dev)
+                for u in gunits:
+                    if isinstance(u.wf, int):
+                        u.wf, u.wtf = self.gfrag_arena[u.wf:], self.gfrag_arena[u.wtf:]
+                self.gfrag = ops.pack_table(entries, self.dev) + (len(entries),)
 
     def _unit(self, conv, bn, src, n, ho, wo, patch=False, need_y=True):
         dt, dev = self.dt, self.dev
@@ -937,6 +964,12 @@ class _Plan(object):
                 ops.group_pack(cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.w)
                 if need_transposed:
                     ops.group_pack(cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.wt, transposed=True)
+        if self.gfrag is not None:
+            if not need_transposed:       # the table packs both orientations: keep the transposed chunks defined
+                for u in self.units:
+                    if u.groups > 1 and u.wtf is not None:
+                        ops.group_pack(u.conv._w2d, u.conv.cout, u.conv.cg, u.conv.chunk, u.conv.k * u.conv.k, u.wt, transposed=True)
+            ops.pack_fragments(self.gw_arena, self.gfrag[0], self.gfrag[2], self.gfrag[1], self.gfrag_arena)
         head = net._head
         if self.head_kind == "linear":
             return

@@ -799,3 +799,63 @@ def test_two_pass_forward_is_bit_identical_to_conv_then_bn_apply(case, stream, c
     ops.bn_apply(y.view(m, C), stats, a_ref.view(m, C), relu=True, relu_bits=bits_ref)
     ops.conv_forward_bn_relu(x, w, a_two, stats, relu_bits=bits_two)
     assert torch.equal(a_two, a_ref) and torch.equal(bits_two, bits_ref)
+
+
+@pytest.mark.parametrize("case", [(4, 128, 14, 14, 32), (2, 256, 28, 28, 32), (1, 512, 7, 7, 32), (3, 64, 9, 11, 8)],
+                         ids=lambda c: "n%d_w%d_%dx%d_g%d" % c)
+def test_grouped_conv3x3_on_the_fragment_kernel(case, conv_env):
+    """ResNeXt's grouped 3x3 / stride 1 on the fragment-weights kernel (blockIdx.y = 64-channel chunk): forward with fused
+    statistics, data gradient with a ReLU-masked residual and with the upstream BN-backward sums — the stored tensors
+    against the tile kernel's (same products, the summation order over K differs: bf16 ulp) and the partial rows against
+    sums over the stored values."""
+    from iif_amd import ops
+    n, width, h, w, groups = case
+    cg = width // groups
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(width + groups + h)
+    x = torch.randn(n, h, w, width, generator=g).to(dt).to(DEV)
+    wt = (torch.randn(width, cg, 3, 3, generator=g) / (9 * cg) ** 0.5).to(dt).float()
+    ldm = (9 * cg + 15) // 16 * 16
+    master = torch.zeros(width, ldm)
+    master[:, :9 * cg] = wt.permute(0, 2, 3, 1).reshape(width, 9 * cg)
+    wp = torch.empty(width, 576, dtype=dt, device=DEV)
+    wpt = torch.empty(width, 576, dtype=dt, device=DEV)
+    ops.group_pack(master.to(DEV), width, cg, 64, 9, wp)
+    ops.group_pack(master.to(DEV), width, cg, 64, 9, wpt, transposed=True)
+    G = width // 64
+    m = n * h * w
+    conv_env(IIF_CONV_V2_FORCE="1")
+    assert ops.conv3x3_frag_ok(n, h, w, 64, 64, dt, groups=G)
+    wf, wtf = _pack_frag(wp, width, 9, 64), _pack_frag(wpt, width, 9, 64)
+    dy = torch.randn(n, h, w, width, generator=g).to(dt).to(DEV)
+    res = torch.randn(n, h, w, width, generator=g).to(dt).to(DEV)
+    rbits = torch.randint(0, 256, (m * width // 8,), dtype=torch.uint8, generator=g).to(DEV)
+    upx = torch.randn(n, h, w, width, generator=g).to(dt).to(DEV)
+    ubits = torch.randint(0, 256, (m * width // 8,), dtype=torch.uint8, generator=g).to(DEV)
+    stats = torch.zeros(4, width)
+    stats[0] = torch.randn(width, generator=g) * 0.1
+    stats[1] = torch.rand(width, generator=g) + 0.5
+    out = {}
+    for mode in ("tile", "frag"):
+        f, ft = (wf, wtf) if mode == "frag" else (None, None)
+        y = torch.full((n, h, w, width), float("nan"), dtype=dt, device=DEV)
+        p = torch.full(((m + 127) // 128 + 8, 2, width), float("nan"), device=DEV)
+        nt = ops.conv_forward_bnstats(x, wp, 3, 3, 1, 1, y, p.view(-1), groups=G, w_frag=f)
+        dx = ops.conv_dgrad(dy, wpt, 3, 3, 1, 1, (h, w), res=res, res_bits=rbits, groups=G, w_frag=ft)
+        dx2 = torch.full((n, h, w, width), float("nan"), dtype=dt, device=DEV)
+        p2 = torch.full(((m + 127) // 128 + 8, 2, width), float("nan"), device=DEV)
+        nt2 = ops.conv_dgrad_bnbwd(dy, wpt, 3, 3, 1, 1, (h, w), dx2, upx, ubits, stats.to(DEV), p2.view(-1), groups=G, w_frag=ft)
+        out[mode] = (y, p[:nt].sum(0).cpu(), dx, dx2, p2[:nt2].sum(0).cpu())
+    for i in (0, 2, 3):
+        a_, b_ = out["frag"][i].float(), out["tile"][i].float()
+        assert not torch.isnan(a_).any()
+        assert (a_ - b_).abs().max().item() <= 2.0 ** -6 * b_.abs().max().item()
+    yf = out["frag"][0].float().cpu().view(m, width)
+    s = out["frag"][1]
+    assert (s[0] - yf.sum(0)).abs().max().item() <= 1e-3 * max(1.0, yf.sum(0).abs().max().item())
+    assert (s[1] - (yf * yf).sum(0)).abs().max().item() <= 1e-3 * (yf * yf).sum(0).abs().max().item()
+    gq = out["frag"][3].float().cpu().view(m, width) * ((ubits.cpu().view(-1, 1).int() >> torch.arange(8).view(1, 8)) & 1).view(m, width)
+    xhat = (upx.float().cpu().view(m, width) - stats[0]) * stats[1]
+    s2 = out["frag"][4]
+    assert (s2[0] - gq.sum(0)).abs().max().item() <= 1e-3 * max(1.0, gq.sum(0).abs().max().item())
+    assert (s2[1] - (gq * xhat).sum(0)).abs().max().item() <= 1e-3 * max(1.0, (gq * xhat).sum(0).abs().max().item())
