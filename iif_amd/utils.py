@@ -43,36 +43,40 @@ def accuracy(output, target, topk=(1,)):
 
 # --------------------------------------------------------------------- meters
 class SmoothedValue(object):
-    """Windowed median / mean plus a global average (utils.py:13-73)."""
+    """One logged scalar: the last ``window_size`` values (median / mean / max / last) and the running total over everything
+    seen (``global_avg``).  Same public surface as the reference's meter (utils.py:13-73: ``update``, the five read-only
+    statistics, ``synchronize_between_processes``, ``str()`` through ``fmt``); plain Python floats inside, no tensors."""
+
+    _FIELDS = ("median", "avg", "global_avg", "max", "value")
 
     def __init__(self, window_size=20, fmt=None):
-        self.fmt = fmt if fmt is not None else "{median:.4f} ({global_avg:.4f})"
-        self.deque = deque(maxlen=window_size)
-        self.total = 0.0
-        self.count = 0
+        self.fmt = "{median:.4f} ({global_avg:.4f})" if fmt is None else fmt
+        self.deque = deque(maxlen=window_size)      # (the attribute name is part of the surface: checkpoints pickle it)
+        self.total, self.count = 0.0, 0
 
     def update(self, value, n=1):
         self.deque.append(value)
-        self.total += value * n
         self.count += n
+        self.total += value * n
 
     def synchronize_between_processes(self):
-        """SUM-all-reduce of [count, total] in fp64 (utils.py:31-43); the window is local."""
+        """count and total become global sums (fp64 SUM all-reduce behind a barrier, utils.py:31-43); the window stays local."""
         if not is_dist_avail_and_initialized():
             return
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        pair = torch.tensor([self.count, self.total], dtype=torch.float64,
+                            device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.barrier()
-        dist.all_reduce(t)
-        self.count, self.total = int(t[0].item()), t[1].item()
+        dist.all_reduce(pair)
+        self.count, self.total = int(pair[0].item()), pair[1].item()
 
     @property
     def median(self):
-        return torch.tensor(list(self.deque)).median().item()
+        w = sorted(self.deque)
+        return float(w[(len(w) - 1) // 2])          # the LOWER middle element for even counts, as torch.median gives
 
     @property
     def avg(self):
-        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
+        return float(sum(self.deque)) / len(self.deque)
 
     @property
     def global_avg(self):
@@ -87,61 +91,61 @@ class SmoothedValue(object):
         return self.deque[-1]
 
     def __str__(self):
-        return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max,
-                               value=self.value)
+        return self.fmt.format(**{k: getattr(self, k) for k in self._FIELDS})
 
 
 class MetricLogger(object):
-    """Named meters + an iterator wrapper that prints progress (utils.py:76-162)."""
+    """A dictionary of meters that prints itself, plus the progress-printing loop wrapper of the training scripts
+    (utils.py:76-162): ``for batch in logger.log_every(loader, freq, header)``."""
 
     def __init__(self, delimiter="\t"):
         self.meters = defaultdict(SmoothedValue)
         self.delimiter = delimiter
 
+    def add_meter(self, name, meter):
+        self.meters[name] = meter
+
     def update(self, **kwargs):
         for name, v in kwargs.items():
-            if isinstance(v, torch.Tensor):
-                v = v.item()
-            assert isinstance(v, (float, int))
+            v = v.item() if isinstance(v, torch.Tensor) else v
+            if not isinstance(v, (float, int)):
+                raise TypeError("meter %r fed with %r" % (name, type(v).__name__))
             self.meters[name].update(v)
 
-    def __getattr__(self, attr):
-        meters = self.__dict__.get("meters", {})
-        if attr in meters:
+    def __getattr__(self, attr):              # logger.loss -> the meter called "loss"
+        meters = self.__dict__.get("meters")
+        if meters is not None and attr in meters:
             return meters[attr]
-        if attr in self.__dict__:
-            return self.__dict__[attr]
         raise AttributeError("'%s' object has no attribute '%s'" % (type(self).__name__, attr))
 
     def __str__(self):
-        return self.delimiter.join("%s: %s" % (k, m) for k, m in self.meters.items())
+        return self.delimiter.join("%s: %s" % item for item in self.meters.items())
 
     def synchronize_between_processes(self):
-        for m in self.meters.values():
-            m.synchronize_between_processes()
+        for meter in self.meters.values():
+            meter.synchronize_between_processes()
 
-    def add_meter(self, name, meter):
-        self.meters[name] = meter
+    def _progress_line(self, header, i, n, step_time, load_time):
+        remaining = datetime.timedelta(seconds=int(step_time.global_avg * (n - i)))
+        parts = [header, "[%*d/%d]" % (len(str(n)), i, n), "eta: %s" % remaining, str(self), "time: %s" % step_time,
+                 "data: %s" % load_time]
+        if torch.cuda.is_available():
+            parts.append("max mem: %.0f" % (torch.cuda.max_memory_allocated() / float(1 << 20)))
+        return self.delimiter.join(parts)
 
     def log_every(self, iterable, print_freq, header=None):
         header = header or ""
         n = len(iterable)
-        width = len(str(n))
-        iter_time, data_time = SmoothedValue(fmt="{avg:.4f}"), SmoothedValue(fmt="{avg:.4f}")
-        t_start = t_end = time.time()
-        for i, obj in enumerate(iterable):
-            data_time.update(time.time() - t_end)
-            yield obj
-            iter_time.update(time.time() - t_end)
+        step_time, load_time = SmoothedValue(fmt="{avg:.4f}"), SmoothedValue(fmt="{avg:.4f}")
+        began = mark = time.time()
+        for i, item in enumerate(iterable):
+            load_time.update(time.time() - mark)
+            yield item
+            step_time.update(time.time() - mark)
             if i % print_freq == 0:
-                eta = datetime.timedelta(seconds=int(iter_time.global_avg * (n - i)))
-                fields = [header, "[%*d/%d]" % (width, i, n), "eta: %s" % eta, str(self),
-                          "time: %s" % iter_time, "data: %s" % data_time]
-                if torch.cuda.is_available():
-                    fields.append("max mem: %.0f" % (torch.cuda.max_memory_allocated() / 2.0 ** 20))
-                print(self.delimiter.join(fields))
-            t_end = time.time()
-        print("%s Total time: %s" % (header, datetime.timedelta(seconds=int(time.time() - t_start))))
+                print(self._progress_line(header, i, n, step_time, load_time))
+            mark = time.time()
+        print("%s Total time: %s" % (header, datetime.timedelta(seconds=int(time.time() - began))))
 
 
 # ------------------------------------------------------------------- schedules
