@@ -37,6 +37,14 @@ __global__ void __launch_bounds__(256) bn3_coef_kernel(const float* P, int ldp, 
     __shared__ float cA[32], cB[32];
     __shared__ float tile[32][33];
     const int ch0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+    // phase 2's operand first: its loads fly while phase 1 reduces (one dependent round trip instead of two)
+    float wv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = ch0 + ty + 8 * i, j = j0 + tx;
+        wv[i] = (ch < C && j < c) ? bf16_bits_to_f32(W[(int64_t)ch * ldw + j]) : 0.f;
+    }
     {
         const int lc = threadIdx.x >> 3, sub = threadIdx.x & 7;
         const int ch = ch0 + lc;
@@ -66,16 +74,12 @@ __global__ void __launch_bounds__(256) bn3_coef_kernel(const float* P, int ldp, 
         }
     }
     __syncthreads();
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
 #pragma unroll
-    for (int r = ty; r < 32; r += 8) {
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 8 * i;
         const int ch = ch0 + r, j = j0 + tx;
-        float w = 0.f;
-        if (ch < C && j < c) {
-            w = bf16_bits_to_f32(W[(int64_t)ch * ldw + j]);
-            BW[(int64_t)ch * c + j] = f32_to_bf16_bits(cB[r] * w);
-        }
-        tile[r][tx] = (ch < C) ? cA[r] * w : 0.f;
+        if (ch < C && j < c) BW[(int64_t)ch * c + j] = f32_to_bf16_bits(cB[r] * wv[i]);
+        tile[r][tx] = (ch < C) ? cA[r] * wv[i] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -144,12 +148,15 @@ constexpr int kGmK = 64;
 __global__ void __launch_bounds__(256) bn3_gm_slab_kernel(const unsigned short* W, int ldw, const unsigned short* BW, const float* coef,
                                                           int C, int c, float* slab, float* bias_slab) {
     __shared__ __attribute__((aligned(16))) float ls[32][kTP], rs[32][kTP];
+    __shared__ float dsl[kGmK];
     const int nt = (c + 63) / 64;
     const int jo0 = (blockIdx.x / nt) * 64, i0 = (blockIdx.x % nt) * 64;
     const int kb = blockIdx.y * kGmK;
     const int ke = kb + kGmK < C ? kb + kGmK : C;
-    const float* D = coef + 2 * C;
     const bool diag = jo0 == i0;
+    // (D of this channel slice goes through LDS with the first batch of loads: read inside the chunk loop it was one more
+    // dependent round trip per chunk; the first barrier of tile_gemm64 publishes it)
+    if (threadIdx.x < kGmK) dsl[threadIdx.x] = kb + (int)threadIdx.x < C ? coef[2 * C + kb + threadIdx.x] : 0.f;
     float bacc = 0.f;
     float acc[4][4];
     tile_gemm64(
@@ -159,7 +166,7 @@ __global__ void __launch_bounds__(256) bn3_gm_slab_kernel(const unsigned short* 
         [&](int ch0) {
             if (diag && threadIdx.x < 64) {
                 const int lim = ke - ch0 < 32 ? ke - ch0 : 32;
-                for (int r = 0; r < lim; ++r) bacc += D[ch0 + r] * rs[r][threadIdx.x];
+                for (int r = 0; r < lim; ++r) bacc += dsl[ch0 - kb + r] * rs[r][threadIdx.x];
             }
         },
         acc, ls, rs);
