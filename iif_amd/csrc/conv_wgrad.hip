@@ -785,6 +785,14 @@ inline int reduce_slabs(float* ws, int64_t ws_bytes, int splits, int64_t slab, i
 }
 
 // all nine taps per block (conv3x3_wgrad_halo_kernel): 3x3 / stride 1 / pad 1, dense, bf16, channels in 64s, W <= 61
+// Experiment knob: pad a weight-gradient launch's LDS request up to IIF_WGRAD_LDS_KB per block (unused dynamic LDS), so that
+// fewer of its blocks fit a CU and the compute stream's kernels keep LDS / wave slots next to them.
+inline unsigned lds_pad(int static_bytes) {
+    static const int kb = getenv("IIF_WGRAD_LDS_KB") ? atoi(getenv("IIF_WGRAD_LDS_KB")) : 0;
+    const int want = kb * 1024;
+    return want > static_bytes ? (unsigned)(want - static_bytes) : 0u;
+}
+
 inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_bytes, int splits_req, int64_t x_bytes,
                              int64_t dy_bytes, hipStream_t st) {
     WgHaloArgs h{};
@@ -819,7 +827,7 @@ inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_b
     // 8-block x ring, 4-block dy ring, two block pairs in flight (48 KB, two blocks per CU).  Deeper rings were
     // measured: <8,8,4> equal at W <= 29, <16,8,6> (one block per CU) 10 % slower at 56x56 -- the issue phase is
     // bound by the DMA path, not by latency.
-    hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<8, 4, 2>), grid, dim3(256), 0, st, h, (unsigned)x_bytes, (unsigned)dy_bytes);
+    hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<8, 4, 2>), grid, dim3(256), lds_pad(49152), st, h, (unsigned)x_bytes, (unsigned)dy_bytes);
     IIF_LAUNCH_CHECK();
     if (splits > 1) return reduce_slabs(ws, ws_bytes, splits, slab, a.groups * a.Cd, a.ldw, a.K, dw, st);
     return IIF_OK;
@@ -934,10 +942,10 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     const bool dma = !force_v1 && x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL;
     if (dma) {
         const unsigned xb = (unsigned)x_bytes, yb = (unsigned)dy_bytes;
-        if (bc == 64) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64>), grid1d, dim3(256), 0, st, a, xb, yb);
+        if (bc == 64) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64>), grid1d, dim3(256), lds_pad(36864), st, a, xb, yb);
         else if (bc == 256) {
-            if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 256, 4>), grid1d, dim3(512), 0, st, a, xb, yb);
-        } else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128>), grid1d, dim3(256), 0, st, a, xb, yb);
+            if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 256, 4>), grid1d, dim3(512), lds_pad(73728), st, a, xb, yb);
+        } else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128>), grid1d, dim3(256), lds_pad(49152), st, a, xb, yb);
     } else {
         if (bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, st, a);
