@@ -303,6 +303,31 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T*
     }
 }
 
+// Sum of rows r, r + 8, r + 16, ... < r1 of column c (both halves of the [2][C] rows) in ROW ORDER, 8 loads in flight: under
+// load a dependent round trip costs 3-5 us, so the depth of this chain is what the small reduction launches take
+// (4 in flight: 17 us per launch inside the step).  The order of the additions is the one the 4-deep loop had.
+__device__ __forceinline__ void lane_sums(const float* partial, int C, int c, int r, int r1, double& a, double& b) {
+    for (; r + 56 < r1; r += 64) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            av[i] = partial[(int64_t)(r + 8 * i) * 2 * C + c];
+            bv[i] = partial[(int64_t)(r + 8 * i) * 2 * C + C + c];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a += av[i]; b += bv[i]; }
+    }
+    for (; r + 24 < r1; r += 32) {
+        const float a0 = partial[(int64_t)r * 2 * C + c], b0 = partial[(int64_t)r * 2 * C + C + c];
+        const float a1 = partial[(int64_t)(r + 8) * 2 * C + c], b1 = partial[(int64_t)(r + 8) * 2 * C + C + c];
+        const float a2 = partial[(int64_t)(r + 16) * 2 * C + c], b2 = partial[(int64_t)(r + 16) * 2 * C + C + c];
+        const float a3 = partial[(int64_t)(r + 24) * 2 * C + c], b3 = partial[(int64_t)(r + 24) * 2 * C + C + c];
+        a += a0; a += a1; a += a2; a += a3;
+        b += b0; b += b1; b += b2; b += b3;
+    }
+    for (; r < r1; r += 8) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
+}
+
 // Stage 1 for many partial rows: slice `blockIdx.y` of the rows is summed (double, fixed order) by 32 channels
 // x 8 lanes per block into out[slice][2][C]; the finalize kernels then see only `slices` rows.
 __global__ void __launch_bounds__(256) bn_partial_reduce_kernel(const float* partial, int nblk, int C, int rows_per_slice,
@@ -314,16 +339,7 @@ __global__ void __launch_bounds__(256) bn_partial_reduce_kernel(const float* par
     int r1 = r0 + rows_per_slice; if (r1 > nblk) r1 = nblk;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        int r = r0 + ln;
-        for (; r + 24 < r1; r += 32) {                  // 4 rows in flight per lane, sums in row order
-            const float a0 = partial[(int64_t)r * 2 * C + c], b0 = partial[(int64_t)r * 2 * C + C + c];
-            const float a1 = partial[(int64_t)(r + 8) * 2 * C + c], b1 = partial[(int64_t)(r + 8) * 2 * C + C + c];
-            const float a2 = partial[(int64_t)(r + 16) * 2 * C + c], b2 = partial[(int64_t)(r + 16) * 2 * C + C + c];
-            const float a3 = partial[(int64_t)(r + 24) * 2 * C + c], b3 = partial[(int64_t)(r + 24) * 2 * C + C + c];
-            a += a0; a += a1; a += a2; a += a3;
-            b += b0; b += b1; b += b2; b += b3;
-        }
-        for (; r < r1; r += 8) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
+        lane_sums(partial, C, c, r0 + ln, r1, a, b);
     }
     sh[ln * 32 + cl] = a; sh[256 + ln * 32 + cl] = b;
     __syncthreads();
@@ -355,16 +371,7 @@ __global__ void __launch_bounds__(256) bn_reduce_finalize_kernel(const float* pa
     int r1 = r0 + rows_per_slice; if (r1 > nblk) r1 = nblk;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        int r = r0 + ln;
-        for (; r + 24 < r1; r += 32) {                  // 4 rows in flight per lane, sums in row order
-            const float a0 = partial[(int64_t)r * 2 * C + c], b0 = partial[(int64_t)r * 2 * C + C + c];
-            const float a1 = partial[(int64_t)(r + 8) * 2 * C + c], b1 = partial[(int64_t)(r + 8) * 2 * C + C + c];
-            const float a2 = partial[(int64_t)(r + 16) * 2 * C + c], b2 = partial[(int64_t)(r + 16) * 2 * C + C + c];
-            const float a3 = partial[(int64_t)(r + 24) * 2 * C + c], b3 = partial[(int64_t)(r + 24) * 2 * C + C + c];
-            a += a0; a += a1; a += a2; a += a3;
-            b += b0; b += b1; b += b2; b += b3;
-        }
-        for (; r < r1; r += 8) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
+        lane_sums(partial, C, c, r0 + ln, r1, a, b);
     }
     sh[ln * 32 + cl] = a; sh[256 + ln * 32 + cl] = b;
     __syncthreads();
@@ -388,11 +395,23 @@ __global__ void __launch_bounds__(256) bn_reduce_finalize_kernel(const float* pa
     // ---- the last block of this channel group: slices in order, 8 lanes x 32 channels
     const int ns = (int)gridDim.y;
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int j = ln; j < ns; j += 8) {
+    if (c < C) {
+        int j = ln;
+        for (; j + 56 < ns; j += 64) {                   // 8 slices in flight per lane, added in slice order
+            float sv[8], qv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                sv[i] = __hip_atomic_load(slices_out + (int64_t)(j + 8 * i) * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                qv[i] = __hip_atomic_load(slices_out + (int64_t)(j + 8 * i) * 2 * C + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s += (double)sv[i]; q += (double)qv[i]; }
+        }
+        for (; j < ns; j += 8) {
             s += (double)__hip_atomic_load(slices_out + (int64_t)j * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             q += (double)__hip_atomic_load(slices_out + (int64_t)j * 2 * C + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
     __syncthreads();
     sh[ln * 32 + cl] = s; sh[256 + ln * 32 + cl] = q;
     __syncthreads();
