@@ -13,3 +13,9 @@ run --model resnext50_32x4d --batch 128
 run --model resnet18 --batch 256
 run --model resnet32 --batch 128 --image 32 --classes 100
 run --model se_resnet32 --batch 128 --image 32 --classes 100
+run --model wide_resnet50_2 --batch 128
+run --model wide_resnet101_2 --batch 64
+run --model resnext101_32x8d --batch 64
+run --model resnet34 --batch 256
+run --model se_resnext50_32x4d --batch 128
+run --model se_resnet152 --batch 64
