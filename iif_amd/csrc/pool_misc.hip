@@ -118,6 +118,64 @@ __global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const T* x, const f
     }
 }
 
+// The stem's shape (3 x 3 / stride 2 / pad 1, 256 % (C / V) == 0): one output row per block pass, a thread keeps ONE channel
+// vector (coefficients loaded once), the nine candidate vectors are all in flight before the first comparison (clamped
+// addresses, predicated use), 32-bit index arithmetic, the eight arg-max codes leave as one store.  Candidates are visited
+// in the (kh, kw) order of the general kernel with its first-valid / strictly-greater / NaN rule: identical results.
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool321_bn_fwd_kernel(const T* x, const float* stats, int N, int H, int W, int C, int Ho,
+                                                                int Wo, T* y, unsigned char* idx) {
+    constexpr int V = PT<T>::V;
+    const unsigned cv = C / V, rowv = (unsigned)Wo * cv;
+    const int c = (int)(threadIdx.x % cv) * V;
+    float ca[V], cb[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) { ca[q] = stats[2 * C + c + q]; cb[q] = stats[3 * C + c + q]; }
+    for (unsigned row = blockIdx.x; row < (unsigned)(N * Ho); row += gridDim.x) {
+        const unsigned n = row / (unsigned)Ho, ho = row - n * Ho;
+        const int h0 = 2 * (int)ho - 1;
+        for (unsigned j = threadIdx.x; j < rowv; j += 256) {
+            const unsigned wo = j / cv;
+            const int w0 = 2 * (int)wo - 1;
+            float v[9][V];
+            bool ok[9];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int h = h0 + kh, w = w0 + kw;
+                    ok[kh * 3 + kw] = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+                    const int hc = h < 0 ? 0 : (h >= H ? H - 1 : h), wc = w < 0 ? 0 : (w >= W ? W - 1 : w);
+                    PT<T>::load(x + (((int64_t)n * H + hc) * W + wc) * C + c, v[kh * 3 + kw]);
+                }
+            float best[V];
+            unsigned bi[V];
+#pragma unroll
+            for (int q = 0; q < V; ++q) { best[q] = -INFINITY; bi[q] = 0; }
+            bool first = true;
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                if (!ok[t9]) continue;
+#pragma unroll
+                for (int q = 0; q < V; ++q) {
+                    float t = fmaxf(fmaf(ca[q], v[t9][q], cb[q]), 0.f);
+                    if constexpr (sizeof(T) == 2) t = bf16_bits_to_f32(f32_to_bf16_bits(t));
+                    if (first || t > best[q] || t != t) { best[q] = t; bi[q] = (unsigned)t9; }
+                }
+                first = false;
+            }
+            const int64_t o = ((int64_t)row * Wo + wo) * C + c;
+            PT<T>::store(y + o, best);
+            if constexpr (V == 8) {
+                const unsigned lo = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24), hi = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+                *reinterpret_cast<uint2*>(idx + o) = make_uint2(lo, hi);
+            } else {
+                *reinterpret_cast<unsigned*>(idx + o) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* gy, const unsigned char* idx, int N, int H, int W,
                                                           int C, int k, int s, int p, int Ho, int Wo, T* dx) {
@@ -440,6 +498,17 @@ int iif_maxpool_bn_forward(const void* x, int dtype, const float* stats, int n, 
     if (mis(x) || mis(y) || c % (dtype == IIF_F32 ? 4 : 8)) return IIF_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
     const int64_t tot = (int64_t)n * ho * wo * (c / (dtype == IIF_F32 ? 4 : 8));
+    const int cvs = c / (dtype == IIF_F32 ? 4 : 8);
+    static const bool no_fast = getenv("IIF_NO_POOL321") != nullptr;
+    if (!no_fast && k == 3 && stride == 2 && pad == 1 && cvs <= 256 && 256 % cvs == 0 && (int64_t)n * ho < 0x7fffffffLL &&
+        (int64_t)n * h * w * c < 0x7fffffffLL) {
+        const int rowblocks = (int)((int64_t)n * ho < 16384 ? (int64_t)n * ho : 16384);
+        IIF_BY_DTYPE(dtype,
+            hipLaunchKernelGGL(maxpool321_bn_fwd_kernel<float>, dim3(rowblocks), dim3(256), 0, st, (const float*)x, stats, n, h, w, c, ho, wo, (float*)y, argmax),
+            hipLaunchKernelGGL(maxpool321_bn_fwd_kernel<unsigned short>, dim3(rowblocks), dim3(256), 0, st, (const unsigned short*)x, stats, n, h, w, c, ho, wo, (unsigned short*)y, argmax))
+        IIF_LAUNCH_CHECK();
+        return IIF_OK;
+    }
     IIF_BY_DTYPE(dtype,
         hipLaunchKernelGGL(maxpool_bn_fwd_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, (const float*)x, stats, n, h, w, c, k, stride, pad, ho, wo, (float*)y, argmax),
         hipLaunchKernelGGL(maxpool_bn_fwd_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, (const unsigned short*)x, stats, n, h, w, c, k, stride, pad, ho, wo, (unsigned short*)y, argmax))

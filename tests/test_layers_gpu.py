@@ -502,3 +502,27 @@ def test_sync_bn_pieces_of_two_halves_equal_the_whole_batch(shape, dt, masked):
     assert (dx2.float() - dx.float()).abs().max().item() <= tol * max(1e-3, dx.float().abs().max().item())
     if gm is not None:
         assert torch.equal(gm2, gm)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 112, 112, 64), (3, 17, 23, 64), (1, 9, 9, 32), (2, 8, 8, 128)], ids=lambda s_: "x".join(map(str, s_)))
+def test_fused_stem_pool_equals_bn_apply_then_maxpool(dt, shape):
+    """iif_maxpool_bn_forward (3/2/1: the row-per-block kernel with nine candidates in flight) = iif_bn_apply (ReLU) followed
+    by iif_maxpool_forward: pooled values and arg-max codes bit-identical, including the borders and the first-max tie rule
+    (ReLU produces runs of equal zeros)."""
+    from iif_amd import _lib, ops
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(h * 10 + w + c)
+    x = (torch.randn(n, h, w, c, generator=g) - 0.3).to(dt).to(DEV)
+    m = n * h * w
+    stats = torch.zeros(4, c, device=DEV)
+    stats[2] = (torch.rand(c, generator=g) * 2 - 0.5).to(DEV)          # some negative gains too
+    stats[3] = (torch.randn(c, generator=g) * 0.3).to(DEV)
+    act = torch.empty_like(x)
+    ops.bn_apply(x.view(m, c), stats, act.view(m, c), relu=True)
+    y_ref, idx_ref = ops.maxpool_forward(act, 3, 2, 1)
+    y = torch.empty_like(y_ref)
+    idx = torch.full_like(idx_ref, 255)
+    _lib.check(_lib.lib().iif_maxpool_bn_forward(_lib.ptr(x), _lib.dtype_code(x), _lib.ptr(stats), n, h, w, c, 3, 2, 1, _lib.ptr(y),
+                                                 _lib.ptr(idx), _lib.stream_ptr()), "iif_maxpool_bn_forward")
+    assert torch.equal(y, y_ref) and torch.equal(idx, idx_ref)
