@@ -311,6 +311,31 @@ def cpu_baseline(counts, sample_bs, steps, device=None):
     return out
 
 
+def _self_launch(args):
+    """Parent of a multi-GPU run started without torchrun: checks that the GPUs are there, spawns
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>`` as a child process, passes its
+    output through and returns its exit code (classification/README.md:32 launches the reference the same way)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    on_one = args.backend == "gloo" and args.device_index is not None           # rehearsal: N ranks on one GPU over gloo
+    visible = torch.cuda.device_count()
+    if not on_one and visible < n:
+        print("bench.py: --gpus %d needs %d GPUs, %d visible (one process per GPU over RCCL; nothing was measured)"
+              % (n, n, visible), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching %d ranks: %s" % (n, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -339,6 +364,12 @@ def main():
     ap.add_argument("--device-index", type=int, default=None, help="put every rank on this GPU (rehearsal only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver types it: this process has not touched the GPU yet (counting devices does
+        # not initialise HIP), so it may start the N ranks as a CHILD torch.distributed.run and relay rank 0's JSON line.
+        # Never an exec: a process that has initialised the GPU must not be replaced on this pool.
+        sys.exit(_self_launch(args))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) if args.device_index is None else args.device_index
@@ -366,7 +397,12 @@ def main():
     from iif_amd.ddp import broadcast_parameters
 
     C = args.classes
-    counts = lt_counts(C, 1280 if C == 1000 else 4980)   # ImageNet-LT / Places-LT shaped profiles
+    if C == 100:
+        # config 1: the reference's CIFAR100-LT profile (imbalanced_dataset.py:23-37: exp, img_max 500, imb 0.01 -> 500 ... 5, 10 847 images)
+        from iif_amd.imbalanced_dataset import img_num_per_cls
+        counts = img_num_per_cls(100, 50000, "exp", 0.01)
+    else:
+        counts = lt_counts(C, 1280 if C == 1000 else 4980)   # ImageNet-LT / Places-LT shaped profiles
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
     if hasattr(resnet_pytorch, args.model):

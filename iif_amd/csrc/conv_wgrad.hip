@@ -47,8 +47,22 @@ template <> struct WT<float> {
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+// Transposing LDS read, issued as inline asm.  With the builtin (__builtin_amdgcn_ds_read_tr16_b64_v4i16) hipcc cannot tell
+// which LDS bytes the read touches and puts `s_waitcnt vmcnt(0)` in front of the first read of every K step: ALL LDS-DMA in
+// flight - the stages fetched ahead included - drained before every multiply, i.e. no prefetch at all (every kernel of this
+// file ran one memory round trip per 32-pixel step: ~2 900 cycles for 256 cycles of MFMA, whatever the ring depth).
+// The asm form is invisible to that pass; the price is that its completion is invisible too: tr_fence<N>() =
+// `s_waitcnt lgkmcnt(N)` pinned in place must stand between the reads and their first use.
+typedef __attribute__((address_space(3))) const unsigned char lds_cu8;
 __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    s16x4 v;
+    const unsigned a = (unsigned)(unsigned long long)(lds_cu8*)(p);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void tr_fence() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <typename T, int BC>
@@ -170,6 +184,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgArgs a) {
                 const s16x4 lo = tr_read(base), hi = tr_read(base + 16 * PY);
                 yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             }
+            tr_fence<0>();
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -256,7 +271,11 @@ template <typename T, int COLS> struct Swz {
 
 // WK wave groups along the output channels (2 x WK waves): 128 kernel columns x BC channels, BC = 64 | 128 with
 // WK = 2, or 256 with WK = 4 (8 waves: 12 instead of 16 KB through the vector L1 per MFLOP, see conv_igemm.hip)
-template <typename T, int BC, int WK = 2>
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NST LDS stages: NST - 1 K steps are in flight while one is multiplied.  A block's step time is (memory latency) / (NST - 1):
+// with three stages and ONE 8-wave block per CU (the 256-channel tile) a step took ~2 900 cycles for 256 cycles of MFMA.
+template <typename T, int BC, int WK = 2, int NST = 3>
 __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsigned x_bytes, unsigned dy_bytes) {
     constexpr int PE = WT<T>::PE, ROWS = WT<T>::ROWS;
     constexpr int BNW = 128;
@@ -271,7 +290,8 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
     constexpr int KJ = CW / 16;
     constexpr unsigned OOB = 0xfffffff0u;
     static_assert((NIX == 1 || NIX == 2) && (NIY == 1 || NIY == 2), "tile geometry");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE];
+    static_assert(NST >= 3 && NST <= 7 && (NST - 2) * LPS <= 63, "ring depth");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -359,8 +379,12 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
 
     const int g = lane >> 4, li = lane & 15;
     const int nst = step1 - step0;
-    if (nst > 0) issue(0, step0);
-    if (nst > 1) { advance(); issue(1, step0 + 1); }
+#pragma unroll
+    for (int s_ = 0; s_ < NST - 1; ++s_)
+        if (s_ < nst) {
+            if (s_ > 0) advance();
+            issue(s_, step0 + s_);
+        }
     int stage = 0;
 #ifdef IIF_CONV_STAMPS
     unsigned long long w_wait = 0, w_issue = 0, w_rest = 0, w0, w1, w2, w3, wb;
@@ -370,13 +394,20 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
 #ifdef IIF_CONV_STAMPS
         IIF_WSTAMP(w0); w_rest += w0 - w3;
 #endif
-        if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {   // stage t has landed once at most min(NST - 2, steps after t) younger stages are outstanding
+            const int rem = nst - 1 - t;
+            if (rem >= NST - 2) wait_vmcnt<(NST - 2) * LPS>();
+            else if (NST > 3 && rem == 1) wait_vmcnt<LPS>();
+            else if (NST > 4 && rem == 2) wait_vmcnt<2 * LPS>();
+            else if (NST > 5 && rem == 3) wait_vmcnt<3 * LPS>();
+            else if (NST > 6 && rem == 4) wait_vmcnt<4 * LPS>();
+            else wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
 #ifdef IIF_CONV_STAMPS
         IIF_WSTAMP(w1);
 #endif
-        if (t + 2 < nst) { advance(); issue(stage == 0 ? 2 : stage - 1, step0 + t + 2); }
+        if (t + NST - 1 < nst) { advance(); issue(stage == 0 ? NST - 1 : stage - 1, step0 + t + NST - 1); }
 #ifdef IIF_CONV_STAMPS
         IIF_WSTAMP(w2); w_wait += w1 - w0; w_issue += w2 - w1; w3 = w2;
 #endif
@@ -384,13 +415,9 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
         const unsigned char* Y = X + XB;
         if constexpr (sizeof(T) == 2) {
             const int q = li >> 2, p = li & 3;
+            // LDS returns in order: the dy fragments first, then the x fragments one 16-column block at a time; the MFMAs of
+            // block ni start as soon as its two reads are back (6 / 4 / 2 / 0 younger reads still outstanding)
             s16x8 xf[4], yf[KJ];
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int colb = (wn * 64 + ni * 16 + 4 * p) * 2;
-                const s16x4 lo = tr_read(X + SX::addr(4 * g + q, colb)), hi = tr_read(X + SX::addr(16 + 4 * g + q, colb));
-                xf[ni] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            }
 #pragma unroll
             for (int kj = 0; kj < KJ; ++kj) {
                 const int colb = (wk * CW + kj * 16 + 4 * p) * 2;
@@ -398,11 +425,19 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
                 yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 4; ++ni) {
+                const int colb = (wn * 64 + ni * 16 + 4 * p) * 2;
+                const s16x4 lo = tr_read(X + SX::addr(4 * g + q, colb)), hi = tr_read(X + SX::addr(16 + 4 * g + q, colb));
+                xf[ni] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                if (ni == 0) tr_fence<6>(); else if (ni == 1) tr_fence<4>(); else if (ni == 2) tr_fence<2>(); else tr_fence<0>();
 #pragma unroll
                 for (int kj = 0; kj < KJ; ++kj)
                     acc[ni][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, xf[ni]), __builtin_bit_cast(bf16x8, yf[kj]), acc[ni][kj], 0, 0, 0);
+            }
         } else {
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
@@ -420,7 +455,7 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
                         acc[ni][kj] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[ni], yf[kj], acc[ni][kj], 0, 0, 0);
             }
         }
-        stage = stage == 2 ? 0 : stage + 1;
+        stage = stage == NST - 1 ? 0 : stage + 1;
     }
 
 #ifdef IIF_CONV_STAMPS
@@ -578,11 +613,16 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, u
             xf[tap] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
+        for (int tap = 0; tap < 9; ++tap) {
+            // in-order LDS returns: tap `tap` may start once at most 2 * (8 - tap) younger reads are outstanding (the counter has 4 bits)
+            if (tap == 0) tr_fence<15>(); else if (tap == 1) tr_fence<14>(); else if (tap == 2) tr_fence<12>();
+            else if (tap == 3) tr_fence<10>(); else if (tap == 4) tr_fence<8>(); else if (tap == 5) tr_fence<6>();
+            else if (tap == 6) tr_fence<4>(); else if (tap == 7) tr_fence<2>(); else tr_fence<0>();
 #pragma unroll
             for (int kj = 0; kj < 4; ++kj)
                 acc[tap][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf[tap]), __builtin_bit_cast(bf16x8, yf[kj]),
                                                                         acc[tap][kj], 0, 0, 0);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the trailing prefetches write LDS: drain before exit
 #ifdef IIF_CONV_STAMPS
@@ -709,11 +749,13 @@ __global__ void __launch_bounds__(256) conv4x4_s2d_wgrad_kernel(WgStemArgs a, un
             xf[s_] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         }
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_)
+        for (int s_ = 0; s_ < 4; ++s_) {
+            if (s_ == 0) tr_fence<6>(); else if (s_ == 1) tr_fence<4>(); else if (s_ == 2) tr_fence<2>(); else tr_fence<0>();
 #pragma unroll
             for (int kj = 0; kj < 4; ++kj)
                 acc[s_][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf[s_]), __builtin_bit_cast(bf16x8, yf[kj]),
                                                                        acc[s_][kj], 0, 0, 0);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -785,14 +827,6 @@ inline int reduce_slabs(float* ws, int64_t ws_bytes, int splits, int64_t slab, i
 }
 
 // all nine taps per block (conv3x3_wgrad_halo_kernel): 3x3 / stride 1 / pad 1, dense, bf16, channels in 64s, W <= 61
-// Experiment knob: pad a weight-gradient launch's LDS request up to IIF_WGRAD_LDS_KB per block (unused dynamic LDS), so that
-// fewer of its blocks fit a CU and the compute stream's kernels keep LDS / wave slots next to them.
-inline unsigned lds_pad(int static_bytes) {
-    static const int kb = getenv("IIF_WGRAD_LDS_KB") ? atoi(getenv("IIF_WGRAD_LDS_KB")) : 0;
-    const int want = kb * 1024;
-    return want > static_bytes ? (unsigned)(want - static_bytes) : 0u;
-}
-
 inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_bytes, int splits_req, int64_t x_bytes,
                              int64_t dy_bytes, hipStream_t st) {
     WgHaloArgs h{};
@@ -827,7 +861,7 @@ inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_b
     // 8-block x ring, 4-block dy ring, two block pairs in flight (48 KB, two blocks per CU).  Deeper rings were
     // measured: <8,8,4> equal at W <= 29, <16,8,6> (one block per CU) 10 % slower at 56x56 -- the issue phase is
     // bound by the DMA path, not by latency.
-    hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<8, 4, 2>), grid, dim3(256), lds_pad(49152), st, h, (unsigned)x_bytes, (unsigned)dy_bytes);
+    hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<8, 4, 2>), grid, dim3(256), 0, st, h, (unsigned)x_bytes, (unsigned)dy_bytes);
     IIF_LAUNCH_CHECK();
     if (splits > 1) return reduce_slabs(ws, ws_bytes, splits, slab, a.groups * a.Cd, a.ldw, a.K, dw, st);
     return IIF_OK;
@@ -901,6 +935,10 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     bool wide = sizeof(T) == 2 && dma_ok && a.groups == 1 && a.Cd >= 256 && a.Cd % 256 == 0;
     if (wide && wide_env) wide = atoi(wide_env) == 256;
     const int bc = wide ? 256 : (a.Cd <= 64 ? 64 : 128);
+    // ring depth per tile (LDS stage: 24 / 16 / 12 KB for the 256 / 128 / 64-channel tile)
+    static const int nst256 = getenv("IIF_WGRAD_NST_256") ? atoi(getenv("IIF_WGRAD_NST_256")) : 3;
+    static const int nst128 = getenv("IIF_WGRAD_NST_128") ? atoi(getenv("IIF_WGRAD_NST_128")) : 3;
+    static const int nst64 = getenv("IIF_WGRAD_NST_64") ? atoi(getenv("IIF_WGRAD_NST_64")) : 3;
     a.ktiles = (a.Cd + bc - 1) / bc;
     a.ntiles = (a.K + 127) / 128;
     a.nsteps = (a.M + ROWS - 1) / ROWS;
@@ -912,11 +950,8 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
         // blocks per CU: 4 (64-channel tile), 3 (128), and ONE 8-wave block for the 256-channel tile: two per CU write twice
         // the split-K slabs for nothing (step 20.67 -> 20.62 ms at one; 0.75 / 1.25 per CU leave a tail round: 21.2 / 20.8;
         // scripts/ab_wgrad_slots.sh).  IIF_WGRAD_SLOT_PCT[_256|_128|_64]: experiment knobs, per cent of these.
-        static const int slot_pct = getenv("IIF_WGRAD_SLOT_PCT") ? atoi(getenv("IIF_WGRAD_SLOT_PCT")) : 100;
-        static const int pct256 = getenv("IIF_WGRAD_SLOT_PCT_256") ? atoi(getenv("IIF_WGRAD_SLOT_PCT_256")) : slot_pct;
-        static const int pct128 = getenv("IIF_WGRAD_SLOT_PCT_128") ? atoi(getenv("IIF_WGRAD_SLOT_PCT_128")) : slot_pct;
-        static const int pct64 = getenv("IIF_WGRAD_SLOT_PCT_64") ? atoi(getenv("IIF_WGRAD_SLOT_PCT_64")) : slot_pct;
-        const int slots = 256 * (bc == 64 ? 4 : (bc == 256 ? 1 : 3)) * (bc == 64 ? pct64 : (bc == 256 ? pct256 : pct128)) / 100;
+        const int per_cu = bc == 256 ? 1 : (bc == 128 ? (nst128 > 3 ? 2 : 3) : (nst64 > 4 ? 2 : (nst64 > 3 ? 3 : 4)));
+        const int slots = 256 * per_cu;
         splits = slots / (tiles * a.groups);
         if (splits < 1) splits = 1;
         const int max_by_work = a.nsteps / 8 > 0 ? a.nsteps / 8 : 1;
@@ -942,10 +977,20 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     const bool dma = !force_v1 && x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL;
     if (dma) {
         const unsigned xb = (unsigned)x_bytes, yb = (unsigned)dy_bytes;
-        if (bc == 64) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64>), grid1d, dim3(256), lds_pad(36864), st, a, xb, yb);
-        else if (bc == 256) {
-            if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 256, 4>), grid1d, dim3(512), lds_pad(73728), st, a, xb, yb);
-        } else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128>), grid1d, dim3(256), lds_pad(49152), st, a, xb, yb);
+        if (bc == 64) {
+            if (nst64 > 4) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64, 2, 6>), grid1d, dim3(256), 0, st, a, xb, yb);
+            else if (nst64 > 3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64, 2, 4>), grid1d, dim3(256), 0, st, a, xb, yb);
+            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64>), grid1d, dim3(256), 0, st, a, xb, yb);
+        } else if (bc == 256) {
+            if constexpr (sizeof(T) == 2) {
+                if (nst256 > 4) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 256, 4, 6>), grid1d, dim3(512), 0, st, a, xb, yb);
+                else if (nst256 > 3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 256, 4, 4>), grid1d, dim3(512), 0, st, a, xb, yb);
+                else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 256, 4>), grid1d, dim3(512), 0, st, a, xb, yb);
+            }
+        } else {
+            if (nst128 > 3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128, 2, 5>), grid1d, dim3(256), 0, st, a, xb, yb);
+            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128>), grid1d, dim3(256), 0, st, a, xb, yb);
+        }
     } else {
         if (bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, st, a);

@@ -1504,9 +1504,13 @@ class _Plan(object):
             elif "ds" in b:
                 self._unit_backward(first, d, first.y, dgrad_out=gin, par=par)
                 du = b["ds"]
-                if lazy_mask:       # in place: g is not needed after the shortcut's BN backward
+                if lazy_mask:
+                    # in place (g is not needed after the shortcut's BN backward) - unless the block's last unit went the
+                    # algebraic route with P on the weight-gradient stream: that GEMM still reads g itself (not a private
+                    # dx copy), so the shortcut's dx goes to its own buffer
+                    alias = last in self.alg3_units and not self._a3_is_pure(last) and self.wg_stream is not None
                     self._unit_backward(du, g, last.y, mask_bits=last.bits, dgrad_out=gin, dgrad_res=gin, par=par,
-                                        fuse_up=up_in)
+                                        fuse_up=up_in, keep_gy=alias, dxkey="dxds" if alias else "dx")
                 else:
                     self._unit_backward(du, g, None, dgrad_out=gin, dgrad_res=gin, par=par, fuse_up=up_in)
             elif "sc" in b:

@@ -1,5 +1,7 @@
-"""Worker of test_ddp_gpu.py: one data-parallel rank of the native engine.  Every rank sits on cuda:0
-(the test box has one GPU; RCCL refuses two ranks on one device, so the rehearsal uses gloo).
+"""Worker of test_ddp_gpu.py: one data-parallel rank of the native engine.  Backend from ``IIF_DDP_BACKEND``:
+``gloo`` (default): every rank sits on cuda:0 (the test box has one GPU; RCCL refuses two ranks on one device);
+``nccl``: rank r sits on cuda:LOCAL_RANK and the buckets go through RCCL (the tests that ask for it skip themselves
+on a box with fewer than two GPUs).
 
 ``same``: every rank feeds the SAME batch, so the averaged gradient equals the single-process gradient bit for bit.
 ``diff``: every rank feeds its OWN batch; ``emulate`` reproduces the data-parallel step in one process (backward on
@@ -14,6 +16,13 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 BATCH = 16
 BF16_LR = 0.002
+BACKEND = os.environ.get("IIF_DDP_BACKEND", "gloo")
+
+
+def _device():
+    idx = int(os.environ.get("LOCAL_RANK", "0")) if BACKEND == "nccl" else 0
+    torch.cuda.set_device(idx)
+    return torch.device("cuda", idx)
 
 
 def _setup(dev):
@@ -36,8 +45,7 @@ def _batch(dev, rank):
 
 def run(out_path, steps, with_reducer, data="same", mode="allreduce", bf16=False, lr=0.05):
     from iif_amd.ddp import broadcast_parameters
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    dev = _device()
     net, crit = _setup(dev)
     reducer = None
     rank = dist.get_rank() if with_reducer else 0
@@ -88,8 +96,7 @@ def run_syncbn(out_path, steps, arch, dt_name, world, rank):
     from iif_amd import resnet_cifar, resnet_pytorch
     from iif_amd.custom import IIFLoss
     from iif_amd.ddp import broadcast_parameters
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    dev = _device()
     torch.manual_seed(5)
     dt = torch.float32 if dt_name == "f32" else torch.bfloat16
     if arch == "resnet20":
@@ -141,7 +148,10 @@ if __name__ == "__main__":
     data = sys.argv[3] if len(sys.argv) > 3 else "same"
     mode = sys.argv[4] if len(sys.argv) > 4 else "allreduce"
     bf16 = len(sys.argv) > 5 and sys.argv[5] == "bf16"
-    dist.init_process_group("gloo")
+    if BACKEND == "nccl":
+        dist.init_process_group("nccl", device_id=_device())          # RCCL over xGMI
+    else:
+        dist.init_process_group("gloo")
     if data == "syncbn":
         run_syncbn(os.path.join(out_dir, "rank%d.pt" % dist.get_rank()), steps, mode, sys.argv[5], dist.get_world_size(), dist.get_rank())
         dist.barrier()

@@ -12,8 +12,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 
-def _launch(tmp_path, port, *worker_args):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+# every two-rank test runs over gloo with both ranks on GPU 0 (the one-GPU box), and once more over RCCL with one rank per GPU
+# wherever two GPUs are visible (torch.cuda.device_count() does not initialise the GPU); nothing to switch on by hand
+def _backends():
+    two = torch.cuda.device_count() >= 2
+    return [pytest.param("gloo", id="gloo"),
+            pytest.param("nccl", id="nccl", marks=pytest.mark.skipif(not two, reason="RCCL needs one GPU per rank: %d visible"
+                                                                                      % torch.cuda.device_count()))]
+
+
+def _launch(tmp_path, port, *worker_args, backend="gloo"):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", IIF_DDP_BACKEND=backend)
+    port += 100 if backend == "nccl" else 0
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "ddp_gpu_worker.py"), str(tmp_path)] + [str(a) for a in worker_args]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -21,9 +31,10 @@ def _launch(tmp_path, port, *worker_args):
     return [torch.load(tmp_path / ("rank%d.pt" % rk), weights_only=False) for rk in (0, 1)]
 
 
-def test_two_ranks_same_batch_equal_single_process_bit_for_bit(tmp_path):
+@pytest.mark.parametrize("backend", _backends())
+def test_two_ranks_same_batch_equal_single_process_bit_for_bit(tmp_path, backend):
     import ddp_gpu_worker
-    ranks = _launch(tmp_path, 29533, 4)
+    ranks = _launch(tmp_path, 29533, 4, backend=backend)
     ddp_gpu_worker.run(str(tmp_path / "single.pt"), 4, False)
     single = torch.load(tmp_path / "single.pt", weights_only=False)
     for got in ranks:
@@ -31,13 +42,14 @@ def test_two_ranks_same_batch_equal_single_process_bit_for_bit(tmp_path):
         assert torch.equal(got["params"], single["params"])       # (g + g) * 0.5 == g exactly
 
 
+@pytest.mark.parametrize("backend", _backends())
 @pytest.mark.parametrize("mode,port", [("allreduce", 29541), ("rs_ag", 29542)])
-def test_two_ranks_different_batches_match_emulated_data_parallel_step(tmp_path, mode, port):
+def test_two_ranks_different_batches_match_emulated_data_parallel_step(tmp_path, mode, port, backend):
     """Rank-distinct batches: every bucket must carry BOTH ranks' final gradients (ordering against backward, the
     weight-gradient stream, full coverage of the arena).  fp32 two-operand sums are order independent, so the
     parameters after 4 steps equal the one-process emulation bit for bit, on both ranks."""
     import ddp_gpu_worker
-    ranks = _launch(tmp_path, port, 4, "diff", mode)
+    ranks = _launch(tmp_path, port, 4, "diff", mode, backend=backend)
     ddp_gpu_worker.emulate(str(tmp_path / "emu.pt"), 4, 2)
     emu = torch.load(tmp_path / "emu.pt", weights_only=False)
     assert ranks[0]["losses"] != ranks[1]["losses"]               # the ranks really saw different data
@@ -49,12 +61,13 @@ def test_two_ranks_different_batches_match_emulated_data_parallel_step(tmp_path,
         assert d["collectives_launched"] == 4 * d["buckets"] * (2 if mode == "rs_ag" else 1)
 
 
-def test_bf16_buckets_keep_the_fp32_loss_curve(tmp_path):
+@pytest.mark.parametrize("backend", _backends())
+def test_bf16_buckets_keep_the_fp32_loss_curve(tmp_path, backend):
     """bf16 gradient buckets are only switched on after the probe on real gradients; the 6-step loss curve then stays
     within 1e-3 relative of the fp32-bucket curve (bf16 rounding of the summed gradient, 2^-8 per element, before
     momentum) and the parameters within 1e-3 of their norm."""
     import ddp_gpu_worker
-    low = _launch(tmp_path, 29543, 6, "diff", "allreduce", "bf16")
+    low = _launch(tmp_path, 29543, 6, "diff", "allreduce", "bf16", backend=backend)
     ddp_gpu_worker.emulate(str(tmp_path / "emu.pt"), 6, 2, lr=ddp_gpu_worker.BF16_LR)
     emu = torch.load(tmp_path / "emu.pt", weights_only=False)
     for rk, got in enumerate(low):
@@ -65,8 +78,9 @@ def test_bf16_buckets_keep_the_fp32_loss_curve(tmp_path):
     assert torch.equal(low[0]["params"], low[1]["params"])        # replicas stay identical
 
 
+@pytest.mark.parametrize("backend", _backends())
 @pytest.mark.parametrize("arch,dt,port", [("resnet20", "f32", 29551), ("resnet50", "f32", 29552), ("resnet50", "bf16", 29553)])
-def test_sync_bn_two_ranks_equal_the_whole_batch_on_one_rank(tmp_path, arch, dt, port):
+def test_sync_bn_two_ranks_equal_the_whole_batch_on_one_rank(tmp_path, arch, dt, port, backend):
     """``--sync-bn`` (classification/train.py:190-191): two ranks, each with half of one batch and cross-replica batch
     statistics, against ONE process on the whole batch.  fp32: logits of both halves, the mean of the two ranks' losses and the
     parameters after 3 SGD steps within 1e-4 / 2e-4 (summation order is all that differs); bf16: the fused-statistics
@@ -75,7 +89,7 @@ def test_sync_bn_two_ranks_equal_the_whole_batch_on_one_rank(tmp_path, arch, dt,
     pre-activation within 1e-6 of zero (scripts/dbg_sync_bn.py counts them: 1 of 131072 in layer4's output, worth 1/64 of a
     dbeta entry there); later losses therefore get 1e-3, and the parameters are compared in the 2-norm."""
     import ddp_gpu_worker
-    ranks = _launch(tmp_path, port, 3, "syncbn", arch, dt)
+    ranks = _launch(tmp_path, port, 3, "syncbn", arch, dt, backend=backend)
     ddp_gpu_worker.run_syncbn(str(tmp_path / "single.pt"), 3, arch, dt, 1, 0)
     one = torch.load(tmp_path / "single.pt", weights_only=False)
     full = torch.cat([ranks[0]["logits0"], ranks[1]["logits0"]], 0)
@@ -95,13 +109,19 @@ def test_sync_bn_two_ranks_equal_the_whole_batch_on_one_rank(tmp_path, arch, dt,
         assert torch.equal(ranks[0]["rstat"], ranks[1]["rstat"])
 
 
+@pytest.mark.parametrize("backend", _backends())
 @pytest.mark.parametrize("extra,port", [([], 29561), (["--sync-bn", "--reduce-mode", "rs_ag"], 29562)])
-def test_train_cli_two_ranks_end_to_end(tmp_path, extra, port):
+def test_train_cli_two_ranks_end_to_end(tmp_path, extra, port, backend):
     """``python -m torch.distributed.run ... -m iif_amd.train`` with two ranks (one-GPU rehearsal: both on GPU 0, gloo):
     init_distributed_mode, the distributed sampler, parameter broadcast, the bucketed reducer under backward, optional
     SyncBatchNorm + reduce-scatter buckets, evaluation with rank 0's BN buffers and the metric all-reduce, and the checkpoint
     (written once, loadable, finite).  classification/train.py:176-292."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", IIF_REHEARSE_ONE_GPU="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    if backend == "gloo":
+        env["IIF_REHEARSE_ONE_GPU"] = "1"
+    else:
+        env.pop("IIF_REHEARSE_ONE_GPU", None)          # one rank per GPU, RCCL
+        port += 100
     out = tmp_path / "out"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", "iif_amd.train", "--model", "resnet20", "--dset_name", "cifar10", "--classif", "iif",

@@ -343,8 +343,9 @@ def test_bf16_fused_bn_backward_sums_match_the_reduction_pass(arch, C, B, hw):
         assert e <= (1e-1 if m_ is net.bn1 else 6e-2), (type(m_).__name__, attr, e)
 
 
+@pytest.mark.parametrize("streams", ["three_streams", "no_shortcut_stream", "one_stream"])
 @pytest.mark.parametrize("pure", [False, True], ids=["sums_from_producer", "sums_from_P"])
-def test_bn3_backward_by_algebra_inside_the_step(monkeypatch, pure):
+def test_bn3_backward_by_algebra_inside_the_step(monkeypatch, pure, streams):
     """The algebraic conv3 + bn3 backward (csrc/bn3_algebra.hip; both variants: sum g~ xhat from the producing data gradient,
     the default below 1.5e8 elements, and sum g~ y from P = g~^T a2, the default above) against the standard route on the
     same step: they differ by bf16 roundings only, which the 50 layers amplify to ~1e-2 (same size as the fused-sums route's
@@ -352,6 +353,10 @@ def test_bn3_backward_by_algebra_inside_the_step(monkeypatch, pure):
     from iif_amd.custom import IIFLoss
     monkeypatch.setenv("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "0" if pure else "1e30")
     monkeypatch.setenv("IIF_TWOPASS", "1")                  # with sums from P: conv3's output is not even stored in forward
+    if streams == "no_shortcut_stream":                     # the shortcut's BN backward then runs on the compute stream, in front
+        monkeypatch.setenv("IIF_NO_BWD_SIDE", "1")          # of a weight-gradient stream that may still read the block's g
+    elif streams == "one_stream":
+        monkeypatch.setenv("IIF_NO_WGRAD_STREAM", "1")
     arch, C, B, hw = "resnet50", 1000, 32, 64
     counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
     net, sd = _build(arch, C, torch.bfloat16)
@@ -381,14 +386,19 @@ def test_bn3_backward_by_algebra_inside_the_step(monkeypatch, pure):
 
 
 @pytest.mark.parametrize("arch,C,B,hw,alg3", [("resnet50", 1000, 16, 64, False), ("resnet50", 1000, 16, 64, True),
+                                              ("resnet50", 1000, 16, 64, "no_shortcut_stream"), ("resnet50", 1000, 16, 64, "one_stream"),
                                               ("resnext50_32x4d", 365, 8, 64, False)])
 def test_bf16_step_is_bit_reproducible(arch, C, B, hw, alg3, monkeypatch):
     """Three streams (main, weight gradients, shortcut branch), split-K slabs, fused statistics: every sum has a
     fixed order and every cross-stream hand-over an event, so the same step twice gives bit-identical gradients
     (alg3: with the algebraic BN3 backward forced on for every eligible bottleneck)."""
     from iif_amd.custom import IIFLoss
-    if alg3:
+    if alg3 is True:
         monkeypatch.setenv("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "0")          # sums from P everywhere (the default is mixed)
+    elif alg3 == "no_shortcut_stream":                                      # sums from the producer, P on the weight-gradient
+        monkeypatch.setenv("IIF_NO_BWD_SIDE", "1")                          # stream, shortcut backward on the compute stream
+    elif alg3 == "one_stream":
+        monkeypatch.setenv("IIF_NO_WGRAD_STREAM", "1")
     counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
     net, sd = _build(arch, C, torch.bfloat16)
     x, y = _data(B, hw, counts, seed=33)
