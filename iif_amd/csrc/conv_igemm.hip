@@ -614,9 +614,11 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
     // tap bit index ut, source soffset usoff (bytes), weight soffset uwoff (bytes)
     int uc = 0, ut = 0;
     unsigned usoff = 0, uwoff = 0;
+    // (the tap table is read with vector loads: without readfirstlane the compiler cannot tell that the two soffsets are
+    // wave-uniform and wraps every LDS-DMA of the K loop in a waterfall loop - readfirstlane, compare, exec mask, branch)
     if constexpr (UTAP) {
-        usoff = (unsigned)((tl.dy[0] * a.Ws + tl.dx[0]) * a.spitch * (int)sizeof(T) + shiftP);
-        uwoff = (unsigned)(tl.w[0] * a.Cs) * (unsigned)sizeof(T);
+        usoff = (unsigned)__builtin_amdgcn_readfirstlane((tl.dy[0] * a.Ws + tl.dx[0]) * a.spitch * (int)sizeof(T) + shiftP);
+        uwoff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(tl.w[0] * a.Cs) * (unsigned)sizeof(T)));
     }
 
     auto issue = [&](auto stage_c) {
@@ -667,8 +669,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, unsigned 
             if (uc >= ((two_src && ut == 1) ? a.Cs2 : a.Cs)) {
                 uc = 0; ++ut;
                 const int tt = ut < a.ntaps ? ut : 0;
-                usoff = (unsigned)((tl.dy[tt] * a.Ws + tl.dx[tt]) * a.spitch * (int)sizeof(T) + shiftP);
-                uwoff = (unsigned)(tl.w[tt] * a.Cs) * (unsigned)sizeof(T);
+                usoff = (unsigned)__builtin_amdgcn_readfirstlane((tl.dy[tt] * a.Ws + tl.dx[tt]) * a.spitch * (int)sizeof(T) + shiftP);
+                uwoff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(tl.w[tt] * a.Cs) * (unsigned)sizeof(T)));
             }
         } else {
             e += KE;

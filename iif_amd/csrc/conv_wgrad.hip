@@ -16,6 +16,7 @@
 // Replaces the cuDNN/MIOpen wgrad calls autograd issues for
 // classification/resnet_pytorch.py:46-62 and resnet_cifar.py:112-115.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #ifndef IIF_WG_AUX_X
@@ -273,8 +274,8 @@ template <typename T, int COLS> struct Swz {
 // WK = 2, or 256 with WK = 4 (8 waves: 12 instead of 16 KB through the vector L1 per MFLOP, see conv_igemm.hip)
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// NST LDS stages: NST - 1 K steps are in flight while one is multiplied.  A block's step time is (memory latency) / (NST - 1):
-// with three stages and ONE 8-wave block per CU (the 256-channel tile) a step took ~2 900 cycles for 256 cycles of MFMA.
+// NST LDS stages: NST - 1 K steps are in flight while one is multiplied.  Measured (round 4, each shape alone): 4 and 6 stages
+// are level with 3 once the prefetch really is in flight (tr_read above), and their LDS footprint costs the step 0.2-0.3 ms.
 template <typename T, int BC, int WK = 2, int NST = 3>
 __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsigned x_bytes, unsigned dy_bytes) {
     constexpr int PE = WT<T>::PE, ROWS = WT<T>::ROWS;
@@ -478,6 +479,166 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 / stride 1 weight gradient (bf16): dW[Cd][Cs] = dy^T x, a plain [M, Cd]^T [M, Cs] contraction over the pixels.
+// Same tile (BNW x-columns x BC dy-channels), 32-pixel steps, three LDS stages and split-K slabs as conv_wgrad_dma_kernel,
+// with the per-step instruction stream of that kernel (measured ~1 900 cycles per step for 256 cycles of MFMA once its
+// prefetch really was in flight) cut to what a 1x1 layer needs:
+//   * a lane's DMA source offset only ever advances by 32 pixel rows: one v_add per piece and step (invalid columns keep a
+//     fixed out-of-range offset with increment 0; rows >= M fall off the end of the buffer by themselves);
+//   * the K loop is unrolled over the three stages, so every fragment read is  lane offset (loop invariant register) +
+//     immediate (stage base, +16 rows for the upper half): no address arithmetic at all in front of the 16 LDS reads;
+//   * BNW = 64 for layers with <= 64 input channels (the 128-column tile multiplied zeros in half of its MFMAs).
+// NWV waves = (BNW / 64) along the x columns x WK along the channels, CW = BC / WK channels per wave.
+struct W1Args {
+    const unsigned char* x; const unsigned char* dy; float* out;
+    int M, Cs, Cd, ldw, ktiles, ntiles, steps_per_split, nsteps, nsplits;
+    int64_t slab;
+};
+
+template <int OFF> __device__ __forceinline__ s16x4 tr_read_at(unsigned a) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+
+template <int BC, int BNW, int NWV>
+__device__ __forceinline__ void wgrad1x1_body(const W1Args& a, unsigned x_bytes, unsigned dy_bytes) {
+    constexpr int NWN = BNW / 64, WK = NWV / NWN, CW = BC / WK, KJ = CW / 16;
+    using SX = Swz<unsigned short, BNW>;
+    using SY = Swz<unsigned short, BC>;
+    constexpr int RBX = SX::RB, RBY = SY::RB;                     // row bytes
+    constexpr int XB = 32 * RBX, YB = 32 * RBY, STAGE = XB + YB;
+    constexpr int NPX = XB / 1024, NPY = YB / 1024;               // 1-KB DMA pieces per step
+    constexpr int NIX = NPX / NWV, NIY = NPY / NWV, LPS = NIX + NIY;
+    constexpr int LPRX = RBX / 16, RPIX = 64 / LPRX, LPRY = RBY / 16, RPIY = 64 / LPRY;
+    constexpr unsigned OOB = 0xfffffff0u;
+    static_assert(NIX >= 1 && NIY >= 1 && NIX * NWV == NPX && NIY * NWV == NPY && KJ >= 1, "tile geometry");
+    static_assert(2 * STAGE + 16 * RBY < 65536 && 2 * STAGE + 16 * RBX < 65536, "fragment reads use 16-bit immediates");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WK, wk = wave % WK;
+    const int tiles = a.ktiles * a.ntiles;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;           // all tiles of one pixel split back to back on ONE XCD
+    const int split = (jj / tiles) * 8 + xcd, tile = jj % tiles;
+    if (split >= a.nsplits) return;
+    const int k0 = (tile % a.ktiles) * BC, n0 = (tile / a.ktiles) * BNW;
+    const int step0 = split * a.steps_per_split;
+    int step1 = step0 + a.steps_per_split;
+    if (step1 > a.nsteps) step1 = a.nsteps;
+    const int nst = step1 - step0;
+
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x), 0, x_bytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.dy), 0, dy_bytes, 0x00020000);
+
+    // ---- DMA: piece p of a step covers tile rows RPI * p ...; this wave issues pieces NI * wave + i
+    unsigned offx[NIX], incx[NIX], offy[NIY], incy[NIY];
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+        const int r = RPIX * (NIX * wave + i) + lane / LPRX;
+        const int col = n0 + SX::logical(lane % LPRX, r) * 8;
+        const bool ok = col < a.Cs;
+        offx[i] = ok ? ((unsigned)(step0 * 32 + r) * (unsigned)a.Cs + (unsigned)col) * 2u : OOB;
+        incx[i] = ok ? 64u * (unsigned)a.Cs : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < NIY; ++i) {
+        const int r = RPIY * (NIY * wave + i) + lane / LPRY;
+        const int col = k0 + SY::logical(lane % LPRY, r) * 8;
+        const bool ok = col < a.Cd;
+        offy[i] = ok ? ((unsigned)(step0 * 32 + r) * (unsigned)a.Cd + (unsigned)col) * 2u : OOB;
+        incy[i] = ok ? 64u * (unsigned)a.Cd : 0u;
+    }
+    auto issue = [&](auto stage_c) {                       // the next step's tiles into stage S; offsets move on by 32 rows
+        constexpr int S = decltype(stage_c)::value;
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_w*)(smem + S * STAGE + (NIX * wave + i) * 1024), 16, offx[i], 0, 0, IIF_WG_AUX_X);
+            offx[i] += incx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NIY; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)(smem + S * STAGE + XB + (NIY * wave + i) * 1024), 16, offy[i], 0, 0, IIF_WG_AUX_Y);
+            offy[i] += incy[i];
+        }
+    };
+
+    // ---- fragment reads: lane offsets inside a stage (the +16-row half and the stage base are immediates)
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    unsigned xo[4], yo[KJ];
+    const unsigned sbase = (unsigned)(unsigned long long)(lds_cu8*)smem;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) xo[ni] = sbase + (unsigned)SX::addr(4 * g + q, (wn * 64 + ni * 16 + 4 * pp) * 2);
+#pragma unroll
+    for (int kj = 0; kj < KJ; ++kj) yo[kj] = sbase + (unsigned)(XB + SY::addr(4 * g + q, (wk * CW + kj * 16 + 4 * pp) * 2));
+
+    f32x4 acc[4][KJ];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int kj = 0; kj < KJ; ++kj) acc[ni][kj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    // one K step on stage S: this wave's pieces of step t have landed (the next step's stay in flight), meet the other
+    // waves, refill the stage read in step t - 1 with step t + 2, multiply
+    auto step = [&](auto stage_c, auto refill_c, int t) {
+        constexpr int S = decltype(stage_c)::value;
+        if (t + 1 < nst) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nst) issue(refill_c);
+        s16x8 xf[4], yf[KJ];
+#pragma unroll
+        for (int kj = 0; kj < KJ; ++kj) {
+            const s16x4 lo = tr_read_at<S * STAGE>(yo[kj]), hi = tr_read_at<S * STAGE + 16 * RBY>(yo[kj]);
+            yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const s16x4 lo = tr_read_at<S * STAGE>(xo[ni]), hi = tr_read_at<S * STAGE + 16 * RBX>(xo[ni]);
+            xf[ni] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            if (ni == 0) tr_fence<6>(); else if (ni == 1) tr_fence<4>(); else if (ni == 2) tr_fence<2>(); else tr_fence<0>();
+#pragma unroll
+            for (int kj = 0; kj < KJ; ++kj)
+                acc[ni][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf[ni]), __builtin_bit_cast(bf16x8, yf[kj]),
+                                                                      acc[ni][kj], 0, 0, 0);
+        }
+    };
+    if (nst > 0) issue(S0{});
+    if (nst > 1) issue(S1{});
+    for (int t = 0; t < nst; t += 3) {
+        step(S0{}, S2{}, t);
+        if (t + 1 < nst) step(S1{}, S0{}, t + 1);
+        if (t + 2 < nst) step(S2{}, S1{}, t + 2);
+    }
+
+    float* out = a.out + (int64_t)split * a.slab;
+#pragma unroll
+    for (int kj = 0; kj < KJ; ++kj) {
+        const int k = k0 + wk * CW + kj * 16 + li;
+        if (k >= a.Cd) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + g * 4;
+            if (n >= a.Cs) continue;
+            *reinterpret_cast<f32x4*>(out + (int64_t)k * a.ldw + n) = acc[ni][kj];
+        }
+    }
+}
+
+// plain kernel names around the body template (hipcc / ROCm 7.2 does not emit the host stub of a __global__ template whose
+// body holds generic lambdas: the same workaround as in conv_igemm.hip)
+__global__ void __launch_bounds__(512) wgrad1x1_256x128_kernel(W1Args a, unsigned xb, unsigned yb) { wgrad1x1_body<256, 128, 8>(a, xb, yb); }
+__global__ void __launch_bounds__(256) wgrad1x1_128x128_kernel(W1Args a, unsigned xb, unsigned yb) { wgrad1x1_body<128, 128, 4>(a, xb, yb); }
+__global__ void __launch_bounds__(256) wgrad1x1_64x128_kernel(W1Args a, unsigned xb, unsigned yb) { wgrad1x1_body<64, 128, 4>(a, xb, yb); }
+__global__ void __launch_bounds__(256) wgrad1x1_64x64_kernel(W1Args a, unsigned xb, unsigned yb) { wgrad1x1_body<64, 64, 4>(a, xb, yb); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 weight gradient with ALL NINE TAPS per block ("halo window", bf16).
@@ -904,6 +1065,50 @@ inline int launch_wgrad_stem(const WgArgs& a, float* dw, float* ws, int64_t ws_b
     return IIF_OK;
 }
 
+// 1x1 / stride 1 (wgrad1x1_body): tile by the channel counts, one co-resident round of splits as below
+inline int launch_wgrad_1x1(const WgArgs& g, float* dw, float* ws, int64_t ws_bytes, int splits_req, int64_t x_bytes, int64_t dy_bytes,
+                            hipStream_t st) {
+    W1Args a{};
+    a.x = g.x; a.dy = g.dy; a.M = g.M; a.Cs = g.Cs; a.Cd = g.Cd; a.ldw = g.ldw;
+    const int bc = (g.Cd >= 256 && g.Cd % 256 == 0) ? 256 : (g.Cd <= 64 ? 64 : 128);
+    const int bnw = (g.Cs <= 64 && bc == 64) ? 64 : 128;      // (256 x 64 as two 4-wave blocks per CU was slower than 256 x 128 with half of its columns empty: 0.115 against 0.106 ms at 56 x 56)
+    a.ktiles = (g.Cd + bc - 1) / bc;
+    a.ntiles = (g.Cs + bnw - 1) / bnw;
+    a.nsteps = (g.M + 31) / 32;
+    const int tiles = a.ktiles * a.ntiles;
+    // blocks per CU by LDS (3 stages of 32 x (bnw + bc) x 2 bytes) and registers: 256 x 128: one 8-wave block (72 KB);
+    // 128 x 128: three (48 KB); 64 x {128, 64}: four
+    const int per_cu = bc == 256 ? 1 : (bc == 128 ? 3 : 4);
+    int splits = splits_req;
+    if (splits <= 0) {
+        splits = 256 * per_cu / tiles;
+        if (splits < 1) splits = 1;
+        const int max_by_work = a.nsteps / 8 > 0 ? a.nsteps / 8 : 1;
+        if (splits > max_by_work) splits = max_by_work;
+    }
+    const int64_t slab = (int64_t)g.Cd * g.ldw;
+    const int64_t fit = ws ? ws_bytes / (slab * 4) : 0;
+    if (splits > fit) splits = (int)fit;
+    if (splits < 1) splits = 1;
+    if (splits > a.nsteps) splits = a.nsteps > 0 ? a.nsteps : 1;
+    if (splits > 65535) splits = 65535;
+    a.steps_per_split = (a.nsteps + splits - 1) / splits;
+    splits = (a.nsteps + a.steps_per_split - 1) / a.steps_per_split;
+    if (splits < 1) splits = 1;
+    a.slab = splits > 1 ? slab : 0;
+    a.out = splits > 1 ? ws : dw;
+    a.nsplits = splits;
+    const dim3 grid((unsigned)(tiles * ((splits + 7) / 8) * 8));
+    const unsigned xb = (unsigned)x_bytes, yb = (unsigned)dy_bytes;
+    if (bc == 256) hipLaunchKernelGGL(wgrad1x1_256x128_kernel, grid, dim3(512), 0, st, a, xb, yb);
+    else if (bc == 128) hipLaunchKernelGGL(wgrad1x1_128x128_kernel, grid, dim3(256), 0, st, a, xb, yb);
+    else if (bnw == 128) hipLaunchKernelGGL(wgrad1x1_64x128_kernel, grid, dim3(256), 0, st, a, xb, yb);
+    else hipLaunchKernelGGL(wgrad1x1_64x64_kernel, grid, dim3(256), 0, st, a, xb, yb);
+    IIF_LAUNCH_CHECK();
+    if (splits > 1) return reduce_slabs(ws, ws_bytes, splits, slab, g.Cd, g.ldw, g.Cs, dw, st);
+    return IIF_OK;
+}
+
 template <typename T>
 int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_req, int64_t x_bytes, int64_t dy_bytes,
                  hipStream_t st) {
@@ -932,13 +1137,15 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
             if (rc != -100) return rc;
         }
     }
+    if constexpr (sizeof(T) == 2) {
+        static const bool no_1x1 = getenv("IIF_WGRAD_NO_1X1") != nullptr;
+        if (dma_ok && !no_1x1 && a.R == 1 && a.S == 1 && a.sshift == 0 && a.pad == 0 && a.groups == 1 && a.Hs == a.Hd && a.Ws == a.Wd &&
+            a.xpitch == a.Cs && a.ypitch == a.Cd)
+            return launch_wgrad_1x1(a, dw, ws, ws_bytes, splits_req, x_bytes, dy_bytes, st);
+    }
     bool wide = sizeof(T) == 2 && dma_ok && a.groups == 1 && a.Cd >= 256 && a.Cd % 256 == 0;
     if (wide && wide_env) wide = atoi(wide_env) == 256;
     const int bc = wide ? 256 : (a.Cd <= 64 ? 64 : 128);
-    // ring depth per tile (LDS stage: 24 / 16 / 12 KB for the 256 / 128 / 64-channel tile)
-    static const int nst256 = getenv("IIF_WGRAD_NST_256") ? atoi(getenv("IIF_WGRAD_NST_256")) : 3;
-    static const int nst128 = getenv("IIF_WGRAD_NST_128") ? atoi(getenv("IIF_WGRAD_NST_128")) : 3;
-    static const int nst64 = getenv("IIF_WGRAD_NST_64") ? atoi(getenv("IIF_WGRAD_NST_64")) : 3;
     a.ktiles = (a.Cd + bc - 1) / bc;
     a.ntiles = (a.K + 127) / 128;
     a.nsteps = (a.M + ROWS - 1) / ROWS;
@@ -950,8 +1157,7 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
         // blocks per CU: 4 (64-channel tile), 3 (128), and ONE 8-wave block for the 256-channel tile: two per CU write twice
         // the split-K slabs for nothing (step 20.67 -> 20.62 ms at one; 0.75 / 1.25 per CU leave a tail round: 21.2 / 20.8;
         // scripts/ab_wgrad_slots.sh).  IIF_WGRAD_SLOT_PCT[_256|_128|_64]: experiment knobs, per cent of these.
-        const int per_cu = bc == 256 ? 1 : (bc == 128 ? (nst128 > 3 ? 2 : 3) : (nst64 > 4 ? 2 : (nst64 > 3 ? 3 : 4)));
-        const int slots = 256 * per_cu;
+        const int slots = 256 * (bc == 256 ? 1 : (bc == 128 ? 3 : 4));
         splits = slots / (tiles * a.groups);
         if (splits < 1) splits = 1;
         const int max_by_work = a.nsteps / 8 > 0 ? a.nsteps / 8 : 1;
@@ -977,20 +1183,10 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     const bool dma = !force_v1 && x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL;
     if (dma) {
         const unsigned xb = (unsigned)x_bytes, yb = (unsigned)dy_bytes;
-        if (bc == 64) {
-            if (nst64 > 4) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64, 2, 6>), grid1d, dim3(256), 0, st, a, xb, yb);
-            else if (nst64 > 3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64, 2, 4>), grid1d, dim3(256), 0, st, a, xb, yb);
-            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64>), grid1d, dim3(256), 0, st, a, xb, yb);
-        } else if (bc == 256) {
-            if constexpr (sizeof(T) == 2) {
-                if (nst256 > 4) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 256, 4, 6>), grid1d, dim3(512), 0, st, a, xb, yb);
-                else if (nst256 > 3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 256, 4, 4>), grid1d, dim3(512), 0, st, a, xb, yb);
-                else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 256, 4>), grid1d, dim3(512), 0, st, a, xb, yb);
-            }
-        } else {
-            if (nst128 > 3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128, 2, 5>), grid1d, dim3(256), 0, st, a, xb, yb);
-            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128>), grid1d, dim3(256), 0, st, a, xb, yb);
-        }
+        if (bc == 64) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64>), grid1d, dim3(256), 0, st, a, xb, yb);
+        else if (bc == 256) {
+            if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 256, 4>), grid1d, dim3(512), 0, st, a, xb, yb);
+        } else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 128>), grid1d, dim3(256), 0, st, a, xb, yb);
     } else {
         if (bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, st, a);

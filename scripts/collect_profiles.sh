@@ -1,6 +1,6 @@
 #!/bin/bash
 # The rocprofv3 passes behind profiles/r<round>_<tag>_*: run ON the GPU box from the repo root (gpurun).
-#   scripts/collect_profiles.sh r3_a
+#   scripts/collect_profiles.sh r4_a
 # 1 kernel trace (stats + timeline), 2 HBM counter passes (FETCH_SIZE / WRITE_SIZE, one counter each), 1 MFMA pass.
 # Counters are collected in passes of their own (--kernel-trace + --pmc only), as the pool requires.
 set -e -o pipefail
