@@ -75,9 +75,8 @@ SIGNATURES = {
     "iif_conv_igemm_bn_relu": [_P, _P, _P, _P, _P, _P, _P, _P],
     "iif_conv_igemm_dgrad_masksum": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "iif_conv_igemm_dgrad2_bnbwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
-    "iif_bn3_algebra_coef": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _P, _L, _P],
-    "iif_bn3_algebra_gm": [_P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _L, _P],
-    "iif_bn3_algebra_gm_scratch_floats": [_I, _I],
+    "iif_bn3_algebra_prep": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P],
+    "iif_bn3_algebra_prep_scratch_floats": [_I, _I],
     "iif_bn3_algebra_dw": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P],
     "iif_conv_pack_fragments": [_P, _P, _I, _I, _P, _P],
     "iif_conv3x3_frag_ok": [_P],
@@ -131,7 +130,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = argtypes
-            fn.restype = _L if name in ("iif_bn_workspace_bytes", "iif_bn3_algebra_gm_scratch_floats") else _I
+            fn.restype = _L if name in ("iif_bn_workspace_bytes", "iif_bn3_algebra_prep_scratch_floats") else _I
         _lib = l
     return _lib
 

@@ -24,71 +24,6 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
-// Block = 32 channels x 32 columns (grid C/32 x c/32).  Phase 1 (8 threads per channel, every block of a channel group
-// repeats it: a lone block walking all c / 32 column tiles was a chain of dependent round trips, 26-40 us inside the step):
-// sum_g from the `slices` rows of column sums, sum g~ xhat from their second half or, with P, from
-// sgy = sum_j P[ch][j] W[ch][j]; the coefficients; the blocks of column tile 0 write coef / dgamma / dbeta.
-// Phase 2: this block's tile of the g~ half of the stacked data-gradient weights, wt[j][ch] = bf16(A[ch] W[ch][j]),
-// transposed through LDS, and of BW[ch][j] = bf16(B[ch] W[ch][j]) (the scaled operand of the Gm product).
-__global__ void __launch_bounds__(256) bn3_coef_kernel(const float* P, int ldp, const unsigned short* W, int ldw, const float* sg_slices,
-                                                       int slices, int sg_pitch, const float* stats, const float* gamma, int C, int c,
-                                                       double count, float* coef, float* dgamma, float* dbeta, unsigned short* wt,
-                                                       int ldwt, unsigned short* BW) {
-    __shared__ float cA[32], cB[32];
-    __shared__ float tile[32][33];
-    const int ch0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
-    // phase 2's operand first: its loads fly while phase 1 reduces (one dependent round trip instead of two)
-    float wv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = ch0 + ty + 8 * i, j = j0 + tx;
-        wv[i] = (ch < C && j < c) ? bf16_bits_to_f32(W[(int64_t)ch * ldw + j]) : 0.f;
-    }
-    {
-        const int lc = threadIdx.x >> 3, sub = threadIdx.x & 7;
-        const int ch = ch0 + lc;
-        float acc = 0.f, s1 = 0.f, sq = 0.f;
-        if (ch < C) {
-            if (P)
-                for (int j = sub; j < c; j += 8) acc += P[(int64_t)ch * ldp + j] * bf16_bits_to_f32(W[(int64_t)ch * ldw + j]);
-            for (int r = sub; r < slices; r += 8) {
-                s1 += sg_slices[(int64_t)r * sg_pitch + ch];
-                sq += sg_slices[(int64_t)r * sg_pitch + C + ch];
-            }
-        }
-#pragma unroll
-        for (int o = 4; o > 0; o >>= 1) { acc += __shfl_xor(acc, o, 64); s1 += __shfl_xor(s1, o, 64); sq += __shfl_xor(sq, o, 64); }
-        if (sub == 0 && ch < C) {
-            const float mu = stats[ch], invstd = stats[C + ch];
-            const float s2 = P ? invstd * (acc - mu * s1) : sq;        // sum g~ xhat
-            const float A = gamma[ch] * invstd;
-            const float B = -A * (float)((double)s2 / count) * invstd;
-            const float D = -A * (float)((double)s1 / count) - B * mu;
-            if (blockIdx.y == 0) {
-                dbeta[ch] = s1;
-                dgamma[ch] = s2;
-                coef[ch] = A; coef[C + ch] = B; coef[2 * C + ch] = D;
-            }
-            cA[lc] = A; cB[lc] = B;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = ty + 8 * i;
-        const int ch = ch0 + r, j = j0 + tx;
-        if (ch < C && j < c) BW[(int64_t)ch * c + j] = f32_to_bf16_bits(cB[r] * wv[i]);
-        tile[r][tx] = (ch < C) ? cA[r] * wv[i] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = ty; r < 32; r += 8) {
-        const int j = j0 + r, ch = ch0 + tx;
-        if (j < c && ch < C) wt[(int64_t)j * ldwt + ch] = f32_to_bf16_bits(tile[tx][r]);
-    }
-}
-
 // 64 x 64 output tile (4 x 4 per thread) of  Out[r][q] = sum_k L(r, k) R(k, q),  k staged through LDS 32 at a time.
 // LF(row, k) / RF(k, col) return 0 outside the problem.  After every staged chunk `each(k0)` runs with the chunk still in LDS
 // (rs[k][col] = R(k0 + k, q0 + col)).
@@ -139,47 +74,227 @@ __device__ __forceinline__ void tile_gemm64(int kbeg, int K, LF lf, RF rf, EF ea
     }
 }
 
-// Gm[jo][i] = sum_ch BW[ch][jo] W[ch][i]  ->  wt[jo][C + i] (bf16);  bias[jo] = sum_ch D[ch] W[ch][jo].
-// Two launches, because a lone block walking all C channels is a chain of C / 32 dependent memory round trips on a loaded
-// memory system (160 us measured in the step):  (1) grid ((c/64)^2, C/kGmK): every block one kGmK-channel slice of one 64 x 64
-// tile -> fp32 slab [slice][c][c], the diagonal tiles also their slice of the bias -> [slice][c] behind the slabs;
-// (2) sum of the slices in a fixed order (deterministic), bf16 conversion into the stacked weights.
-constexpr int kGmK = 64;
-__global__ void __launch_bounds__(256) bn3_gm_slab_kernel(const unsigned short* W, int ldw, const unsigned short* BW, const float* coef,
-                                                          int C, int c, float* slab, float* bias_slab) {
-    __shared__ __attribute__((aligned(16))) float ls[32][kTP], rs[32][kTP];
-    __shared__ float dsl[kGmK];
-    const int nt = (c + 63) / 64;
-    const int jo0 = (blockIdx.x / nt) * 64, i0 = (blockIdx.x % nt) * 64;
-    const int kb = blockIdx.y * kGmK;
-    const int ke = kb + kGmK < C ? kb + kGmK : C;
-    const bool diag = jo0 == i0;
-    // (D of this channel slice goes through LDS with the first batch of loads: read inside the chunk loop it was one more
-    // dependent round trip per chunk; the first barrier of tile_gemm64 publishes it)
-    if (threadIdx.x < kGmK) dsl[threadIdx.x] = kb + (int)threadIdx.x < C ? coef[2 * C + kb + threadIdx.x] : 0.f;
-    float bacc = 0.f;
-    float acc[4][4];
-    tile_gemm64(
-        kb, ke,
-        [&](int row, int ch) { return (ch < ke && jo0 + row < c) ? bf16_bits_to_f32(BW[(int64_t)ch * c + jo0 + row]) : 0.f; },
-        [&](int ch, int col) { return (ch < ke && i0 + col < c) ? bf16_bits_to_f32(W[(int64_t)ch * ldw + i0 + col]) : 0.f; },
-        [&](int ch0) {
-            if (diag && threadIdx.x < 64) {
-                const int lim = ke - ch0 < 32 ? ke - ch0 : 32;
-                for (int r = 0; r < lim; ++r) bacc += dsl[ch0 - kb + r] * rs[r][threadIdx.x];
-            }
-        },
-        acc, ls, rs);
-    const int tj = (threadIdx.x >> 4) * 4, ti = (threadIdx.x & 15) * 4;
-    float* out = slab + (int64_t)blockIdx.y * c * c;
-#pragma unroll
-    for (int a_ = 0; a_ < 4; ++a_) {
-        const int jo = jo0 + tj + a_, i = i0 + ti;
-        if (jo < c && i < c) *reinterpret_cast<float4*>(out + (int64_t)jo * c + i) = make_float4(acc[a_][0], acc[a_][1], acc[a_][2], acc[a_][3]);
-    }
-    if (diag && threadIdx.x < 64 && jo0 + (int)threadIdx.x < c) bias_slab[(int64_t)blockIdx.y * c + jo0 + threadIdx.x] = bacc;
+// ---------------------------------------------------------------------------------------------------------------
+// Everything between the producer's partial rows and the stacked-weights data gradient in ONE launch (+ the slab sum below):
+// round 3 ran four dependent launches here (slice sums, coefficients, c x c products, slab sum: 50-90 us per block inside the
+// step, with 40-85 us idle gaps behind them on the compute stream).
+// Grid (C / 64 channel groups, S row slices).  Phase 1, every block: the slice's column sums of its group's 128 columns
+// (sum g~ and sum g~ xhat of 64 channels), published with agent-scope atomic exchanges, one ticket per group (the fence-free
+// protocol of bn_reduce_finalize_kernel).  Phase 2, the LAST block of a group: the S slices in order -> sums; (A, B, D), dgamma,
+// dbeta of its 64 channels; the g~ half of the stacked weights wt[j][ch] = bf16(A[ch] W[ch][j]); and the group's share of the a2
+// half, slab[g][jo][i] = sum_{ch in g} bf16(B[ch] W[ch][jo]) W[ch][i] on the matrix pipe (K = 64 channels: two
+// v_mfma_f32_16x16x32_bf16 per 16 x 16 tile, fragments by ds_read_b64_tr_b16 from two swizzled [64][c] LDS tiles), plus
+// bias_slab[g][jo] = sum_ch D[ch] W[ch][jo].  c in {64, 128, 256}.
+typedef __attribute__((address_space(3))) const unsigned char lds_cu8;
+__device__ __forceinline__ s16x4 tr_read_lds(const unsigned char* p) {       // (inline asm: see tr_read in conv_wgrad.hip)
+    s16x4 v;
+    const unsigned a = (unsigned)(unsigned long long)(lds_cu8*)(p);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// byte offset of logical byte column colb of row `row` in a [rows][rb] tile: conflict-free for the transposing reads
+__device__ __forceinline__ int swz_addr(int row, int colb, int rb) {
+    const int key = rb >= 256 ? (row & 7) : ((row >> 1) & 3);
+    return row * rb + ((((colb >> 5) ^ key)) << 5) + (colb & 31);
 }
 
+constexpr int kGC = 64;                                  // channels per group
+// (c is a template parameter: with a run-time trip count hipcc branches around every load of the batched requests below and
+// waits for each one separately)
+template <int c>
+__global__ void __launch_bounds__(256) bn3_prep_kernel(const float* P, int ldp, const unsigned short* W, int ldw, const float* partial,
+                                                       int nrows, int rows_per_slice, const float* stats, const float* gamma, int C,
+                                                       double count, float* slices, int* tickets, float* coef, float* dgamma, float* dbeta,
+                                                       unsigned short* wt, int ldwt, float* slab, float* bias_slab) {
+    __shared__ __attribute__((aligned(1024))) unsigned char tiles[2 * kGC * 512];      // W and B o W, [64][c] bf16 each
+    __shared__ double shd[256];
+    __shared__ float cA[kGC], cB[kGC], cD[kGC], ssum[2 * kGC];
+    __shared__ int last;
+    const int g = blockIdx.x, sl = blockIdx.y, S = gridDim.y;
+    const int ch0 = g * kGC, C2 = 2 * C;
+    const int t = threadIdx.x;
+    // ---- phase 1: this slice's sums of the group's 128 columns (two threads per column, interleaved rows, fixed order)
+    {
+        const int col = t & 127, half = t >> 7;
+        const int ch = ch0 + (col & 63);
+        const int gcol = (col < 64 ? 0 : C) + ch;
+        const int r0 = sl * rows_per_slice;
+        int r1 = r0 + rows_per_slice; if (r1 > nrows) r1 = nrows;
+        double a = 0.0;
+        if (ch < C) {
+            // every dependent round trip costs 3-5 us while the other streams saturate the memory system: 32 rows in flight
+            // per thread, i.e. one or two batches per slice
+            for (int rb_ = r0 + half; rb_ < r1; rb_ += 64) {
+                float v[32];
+                // (unconditional loads from a clamped row, masked afterwards: a conditional load is branched around and waited
+                // for on its own - 32 dependent round trips instead of one)
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int r = rb_ + 2 * i;
+                    v[i] = partial[(int64_t)(r < r1 ? r : r1 - 1) * C2 + gcol];
+                }
+#pragma unroll
+                for (int i = 0; i < 32; ++i) a += (rb_ + 2 * i < r1) ? (double)v[i] : 0.0;
+            }
+        }
+        shd[t] = a;
+        __syncthreads();
+        float keep = 0.f;
+        if (t < 128 && ch < C)
+            keep = __hip_atomic_exchange(slices + (int64_t)sl * C2 + gcol, (float)(shd[t] + shd[t + 128]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" : : "v"(keep) : "memory");        // this wave's exchanges have returned
+        __syncthreads();
+        if (t == 0) {
+            const int tk = __hip_atomic_fetch_add(tickets + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (tk == S - 1);
+        }
+        __syncthreads();
+        if (!last) return;
+    }
+    // ---- phase 2: the last block of channel group g.  Everything it needs from memory is requested in ONE batch (the slices,
+    // its rows of W and P, the statistics): two dependent round trips to the coefficients instead of six
+    constexpr int rb = c * 2, cpr = c / 8;                 // row bytes, 16-byte chunks per row
+    constexpr int nchunk = kGC * cpr / 256;                 // W chunks per thread: 2 / 4 / 8
+    u32x4 wreg[nchunk];
+#pragma unroll
+    for (int k = 0; k < nchunk; ++k) {
+        const int idx = t + 256 * k, row = idx / cpr, q = idx - row * cpr;
+        wreg[k] = *reinterpret_cast<const u32x4*>(W + (int64_t)(ch0 + row < C ? ch0 + row : 0) * ldw + q * 8);
+        if (ch0 + row >= C) wreg[k] = u32x4{0u, 0u, 0u, 0u};
+    }
+    // P rows for sum_j P[ch][j] W[ch][j] (only with P; without it the same loads read the head of `partial` and are dropped):
+    // 4 threads per channel, a contiguous quarter of the row each
+    const int lc4 = t >> 2, sub4 = t & 3;
+    const bool chv = ch0 + lc4 < C;
+    constexpr int pq = c / 16;                              // float4 pieces of P per thread: 4 / 8 / 16
+    const float* prow = (P && chv) ? P + (int64_t)(ch0 + lc4) * ldp + sub4 * (c / 4) : partial;
+    f32x4 preg[pq];
+#pragma unroll
+    for (int k = 0; k < pq; ++k) preg[k] = *reinterpret_cast<const f32x4*>(prow + 4 * k);
+    const int chs = chv ? ch0 + lc4 : 0;
+    const float mu_ = stats[chs], invstd_ = stats[C + chs], gamma_ = gamma[chs];
+    {
+        // slices: threads t and t + 128 take the halves [0, 32) and [32, 64) of column t & 127, all loads in flight
+        const int col = t & 127, hf = t >> 7;
+        const int ch = ch0 + (col & 63);
+        const int gcol = (col < 64 ? 0 : C) + (ch < C ? ch : 0);
+        const int j0 = hf * 32;
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            v[i] = __hip_atomic_load(slices + (int64_t)(j0 + i < S ? j0 + i : S - 1) * C2 + gcol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double a = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a += (j0 + i < S && ch < C) ? (double)v[i] : 0.0;
+        shd[t] = a;
+    }
+    if (t == 0) __hip_atomic_store(tickets + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // W rows of the group -> LDS (swizzled)
+    unsigned char* const WT = tiles;
+    unsigned char* const BT = tiles + kGC * rb;
+#pragma unroll
+    for (int k = 0; k < nchunk; ++k) {
+        const int idx = t + 256 * k, row = idx / cpr, q = idx - row * cpr;
+        *reinterpret_cast<u32x4*>(WT + swz_addr(row, q * 16, rb)) = wreg[k];
+    }
+    __syncthreads();
+    if (t < 128) ssum[t] = (float)(shd[t] + shd[t + 128]);
+    float pw = 0.f;
+    if (P) {
+#pragma unroll
+        for (int k = 0; k < pq; ++k) {
+            const int j = sub4 * (c / 4) + 4 * k;
+            const u32x2 wv = *reinterpret_cast<const u32x2*>(WT + swz_addr(lc4, j * 2, rb));
+            pw += preg[k].x * bf16_bits_to_f32(wv.x & 0xffffu); pw += preg[k].y * __uint_as_float(wv.x & 0xffff0000u);
+            pw += preg[k].z * bf16_bits_to_f32(wv.y & 0xffffu); pw += preg[k].w * __uint_as_float(wv.y & 0xffff0000u);
+        }
+    }
+    pw += __shfl_xor(pw, 1, 64); pw += __shfl_xor(pw, 2, 64);
+    __syncthreads();
+    if (sub4 == 0) {
+        const int lc = lc4, ch = ch0 + lc;
+        float A = 0.f, B = 0.f, D = 0.f;
+        if (ch < C) {
+            const float mu = mu_, invstd = invstd_;
+            const float s1 = ssum[lc];
+            const float s2 = P ? invstd * (pw - mu * s1) : ssum[kGC + lc];        // sum g~ xhat
+            A = gamma_ * invstd;
+            B = -A * (float)((double)s2 / count) * invstd;
+            D = -A * (float)((double)s1 / count) - B * mu;
+            dbeta[ch] = s1; dgamma[ch] = s2;
+            coef[ch] = A; coef[C + ch] = B; coef[2 * C + ch] = D;
+        }
+        cA[lc] = A; cB[lc] = B; cD[lc] = D;
+    }
+    __syncthreads();
+    // B o W beside it
+#pragma unroll
+    for (int k = 0; k < nchunk; ++k) {
+        const int idx = t + 256 * k, row = idx / cpr, q = idx - row * cpr;
+        const u32x4 w = wreg[k];
+        const float b = cB[row];
+        u32x4 bw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            bw[e] = pack_bf16x2(b * bf16_bits_to_f32(w[e] & 0xffffu), b * __uint_as_float(w[e] & 0xffff0000u));
+        *reinterpret_cast<u32x4*>(BT + swz_addr(row, q * 16, rb)) = bw;
+    }
+    __syncthreads();
+    // the g~ half of the stacked weights: wt[j][ch0 + lane] = bf16(A W[ch][j]); a wave writes 128 contiguous bytes per j
+    {
+        const int lane = t & 63, wv = t >> 6;
+        if (ch0 + lane < C) {
+            const float A = cA[lane];
+            for (int j = wv; j < c; j += 4) {
+                const unsigned short wb = *reinterpret_cast<const unsigned short*>(WT + swz_addr(lane, j * 2, rb));
+                wt[(int64_t)j * ldwt + ch0 + lane] = f32_to_bf16_bits(A * bf16_bits_to_f32(wb));
+            }
+        }
+        // bias_slab[g][jo] = sum_ch D[ch] W[ch][jo]
+        if (t < c) {
+            float bsum = 0.f;
+            for (int ch = 0; ch < kGC; ++ch)
+                bsum += cD[ch] * bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(WT + swz_addr(ch, t * 2, rb)));
+            bias_slab[(int64_t)g * c + t] = bsum;
+        }
+    }
+    // slab[g][jo][i] on the matrix pipe: A operand = W (rows i), B operand = B o W (columns jo), K = the group's 64 channels
+    {
+        const int lane = t & 63, wv = t >> 6;
+        const int gq = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+        float* const out = slab + (int64_t)g * c * c;
+        constexpr int nb = c / 16;
+        for (int ib = wv; ib < nb; ib += 4) {
+            s16x8 af[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const s16x4 lo = tr_read_lds(WT + swz_addr(kb * 32 + 4 * gq + q, (ib * 16 + 4 * pp) * 2, rb));
+                const s16x4 hi = tr_read_lds(WT + swz_addr(kb * 32 + 16 + 4 * gq + q, (ib * 16 + 4 * pp) * 2, rb));
+                af[kb] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+            for (int jb = 0; jb < nb; ++jb) {
+                s16x8 bf[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const s16x4 lo = tr_read_lds(BT + swz_addr(kb * 32 + 4 * gq + q, (jb * 16 + 4 * pp) * 2, rb));
+                    const s16x4 hi = tr_read_lds(BT + swz_addr(kb * 32 + 16 + 4 * gq + q, (jb * 16 + 4 * pp) * 2, rb));
+                    bf[kb] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                }
+                lds_fence();
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[0]), __builtin_bit_cast(bf16x8, bf[0]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[1]), __builtin_bit_cast(bf16x8, bf[1]), acc, 0, 0, 0);
+                *reinterpret_cast<f32x4*>(out + (int64_t)(jb * 16 + li) * c + ib * 16 + 4 * gq) = acc;
+            }
+        }
+    }
+}
+
+// sum of the channel-group slabs of bn3_prep_kernel in a fixed order (deterministic), bf16 conversion into the stacked weights
 __global__ void __launch_bounds__(256) bn3_gm_finish_kernel(const float* slab, const float* bias_slab, int slices, int C, int c,
                                                             unsigned short* wt, int ldwt, float* bias) {
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -221,64 +336,39 @@ __global__ void __launch_bounds__(256) bn3_dw_kernel(const float* P, int ldp, co
     }
 }
 
-// stage 1 of the column sums of many partial rows ([2][C] each): slice blockIdx.y of the rows, 32 of the 2 C columns per
-// block -> out[slice][2 C]
-__global__ void __launch_bounds__(256) bn3_slice_sums_kernel(const float* partial, int nrows, int C2, int rows_per_slice, float* out) {
-    __shared__ float sh[256];
-    const int cl = threadIdx.x & 31, ln = threadIdx.x >> 5;
-    const int ch = blockIdx.x * 32 + cl;
-    const int r0 = blockIdx.y * rows_per_slice;
-    int r1 = r0 + rows_per_slice; if (r1 > nrows) r1 = nrows;
-    float a = 0.f;
-    if (ch < C2)
-        for (int r = r0 + ln; r < r1; r += 8) a += partial[(int64_t)r * C2 + ch];
-    sh[ln * 32 + cl] = a;
-    __syncthreads();
-    if (ln == 0 && ch < C2) {
-        float s = 0.f;
-        for (int q = 0; q < 8; ++q) s += sh[q * 32 + cl];
-        out[(int64_t)blockIdx.y * C2 + ch] = s;
-    }
-}
-
 }  // namespace
 
 extern "C" {
 
-int iif_bn3_algebra_coef(const float* P, int ldp, const void* w_bf16, int ldw, const float* partial, int n_partials,
-                         const float* stats, const float* gamma, int C, int c, int64_t m, float* coef, float* dgamma, float* dbeta,
-                         void* wt, int ldwt, void* bw, float* scratch, int64_t scratch_floats, void* stream) {
-    if (!w_bf16 || !partial || !stats || !gamma || !coef || !dgamma || !dbeta || !wt || !bw || !scratch || C <= 0 || c <= 0 ||
-        m <= 0 || n_partials <= 0)
-        return IIF_EINVAL;
-    if (c > 256 || (c % 32) || (P && ldp < c) || ldw < c || ldwt < C + c) return IIF_EUNSUPPORTED;
-    const int slices = n_partials < 64 ? n_partials : 64;
-    if ((int64_t)slices * 2 * C > scratch_floats) return IIF_EINVAL;
-    const int rps = (n_partials + slices - 1) / slices;
-    hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(bn3_slice_sums_kernel, dim3((2 * C + 31) / 32, slices), dim3(256), 0, st, partial, n_partials, 2 * C, rps, scratch);
-    IIF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn3_coef_kernel, dim3((C + 31) / 32, (c + 31) / 32), dim3(256), 0, st, P, ldp, (const unsigned short*)w_bf16, ldw, scratch, slices, 2 * C,
-                       stats, gamma, C, c, (double)m, coef, dgamma, dbeta, (unsigned short*)wt, ldwt, (unsigned short*)bw);
-    IIF_LAUNCH_CHECK();
-    return IIF_OK;
+int64_t iif_bn3_algebra_prep_scratch_floats(int C, int c) {
+    const int64_t G = (C + kGC - 1) / kGC;
+    return (int64_t)64 * 2 * C + G * ((int64_t)c * c + c);
 }
 
-int64_t iif_bn3_algebra_gm_scratch_floats(int C, int c) { return (int64_t)((C + kGmK - 1) / kGmK) * ((int64_t)c * c + c); }
-
-int iif_bn3_algebra_gm(const void* w_bf16, int ldw, const void* bw, const float* coef, int C, int c, void* wt, int ldwt, float* bias,
-                       float* scratch, int64_t scratch_floats, void* stream) {
-    if (!w_bf16 || !bw || !coef || !wt || !bias || !scratch || C <= 0 || c <= 0) return IIF_EINVAL;
-    if (c > 256 || (c % 4) || ldw < c || ldwt < C + c) return IIF_EUNSUPPORTED;
-    if (scratch_floats < iif_bn3_algebra_gm_scratch_floats(C, c)) return IIF_EINVAL;
-    const int slices = (C + kGmK - 1) / kGmK, nt = (c + 63) / 64;
-    float* bias_slab = scratch + (int64_t)slices * c * c;
+int iif_bn3_algebra_prep(const float* P, int ldp, const void* w_bf16, int ldw, const float* partial, int n_partials,
+                         const float* stats, const float* gamma, int C, int c, int64_t m, float* coef, float* dgamma, float* dbeta,
+                         void* wt, int ldwt, float* bias, float* scratch, int64_t scratch_floats, int32_t* tickets, void* stream) {
+    if (!w_bf16 || !partial || !stats || !gamma || !coef || !dgamma || !dbeta || !wt || !bias || !scratch || !tickets || C <= 0 ||
+        c <= 0 || m <= 0 || n_partials <= 0)
+        return IIF_EINVAL;
+    if ((c != 64 && c != 128 && c != 256) || (P && ldp < c) || ldw < c || (ldw % 8) || ldwt < C + c) return IIF_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(w_bf16) & 15) != 0) return IIF_EUNSUPPORTED;
+    if (scratch_floats < iif_bn3_algebra_prep_scratch_floats(C, c)) return IIF_EINVAL;
+    const int G = (C + kGC - 1) / kGC;
+    if (G > 64) return IIF_EUNSUPPORTED;                  // tickets: int32[64]
+    const int slices = n_partials < 64 ? n_partials : 64;
+    const int rps = (n_partials + slices - 1) / slices;
+    const int S = (n_partials + rps - 1) / rps;
+    float* slab = scratch + (int64_t)64 * 2 * C;
+    float* bias_slab = slab + (int64_t)G * c * c;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(bn3_gm_slab_kernel, dim3(nt * nt, slices), dim3(256), 0, st, (const unsigned short*)w_bf16, ldw,
-                       (const unsigned short*)bw, coef, C, c, scratch, bias_slab);
+#define IIF_PREP(CC) hipLaunchKernelGGL(bn3_prep_kernel<CC>, dim3(G, S), dim3(256), 0, st, P, ldp, (const unsigned short*)w_bf16, ldw, partial, \
+                                        n_partials, rps, stats, gamma, C, (double)m, scratch, tickets, coef, dgamma, dbeta, (unsigned short*)wt, ldwt, slab, bias_slab)
+    if (c == 64) IIF_PREP(64); else if (c == 128) IIF_PREP(128); else IIF_PREP(256);
+#undef IIF_PREP
     IIF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn3_gm_finish_kernel, dim3((c * c + 255) / 256), dim3(256), 0, st, scratch, bias_slab, slices, C, c,
-                       (unsigned short*)wt, ldwt, bias);
+    hipLaunchKernelGGL(bn3_gm_finish_kernel, dim3((c * c + 255) / 256), dim3(256), 0, st, slab, bias_slab, G, C, c, (unsigned short*)wt, ldwt,
+                       bias);
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }

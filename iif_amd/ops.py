@@ -488,24 +488,18 @@ def conv_dgrad2_bnbwd(src, src2, wt, bias, out, up_x=None, up_bits=None, up_stat
     return nt.value
 
 
-def bn3_algebra_coef(P, w_bf16, c, partial, n_partials, stats, gamma, m, coef, dgamma, dbeta, wt, bw, scratch):
+def bn3_algebra_prep_scratch(C, c, device):
+    return torch.empty(lib().iif_bn3_algebra_prep_scratch_floats(C, c), dtype=torch.float32, device=device)
+
+
+def bn3_algebra_prep(P, w_bf16, c, partial, n_partials, stats, gamma, m, coef, dgamma, dbeta, wt, bias, scratch, tickets):
     """P [C, ldp] fp32 (or None: sum g~ xhat comes from the second half of the partial rows), w_bf16 [C, ldw] (c valid
-    columns), the producer's partial rows -> coef [3, C], dgamma, dbeta, wt[:, :C] (stacked bf16 weights [c, ldwt]) and
-    bw [C, c] = bf16(B o W)."""
+    columns), the producer's partial rows -> coef [3, C], dgamma, dbeta, the stacked bf16 weights wt [c, ldwt >= C + c]
+    (g~ half and a2 half) and bias [c].  tickets: int32[64], zero before the first call (self-resetting)."""
     C = w_bf16.shape[0]
-    check(lib().iif_bn3_algebra_coef(ptr(P), 0 if P is None else P.stride(0), ptr(w_bf16), w_bf16.stride(0), ptr(partial), n_partials, ptr(stats),
-                                     ptr(gamma), C, c, int(m), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(wt), wt.stride(0), ptr(bw),
-                                     ptr(scratch), scratch.numel(), stream_ptr()), "iif_bn3_algebra_coef")
-
-
-def bn3_algebra_gm_scratch(C, c, device):
-    return torch.empty(lib().iif_bn3_algebra_gm_scratch_floats(C, c), dtype=torch.float32, device=device)
-
-
-def bn3_algebra_gm(w_bf16, c, bw, coef, wt, bias, scratch):
-    C = w_bf16.shape[0]
-    check(lib().iif_bn3_algebra_gm(ptr(w_bf16), w_bf16.stride(0), ptr(bw), ptr(coef), C, c, ptr(wt), wt.stride(0), ptr(bias),
-                                   ptr(scratch), scratch.numel(), stream_ptr()), "iif_bn3_algebra_gm")
+    check(lib().iif_bn3_algebra_prep(ptr(P), 0 if P is None else P.stride(0), ptr(w_bf16), w_bf16.stride(0), ptr(partial), n_partials, ptr(stats),
+                                     ptr(gamma), C, c, int(m), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(wt), wt.stride(0), ptr(bias),
+                                     ptr(scratch), scratch.numel(), ptr(tickets), stream_ptr()), "iif_bn3_algebra_prep", tickets)
 
 
 def bn3_algebra_dw(P, w_bf16, c, gram, csum, coef, dW):

@@ -771,7 +771,7 @@ class _Plan(object):
                     continue
                 u3 = b["units"][-1]
                 cv3 = u3.conv
-                if (cv3.k == 1 and cv3.stride == 1 and cv3.groups == 1 and cv3.cin % 32 == 0 and cv3.cin <= a3_maxc and cv3.cout % 64 == 0
+                if (cv3.k == 1 and cv3.stride == 1 and cv3.groups == 1 and cv3.cin in (64, 128, 256) and cv3.cin <= a3_maxc and cv3.cout % 64 == 0 and cv3.cout <= 4096
                         and _dma_ok(u3.x) and u3.n * u3.ho * u3.wo < (1 << 30) and u3.n * u3.ho * u3.wo * cv3.cout >= a3_min):
                     self.alg3_units.add(u3)
         # Two-pass forward (conv3's raw output is never stored): pass 1 = statistics only, pass 2 = the same convolution with
@@ -796,11 +796,11 @@ class _Plan(object):
             F = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)   # noqa: E731
             # per-block scratch rotates over wg_lag slots (the weight-gradient stream finishes block b before block b - wg_lag
             # starts: _wgrad_fence); Gram / colsum are issued one block AHEAD on another stream, so they rotate over wg_lag + 1
-            self.a3 = [{"P": F(Cm, ldm), "scr": F(128 * Cm), "coef": F(3, Cm), "bias": F(cm),
+            self.a3 = [{"P": F(Cm, ldm), "coef": F(3, Cm), "bias": F(cm),
                         "wt": torch.zeros(cm * (Cm + cm), dtype=dt, device=dev),
-                        "bw": torch.zeros(Cm * cm, dtype=dt, device=dev),
-                        "gms": torch.empty(max(ops.lib().iif_bn3_algebra_gm_scratch_floats(u.conv.cout, u.conv.cin)
-                                               for u in self.alg3_units), dtype=torch.float32, device=dev)}
+                        "scr": torch.empty(max(ops.lib().iif_bn3_algebra_prep_scratch_floats(u.conv.cout, u.conv.cin)
+                                               for u in self.alg3_units), dtype=torch.float32, device=dev),
+                        "tickets": torch.zeros(64, dtype=torch.int32, device=dev)}
                        for _ in range(self.wg_lag)]
             self.a3g = [{"gram": F(cm, ldm), "csum": F(2, cm), "ws_gram": torch.empty(64 << 20, dtype=torch.uint8, device=dev),
                          "ws_sum": ops.bn_workspace(max(u.n * u.ho * u.wo for u in self.alg3_units), cm, dev), "ev": None}
@@ -1355,8 +1355,8 @@ class _Plan(object):
             ops.conv_wgrad(u.src, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=self.a3_ws)
         wt = A["wt"][:c * (C + c)].view(c, C + c)
         coef = A["coef"][:, :C]
-        ops.bn3_algebra_coef(P if pure else None, wb, c, self.bw_partial, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt, A["bw"], A["scr"])
-        ops.bn3_algebra_gm(wb, c, A["bw"], coef, wt, A["bias"][:c], A["gms"])
+        ops.bn3_algebra_prep(P if pure else None, wb, c, self.bw_partial, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt,
+                             A["bias"][:c], A["scr"], A["tickets"])
         # the weight gradient needs Gram / colsum (issued a block ahead) and nothing on the critical path needs it
         gram_ev = Ag["ev"]
 
@@ -1501,18 +1501,20 @@ class _Plan(object):
                 # the shortcut's gradient was computed next to the main branch: the first unit's dgrad adds it
                 torch.cuda.current_stream().wait_event(ds_done)
                 self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=gin_ds, par=par, fuse_up=up_in)
+            elif "ds" in b and lazy_mask:
+                # no shortcut stream: the same order on the compute stream - the shortcut's backward first (its dx in a buffer
+                # of its own: g is still read by the gated identity add and, on the algebraic route, by the P GEMM of the
+                # weight-gradient stream), then the first unit's data gradient adds it and carries the upstream sums, so the
+                # previous block's last unit takes the same route as with the stream
+                du = b["ds"]
+                gin_ds = self._gbuf(("ginds", tuple(inp.shape), par), inp.shape)
+                pending, self._bw_ready = self._bw_ready, None          # the fused sums waiting for `first` are not the shortcut's
+                self._unit_backward(du, g, last.y, mask_bits=last.bits, keep_gy=True, dgrad_out=gin_ds, par=par, dxkey="dxds")
+                self._bw_ready = pending
+                self._unit_backward(first, d, first.y, dgrad_out=gin, dgrad_res=gin_ds, par=par, fuse_up=up_in)
             elif "ds" in b:
                 self._unit_backward(first, d, first.y, dgrad_out=gin, par=par)
-                du = b["ds"]
-                if lazy_mask:
-                    # in place (g is not needed after the shortcut's BN backward) - unless the block's last unit went the
-                    # algebraic route with P on the weight-gradient stream: that GEMM still reads g itself (not a private
-                    # dx copy), so the shortcut's dx goes to its own buffer
-                    alias = last in self.alg3_units and not self._a3_is_pure(last) and self.wg_stream is not None
-                    self._unit_backward(du, g, last.y, mask_bits=last.bits, dgrad_out=gin, dgrad_res=gin, par=par,
-                                        fuse_up=up_in, keep_gy=alias, dxkey="dxds" if alias else "dx")
-                else:
-                    self._unit_backward(du, g, None, dgrad_out=gin, dgrad_res=gin, par=par, fuse_up=up_in)
+                self._unit_backward(b["ds"], g, None, dgrad_out=gin, dgrad_res=gin, par=par, fuse_up=up_in)
             elif "sc" in b:
                 self._unit_backward(first, d, first.y, dgrad_out=gin, par=par)
                 ops.shortcut_a_backward_acc(g, gin)

@@ -395,18 +395,18 @@ int iif_conv3x3_frag_ok(const iif_conv_desc* d);
  *   iif_conv_igemm_dgrad_masksum  the data gradient that PRODUCES the block-output gradient stores it gated by up_bits and
  *                                 emits per tile into `partial` either (sum dst, 0) (up_x NULL: no read of y) or, with up_x /
  *                                 up_stats (y and its batch statistics), (sum dst, sum dst * xhat) as iif_conv_igemm_dgrad_bnbwd;
- *   iif_bn3_algebra_coef          those partial rows (scratch >= 128 C floats), W (the bf16 copy the forward used) and EITHER
- *                                 P (sum g~ y = rowdot(P, W): y is never read, but P is needed before the data gradient) OR
- *                                 P = NULL (sum g~ xhat from the second half of the rows: y is read once by the producer and
- *                                 P is only needed for dW, off the critical path) -> coef [3][C] = (A, B, D), dgamma, dbeta,
- *                                 the g~ half of the stacked bf16 weights wt [c][ldwt >= C + c]: wt[j][ch] = A[ch] W[ch][j],
- *                                 and bw [C][c] = bf16(B[ch] W[ch][j]);
- *   iif_bn3_algebra_gm            the a2 half: wt[j][C + i] = sum_ch bw[ch][j] W[ch][i], and bias[j] = sum_ch D[ch] W[ch][j]
- *                                 (scratch: iif_bn3_algebra_gm_scratch_floats(C, c) floats of channel-slice slabs);
+ *   iif_bn3_algebra_prep          those partial rows, W (the bf16 copy the forward used) and EITHER P (sum g~ y = rowdot(P, W):
+ *                                 y is never read, but P is needed before the data gradient) OR P = NULL (sum g~ xhat from the
+ *                                 second half of the rows: y is read once by the producer and P is only needed for dW, off the
+ *                                 critical path) -> coef [3][C] = (A, B, D), dgamma, dbeta and the stacked bf16 weights
+ *                                 wt [c][ldwt >= C + c]: wt[j][ch] = A[ch] W[ch][j], wt[j][C + i] = sum_ch bf16(B[ch] W[ch][j]) W[ch][i],
+ *                                 and bias[j] = sum_ch D[ch] W[ch][j].  Two launches (one ticketed kernel over channel groups x row
+ *                                 slices, one slab sum); scratch: iif_bn3_algebra_prep_scratch_floats(C, c) floats; tickets:
+ *                                 int32[64], zero on entry, zero again on exit.  c in {64, 128, 256}, C <= 4096;
  *   iif_conv_igemm_dgrad2_bnbwd   dst = [src | src2] wgt^T + bias (1x1, stride 1, bf16; K runs over src's cs then src2's cs2
  *                                 channels), optionally with the upstream BN-backward sums of iif_conv_igemm_dgrad_bnbwd;
  *   iif_bn3_algebra_dw            dW [C][lddw] from P, W, Gram, csum, coef.
- * c <= 256 (the 56x56 ... 14x14 stages of the ImageNet networks).  Everything sums in a fixed order. */
+ * c in {64, 128, 256} (the 56x56 ... 14x14 stages of the ImageNet networks).  Everything sums in a fixed order. */
 /* Two-pass forward of conv + BN (+ identity) + ReLU for the expanding 1x1 layer of a bottleneck (resnet_pytorch.py:160-167),
  * bf16, 1x1 / stride 1: the raw convolution output is never stored.
  *   iif_conv_igemm_stats_only   pass 1: the per-tile (sum, sum of squares) partial rows of iif_conv_igemm_bnstats — same
@@ -426,12 +426,10 @@ int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* src, const v
                                 const float* bias, void* dst, const void* up_x, const unsigned char* up_bits,
                                 const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,
                                 void* stream);
-int iif_bn3_algebra_coef(const float* P, int ldp, const void* w_bf16, int ldw, const float* partial, int n_partials,
+int64_t iif_bn3_algebra_prep_scratch_floats(int C, int c);
+int iif_bn3_algebra_prep(const float* P, int ldp, const void* w_bf16, int ldw, const float* partial, int n_partials,
                          const float* stats, const float* gamma, int C, int c, int64_t m, float* coef, float* dgamma, float* dbeta,
-                         void* wt, int ldwt, void* bw, float* scratch, int64_t scratch_floats, void* stream);
-int64_t iif_bn3_algebra_gm_scratch_floats(int C, int c);
-int iif_bn3_algebra_gm(const void* w_bf16, int ldw, const void* bw, const float* coef, int C, int c, void* wt, int ldwt, float* bias,
-                       float* scratch, int64_t scratch_floats, void* stream);
+                         void* wt, int ldwt, float* bias, float* scratch, int64_t scratch_floats, int32_t* tickets, void* stream);
 int iif_bn3_algebra_dw(const float* P, int ldp, const void* w_bf16, int ldw, const float* gram, int ldg, const float* csum,
                        const float* coef, int C, int c, float* dW, int lddw, void* stream);
 

@@ -695,12 +695,13 @@ def test_bn3_backward_by_algebra(case, from_p):
     dgam, dbet = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     wt = torch.zeros(c, C + c, dtype=dt, device=DEV)
     bias = torch.empty(c, device=DEV)
-    bw = torch.empty(C, c, dtype=dt, device=DEV)
     if from_p:
-        part[:, 1] = float("nan")                                    # never read: sum g~ y comes from rowdot(P, W)
-    ops.bn3_algebra_coef(P if from_p else None, Wd, c, part, npart, stats, d(gamma), m, coef, dgam, dbet, wt, bw,
-                         torch.empty(128 * C, device=DEV))
-    ops.bn3_algebra_gm(Wd, c, bw, coef, wt, bias, ops.bn3_algebra_gm_scratch(C, c, DEV))
+        part[:, 1] = 1e30                                            # (summed, never used: sum g~ y comes from rowdot(P, W))
+    tickets = torch.zeros(64, dtype=torch.int32, device=DEV)
+    for _ in range(2):                                               # twice: the tickets reset themselves
+        ops.bn3_algebra_prep(P if from_p else None, Wd, c, part, npart, stats, d(gamma), m, coef, dgam, dbet, wt, bias,
+                             ops.bn3_algebra_prep_scratch(C, c, DEV), tickets)
+    assert not tickets.any()
     da = torch.full((n, hw, hw, c), float("nan"), dtype=dt, device=DEV)
     ops.conv_dgrad2_bnbwd(gtd, a2d, wt, bias, da)
     dW = torch.zeros(C, ldw, device=DEV)
