@@ -372,86 +372,123 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
         for (int q = 0; q < 8; ++q) sb[q] = a.sbias[n + q];
     }
     if (n < a.Cd) {
-        // (issuing the residual / upstream-x loads of 4 rows ahead of the stores was measured 2-3 % slower end to end)
-#pragma unroll 4
-        for (int row = r0; row < BM; row += RPP) {
-            const int m = m0 + row;
-            if (m >= a.M) break;
-            u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PITCH + chunk * 16);
-            const int64_t o = (dst_row(a, m) * a.dpitch + goff + n) * 2;
-            if (a.sbias) {                          // block-uniform
+        // Everything a batch of RBATCH rows needs from memory (residual, its ReLU bits, the upstream bits, the upstream x) is
+        // requested before the first row is touched, UNCONDITIONALLY: an operand the launch does not have is read from one
+        // fixed dummy address (the head of the weights: an L1 hit).  Round 3 loaded each operand under its own `if (a.res)` /
+        // `if (a.bw_x)`: hipcc branches around such a load and waits for it on its own, so a thread went through its 8 rows in
+        // 24-32 dependent memory round trips (20-25 us per tile under load; the data gradients with fused epilogues took
+        // 12 tile rounds x 25 us at 56 x 56).  Now: one round trip per batch.
+        constexpr int RT = BM / RPP;                    // rows per thread (8; 4 for the 64-channel tile)
+        constexpr int RBATCH = RT < 2 ? RT : 2;        // (4 rows per batch: 133 registers in the 256-row kernel, one block per CU instead of two)
+        static_assert(RT % RBATCH == 0, "row batches");
+        const unsigned char* const dummy = a.wgt;
+        const bool has_res = a.res != nullptr, has_rb = a.res_bits != nullptr, has_bx = a.bw_x != nullptr;
+        const bool has_bb = a.bw_bits != nullptr;
+        const bool res_nt = a.aff == nullptr;           // the fused block-output epilogue re-reads its residual soon: keep it cached
+#pragma unroll 1
+        for (int b0 = 0; b0 < RT; b0 += RBATCH) {
+            int64_t ob[RBATCH];
+            bool live[RBATCH];
+            u32x4 rrv[RBATCH], xvv[RBATCH];
+            unsigned rbv[RBATCH], mbv[RBATCH];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    v[q] = pack_bf16x2(bf16_bits_to_f32(v[q] & 0xffffu) + sb[2 * q], __uint_as_float(v[q] & 0xffff0000u) + sb[2 * q + 1]);
+            for (int i = 0; i < RBATCH; ++i) {
+                const int m = m0 + r0 + (b0 + i) * RPP;
+                live[i] = m < a.M;
+                ob[i] = (dst_row(a, live[i] ? m : a.M - 1) * a.dpitch + goff + n) * 2;
             }
-            if (a.aff) {                            // block-uniform: BN affine + identity + ReLU of the block output
-                u32x4 rr = {0u, 0u, 0u, 0u};
-                if (a.res) rr = *reinterpret_cast<const u32x4*>(a.res + o);     // the block input: read again by the next conv1's data gradient... keep it cached
-                unsigned bits = 0;
+            if (res_nt) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float lo = fmaf(bmean[2 * q], bf16_bits_to_f32(v[q] & 0xffffu), bistd[2 * q]);
-                    float hi = fmaf(bmean[2 * q + 1], __uint_as_float(v[q] & 0xffff0000u), bistd[2 * q + 1]);
-                    if (a.res) { lo += bf16_bits_to_f32(rr[q] & 0xffffu); hi += __uint_as_float(rr[q] & 0xffff0000u); }
-                    bits |= (lo > 0.f ? 1u : 0u) << (2 * q);
-                    bits |= (hi > 0.f ? 1u : 0u) << (2 * q + 1);
-                    v[q] = pack_bf16x2(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
-                }
-                if (a.relu_out) a.relu_out[o >> 4] = (unsigned char)bits;
-            } else if (a.res) {
+                for (int i = 0; i < RBATCH; ++i)
 #ifndef IIF_NO_NT_EPILOGUE_LOADS   // the residual's last use
-                const u32x4 rr = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res + o));
+                    rrv[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(has_res ? a.res + ob[i] : dummy));
 #else
-                const u32x4 rr = *reinterpret_cast<const u32x4*>(a.res + o);
+                    rrv[i] = *reinterpret_cast<const u32x4*>(has_res ? a.res + ob[i] : dummy);
 #endif
-                const unsigned rb = a.res_bits ? a.res_bits[o >> 4] : 0xffu;
+            } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float lo = bf16_bits_to_f32(v[q] & 0xffffu) + ((rb >> (2 * q)) & 1u ? bf16_bits_to_f32(rr[q] & 0xffffu) : 0.f);
-                    const float hi = __uint_as_float(v[q] & 0xffff0000u) + ((rb >> (2 * q + 1)) & 1u ? __uint_as_float(rr[q] & 0xffff0000u) : 0.f);
-                    v[q] = pack_bf16x2(lo, hi);
-                }
+                for (int i = 0; i < RBATCH; ++i) rrv[i] = *reinterpret_cast<const u32x4*>(has_res ? a.res + ob[i] : dummy);
             }
-            if (a.mask_store) {                     // block-uniform: the stored gradient is gated by the upstream ReLU bits
-                const unsigned mb = a.bw_bits[o >> 4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned lo = (mb >> (2 * q)) & 1u ? (v[q] & 0xffffu) : 0u;
-                    const unsigned hi = (mb >> (2 * q + 1)) & 1u ? (v[q] & 0xffff0000u) : 0u;
-                    v[q] = lo | hi;
-                    if (!a.bw_x) { bs[2 * q] += bf16_bits_to_f32(lo); bs[2 * q + 1] += __uint_as_float(hi); }
-                }
-            }
-            if (!a.no_store) {
-#ifndef IIF_NO_NT_CONV_STORE     // the tile is next read by another XCD (BN apply): streaming it out keeps the pixel operand's lines in L2 (-0.7 % on the step)
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + o));
-#else
-                *reinterpret_cast<u32x4*>(a.dst + o) = v;
-#endif
-            }
-            if (a.bw_x) {                           // (with mask_store v is gated already; gating it again below changes nothing)
+            for (int i = 0; i < RBATCH; ++i) {
+                rbv[i] = *(has_rb ? a.res_bits + (ob[i] >> 4) : dummy);
+                mbv[i] = *(has_bb ? a.bw_bits + (ob[i] >> 4) : dummy);
 #ifndef IIF_NO_NT_EPILOGUE_LOADS   // streamed once by this kernel (next reader: the BN backward, from another XCD)
-                const u32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.bw_x + o));
+                xvv[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(has_bx ? a.bw_x + ob[i] : dummy));
 #else
-                const u32x4 xv = *reinterpret_cast<const u32x4*>(a.bw_x + o);
+                xvv[i] = *reinterpret_cast<const u32x4*>(has_bx ? a.bw_x + ob[i] : dummy);
 #endif
-                const unsigned mb = a.bw_bits ? a.bw_bits[o >> 4] : 0xffu;
+            }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float glo = (mb >> (2 * q)) & 1u ? bf16_bits_to_f32(v[q] & 0xffffu) : 0.f;
-                    const float ghi = (mb >> (2 * q + 1)) & 1u ? __uint_as_float(v[q] & 0xffff0000u) : 0.f;
-                    const float xlo = (bf16_bits_to_f32(xv[q] & 0xffffu) - bmean[2 * q]) * bistd[2 * q];
-                    const float xhi = (__uint_as_float(xv[q] & 0xffff0000u) - bmean[2 * q + 1]) * bistd[2 * q + 1];
-                    bs[2 * q] += glo; bq[2 * q] += glo * xlo;
-                    bs[2 * q + 1] += ghi; bq[2 * q + 1] += ghi * xhi;
+            for (int i = 0; i < RBATCH; ++i) {
+                if (!live[i]) continue;
+                const int row = r0 + (b0 + i) * RPP;
+                const int64_t o = ob[i];
+                u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PITCH + chunk * 16);
+                if (a.sbias) {                          // block-uniform
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[q] = pack_bf16x2(bf16_bits_to_f32(v[q] & 0xffffu) + sb[2 * q], __uint_as_float(v[q] & 0xffff0000u) + sb[2 * q + 1]);
                 }
-            } else if (a.mask_store) {              // column sums only, accumulated with the gate above
-            } else if (a.bn_partial) {
+                if (a.aff) {                            // block-uniform: BN affine + identity + ReLU of the block output
+                    const u32x4 rr = rrv[i];
+                    unsigned bits = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float lo = bf16_bits_to_f32(v[q] & 0xffffu), hi = __uint_as_float(v[q] & 0xffff0000u);
-                    bs[2 * q] += lo; bq[2 * q] = fmaf(lo, lo, bq[2 * q]);
-                    bs[2 * q + 1] += hi; bq[2 * q + 1] = fmaf(hi, hi, bq[2 * q + 1]);
+                    for (int q = 0; q < 4; ++q) {
+                        float lo = fmaf(bmean[2 * q], bf16_bits_to_f32(v[q] & 0xffffu), bistd[2 * q]);
+                        float hi = fmaf(bmean[2 * q + 1], __uint_as_float(v[q] & 0xffff0000u), bistd[2 * q + 1]);
+                        if (has_res) { lo += bf16_bits_to_f32(rr[q] & 0xffffu); hi += __uint_as_float(rr[q] & 0xffff0000u); }
+                        bits |= (lo > 0.f ? 1u : 0u) << (2 * q);
+                        bits |= (hi > 0.f ? 1u : 0u) << (2 * q + 1);
+                        v[q] = pack_bf16x2(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
+                    }
+                    if (a.relu_out) a.relu_out[o >> 4] = (unsigned char)bits;
+                } else if (has_res) {
+                    const u32x4 rr = rrv[i];
+                    const unsigned rb = has_rb ? rbv[i] : 0xffu;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16_bits_to_f32(v[q] & 0xffffu) + ((rb >> (2 * q)) & 1u ? bf16_bits_to_f32(rr[q] & 0xffffu) : 0.f);
+                        const float hi = __uint_as_float(v[q] & 0xffff0000u) + ((rb >> (2 * q + 1)) & 1u ? __uint_as_float(rr[q] & 0xffff0000u) : 0.f);
+                        v[q] = pack_bf16x2(lo, hi);
+                    }
+                }
+                const unsigned mb = has_bb ? mbv[i] : 0xffu;
+                if (a.mask_store) {                     // block-uniform: the stored gradient is gated by the upstream ReLU bits
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned lo = (mb >> (2 * q)) & 1u ? (v[q] & 0xffffu) : 0u;
+                        const unsigned hi = (mb >> (2 * q + 1)) & 1u ? (v[q] & 0xffff0000u) : 0u;
+                        v[q] = lo | hi;
+                        if (!has_bx) { bs[2 * q] += bf16_bits_to_f32(lo); bs[2 * q + 1] += __uint_as_float(hi); }
+                    }
+                }
+                if (!a.no_store) {
+#ifndef IIF_NO_NT_CONV_STORE     // the tile is next read by another XCD (BN apply): streaming it out keeps the pixel operand's lines in L2 (-0.7 % on the step)
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + o));
+#else
+                    *reinterpret_cast<u32x4*>(a.dst + o) = v;
+#endif
+                }
+                if (has_bx) {                           // (with mask_store v is gated already; gating it again below changes nothing)
+                    const u32x4 xv = xvv[i];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float glo = (mb >> (2 * q)) & 1u ? bf16_bits_to_f32(v[q] & 0xffffu) : 0.f;
+                        const float ghi = (mb >> (2 * q + 1)) & 1u ? __uint_as_float(v[q] & 0xffff0000u) : 0.f;
+                        const float xlo = (bf16_bits_to_f32(xv[q] & 0xffffu) - bmean[2 * q]) * bistd[2 * q];
+                        const float xhi = (__uint_as_float(xv[q] & 0xffff0000u) - bmean[2 * q + 1]) * bistd[2 * q + 1];
+                        bs[2 * q] += glo; bq[2 * q] += glo * xlo;
+                        bs[2 * q + 1] += ghi; bq[2 * q + 1] += ghi * xhi;
+                    }
+                } else if (a.mask_store) {              // column sums only, accumulated with the gate above
+                } else if (a.bn_partial) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16_bits_to_f32(v[q] & 0xffffu), hi = __uint_as_float(v[q] & 0xffff0000u);
+                        bs[2 * q] += lo; bq[2 * q] = fmaf(lo, lo, bq[2 * q]);
+                        bs[2 * q + 1] += hi; bq[2 * q + 1] = fmaf(hi, hi, bq[2 * q + 1]);
+                    }
                 }
             }
         }
