@@ -451,14 +451,12 @@ inline int stage1_slices(int n_partials, int c, int64_t scratch_floats) {
 
 // partial rows above which the sums are pre-reduced into 64 slices by a separate launch
 inline int two_stage_rows() {
-    static const int v = getenv("IIF_BN_TWO_STAGE_ROWS") ? atoi(getenv("IIF_BN_TWO_STAGE_ROWS")) : 512;
-    return v;
+    return 512;
 }
 
 // channels per finalize block: few channels x many lanes when there are many partial rows
 inline int finalize_cb(int nblk) {
-    static const int t32 = getenv("IIF_BN_FIN_T32") ? atoi(getenv("IIF_BN_FIN_T32")) : 256;
-    return nblk > 2048 ? 4 : (nblk > t32 ? 8 : 32);
+    return nblk > 2048 ? 4 : (nblk > 256 ? 8 : 32);
 }
 
 inline int launch_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
@@ -473,7 +471,7 @@ inline int launch_bn_finalize(const float* partial, int nblk, int C, double coun
 }
 
 inline int stream_blocks(int64_t total_vec) {
-    static const int cap = getenv("IIF_BN_BLOCKS") ? atoi(getenv("IIF_BN_BLOCKS")) : 4096;
+    constexpr int cap = 4096;
     const int64_t b = (total_vec + 255) / 256;
     return (int)(b < cap ? b : cap);
 }

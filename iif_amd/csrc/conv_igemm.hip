@@ -1078,7 +1078,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo128_kernel(ConvArgs a, unsign
 // divisions they were ~4 us of every tile's prologue.
 __device__ __forceinline__ int fdiv(int x, float rd) { return (int)(((float)x + 0.5f) * rd); }
 
-template <int WM, int WN, int TM, int NAP, bool PERSIST, int WD>
+template <int WM, int WN, int TM, int NAP>
 __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_bytes) {
     constexpr int BM = WM * TM, BN = WN * 64, NWV = WM * WN, PJ = TM / 16, CI = 4;
     static_assert(NWV == 4 && BM == 256, "four waves, 256-pixel tiles");
@@ -1086,13 +1086,13 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
     // 8 every window of <= 512 rows (28x28 and smaller)
     constexpr int HR = NAP * NWV * 16, ABUF = HR * 64;   // halo rows per buffer
     constexpr int PITCH = BN * 2 + 16, STG = BM * PITCH;
-    // PERSIST (one block per CU walking tiles): the staged output tile has its own buffer, so the next tile's halo window and
-    // first weights are already in flight while this tile is drained.  Otherwise (two blocks per CU) it overlays the halo buffers.
-    constexpr int SMEM = PERSIST ? 2 * ABUF + STG : (STG > 2 * ABUF ? STG : 2 * ABUF);
-    static_assert(PERSIST ? SMEM <= 160 * 1024 : SMEM <= 80 * 1024, "LDS budget");
+    // two blocks per CU: the staged output tile overlays the halo buffers
+    constexpr int SMEM = STG > 2 * ABUF ? STG : 2 * ABUF;
+    static_assert(SMEM <= 80 * 1024, "LDS budget");
     constexpr unsigned OOB = 0x80000000u;
+    constexpr int WD = 3;                                // weight register sets: two taps ahead
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
-    unsigned char* const stage = PERSIST ? smem + 2 * ABUF : smem;
+    unsigned char* const stage = smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1103,7 +1103,7 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
     const int nchunks = a.Cs / 32;
     // grouped launch (64-channel chunks, non-persistent variant): blockIdx.y = chunk; its source / destination channels start
     // at grp * Cs / grp * Cd of the spitch / dpitch wide tensors, its fragments follow those of the chunks before it
-    const int grp = PERSIST ? 0 : (int)blockIdx.y;
+    const int grp = (int)blockIdx.y;
     const unsigned gsrc = (unsigned)(grp * a.Cs) * 2u;
     const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src), 0, src_bytes, 0x00020000);
     // (buffer loads: ONE address register per lane = lane * 16, the fragment is selected by the scalar offset)
@@ -1182,14 +1182,9 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
     constexpr int NH = 9 * HPT;                            // halves per chunk
     const unsigned smem_base = (unsigned)(uintptr_t)smem;   // LDS byte address of the halo buffers (1 KB aligned)
     const unsigned fcs = (unsigned)fc << 4;
-    // Weights: a ring of NINE taps (144 registers), slot = tap.  vmcnt retires in issue order, so a wait for any register load
-    // also waits for every LDS-DMA piece issued before it: with the weights requested only two taps ahead, the third tap of
-    // every chunk sat waiting for the NEXT chunk's halo window to come back from HBM (~2 us per chunk, measured as 32 % of
-    // the wave cycles in s_waitcnt).  Here the weights of (chunk c + 1, tap t) are requested right after tap t of chunk c has
-    // used its slot: every register load is either older than the halo pieces of its chunk or a whole chunk younger.
-    // (WD = 3: the two-taps-ahead scheme, for the 64-channel variant whose 256 registers cannot hold the ring and whose
-    // layers have two chunks only.)
-    static_assert(WD == 9 || WD == 3, "ring of nine taps, or two taps ahead");
+    // Weights: three register sets, the weights of tap t + 2 requested at the start of tap t.  (Round 3 also built a ring of nine
+    // taps on a persistent 128-channel variant: level with or behind the halo kernel on every shape, removed in round 4;
+    // its phase stamps are in profiles/r3_conv3x3_fragment_kernel.txt.)
     u32x4 wb[WD][CI];
 
 #ifdef IIF_CONV_STAMPS
@@ -1200,7 +1195,7 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
     if (!set_tile(tile)) return;
     issue_halo(0);
 #pragma unroll
-    for (int t = 0; t < (WD == 9 ? 9 : 2); ++t) wload(t, 0, wb[t]);
+    for (int t = 0; t < 2; ++t) wload(t, 0, wb[t]);
     for (;;) {
 #ifdef IIF_CONV_STAMPS
         IIF_STAMP(v_a);
@@ -1248,9 +1243,7 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
             for (int h = 0; h < NH; ++h) {
                 const int t = h / HPT, ph = (h % HPT) * 4;
                 if (h + 1 < NH) read4(ad, xfb[(h + 1) & 1]);
-                if constexpr (WD == 9) {
-                    if (h % HPT == 0 && t > 0 && c + 1 < nchunks) wload(t - 1, c + 1, wb[t - 1]);   // the previous tap's slot is free
-                } else if (h % HPT == 0) {                // start of tap t: the weights of tap t + 2 (of the next chunk at the end)
+                if (h % HPT == 0) {                       // start of tap t: the weights of tap t + 2 (of the next chunk at the end)
                     const int t2 = t + 2 < 9 ? t + 2 : t + 2 - 9, c2 = t + 2 < 9 ? c : c + 1;
                     if (c2 < nchunks) wload(t2, c2, wb[(t + 2) % 3]);
                 }
@@ -1281,8 +1274,7 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
             // chunk boundary: the last tap's slot, then: this wave's halo pieces of chunk c + 1 have landed (everything but the
             // 9 CI loads issued after them = the next chunk's weights), its reads of buffer c & 1 are done; then all waves
             if (c + 1 < nchunks) {
-                if constexpr (WD == 9) wload(8, c + 1, wb[8]);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WD == 9 ? 9 * CI : 2 * CI) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CI) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -1306,17 +1298,7 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
                 w.y = pack_bf16x2(acc[ci][pj].z, acc[ci][pj].w);
                 *reinterpret_cast<u32x2*>(stage + row * PITCH + ch * 2) = w;
             }
-        bool more_tiles = false;
-        if constexpr (PERSIST) {
-            // the next tile's window and first weights fly while this one is drained
-            tile += (int)gridDim.x;
-            more_tiles = set_tile(tile);
-            if (more_tiles) {
-                issue_halo(0);
-#pragma unroll
-                for (int t = 0; t < (WD == 9 ? 9 : 2); ++t) wload(t, 0, wb[t]);
-            }
-        }
+        const bool more_tiles = false;
         __syncthreads();
         staged_drain<BN, BM, 256>(a, stage, dm0, dn0, dmt, grp * a.Cd);
 #ifdef IIF_CONV_STAMPS
@@ -1330,14 +1312,8 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
     }
 }
 
-__global__ void __launch_bounds__(256, 1) conv3x3_v2_kernel(ConvArgs a, unsigned src_bytes) {
-    conv3x3_v2_body<2, 2, 128, 8, true, 9>(a, src_bytes);
-}
-__global__ void __launch_bounds__(256, 1) conv3x3_v2big_kernel(ConvArgs a, unsigned src_bytes) {
-    conv3x3_v2_body<2, 2, 128, 10, true, 9>(a, src_bytes);
-}
 __global__ void __launch_bounds__(256, 2) conv3x3_v2n64_kernel(ConvArgs a, unsigned src_bytes) {
-    conv3x3_v2_body<4, 1, 64, 10, false, 3>(a, src_bytes);
+    conv3x3_v2_body<4, 1, 64, 10>(a, src_bytes);
 }
 
 // Weights as MFMA fragments.  src: [N][ld] bf16 rows of taps x K channels (forward: [cout][9 * cin]; data gradient: the
@@ -1708,69 +1684,56 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
     if (stats) emit_partial(seq + (my_tiles - 1) * G);
 }
 
-// Experiment / test switches of this file, read from the environment ONCE (they used to cost several getenv per launch on
-// the hot host path); iif_conv_reload_env() re-reads them (tests and A/B scripts flip them between calls).
+// Test switches of this file (the whole list: DESIGN.md, "Switches"), read from the environment ONCE; iif_conv_reload_env()
+// re-reads them (tests flip them between calls).
+//   IIF_CONV_REGSTAGE        every launch on the register-staged kernels (the fallback for operands >= 2 GiB)
+//   IIF_CONV_NO_STREAM1X1    no launch on the persistent streaming 1x1 kernel;  IIF_CONV_STREAM1X1_FORCE: every shape it has a
+//                            plan for, small grids and data gradients included (default: three forward shapes, see use_stream1x1)
+//   IIF_CONV_NO_HALO / IIF_CONV_HALO_FORCE   3x3 halo kernel off / also on small grids
+//   IIF_CONV_NO_V2 / IIF_CONV_V2_FORCE       3x3 fragment kernel (64 channels) off / also on small grids
 struct ConvSwitches {
-    bool no_stream, force_stream, stream_fwd_only, stream_r2, no_shortk, regstage, no_v2, no_halo, force_halo, v2_wide, v2_force, no_merge_classes, stream_twopass, no_v2_grouped;
-    int force_bn64_k, twostage_k;
+    bool no_stream, force_stream, regstage, no_v2, no_halo, force_halo, v2_force;
     static ConvSwitches read() {
         ConvSwitches c;
         c.no_stream = getenv("IIF_CONV_NO_STREAM1X1") != nullptr;
         c.force_stream = getenv("IIF_CONV_STREAM1X1_FORCE") != nullptr;
-        c.stream_fwd_only = getenv("IIF_CONV_STREAM1X1_FWD_ONLY") != nullptr;
-        // Default coverage = what wins alone AND in the step (scripts/bm_stream1x1.py, gpurun_out/r3/bm_stream_a.log): the forward
-        // launches whose whole weight matrix is resident (64->256, 256->128, 256->64).  The N-sliced shapes and the data
-        // gradients with prefetched epilogue operands are correct (tests force them) but level with or behind the
-        // 4-blocks-per-CU tile kernel (weighted 5.16 against 5.05 ms per step alone, 21.28 against 21.19 ms in the step):
-        // IIF_CONV_STREAM1X1_ALL opts in.
-        c.stream_r2 = getenv("IIF_CONV_STREAM1X1_ALL") == nullptr;
-        c.stream_twopass = getenv("IIF_CONV_STREAM_TWOPASS") != nullptr;
-        c.no_v2_grouped = getenv("IIF_CONV_NO_V2_GROUPED") != nullptr;     // two-pass epilogue options on the streaming kernel
-        c.no_shortk = getenv("IIF_CONV_NO_SHORTK") != nullptr;
         c.regstage = getenv("IIF_CONV_REGSTAGE") != nullptr;
         c.no_v2 = getenv("IIF_CONV_NO_V2") != nullptr;
         c.no_halo = getenv("IIF_CONV_NO_HALO") != nullptr;
-        c.v2_wide = getenv("IIF_CONV_V2_WIDE") != nullptr;
-        c.no_merge_classes = getenv("IIF_CONV_NO_MERGE_CLASSES") != nullptr;
         c.v2_force = getenv("IIF_CONV_V2_FORCE") != nullptr;
         c.force_halo = getenv("IIF_CONV_HALO_FORCE") != nullptr;
-        const char* f64 = getenv("IIF_CONV_FORCE_BN64");
-        c.force_bn64_k = f64 ? atoi(f64) : -1;
-        const char* k2 = getenv("IIF_CONV_TWOSTAGE_K");
-        c.twostage_k = k2 ? atoi(k2) : 2304;
         return c;
     }
 };
+constexpr int kTwoStageK = 2304;          // the two-stage / 4-blocks-per-CU tile variant up to this K (everything the halo / 256-row kernels leave)
 ConvSwitches g_sw = ConvSwitches::read();
 
 // Which launches the streaming kernel takes, and its slice width: (K, N) -> BN columns per block with [BN x K] <= 64 KB
 // resident; S = N / BN slices.  A tile sequence needs a few tiles to pipeline across: mtiles * S >= 4 * grid.
 struct StreamPlan { int bn, kmax, slices; };
 inline bool use_stream1x1(const ConvArgs& a, bool utap, int esz, bool outf32, StreamPlan* pl) {
-    const bool off_ = g_sw.no_stream, force_ = g_sw.force_stream, no_dgrad = g_sw.stream_fwd_only, old_only = g_sw.stream_r2;
-    if (off_ || !utap || esz != 2 || outf32 || a.groups > 1 || a.scatter || a.in_shift != 0 || a.sshift != 0) return false;
+    const bool force_ = g_sw.force_stream;
+    if (g_sw.no_stream || !utap || esz != 2 || outf32 || a.groups > 1 || a.scatter || a.in_shift != 0 || a.sshift != 0) return false;
     if (a.R != 1 || a.S != 1 || a.pad != 0 || a.ntaps != 1 || a.bias || a.src2 || a.sbias || a.mask_store) return false;
-    if ((a.no_store || a.aff) && !g_sw.stream_twopass) return false;
+    if ((a.no_store || a.aff) && !force_) return false;
     if (a.Hs != a.Hd || a.Ws != a.Wd || (a.Cs % 32) || a.spitch != a.Cs || a.dpitch != a.Cd) return false;
     const int K = a.Cs, N = a.Cd;
+    // the shapes whose whole weight matrix is resident (measured alone AND in the step, scripts/bm_stream1x1.py): 64 -> 256,
+    // 256 -> 128, 256 -> 64.  N-sliced plans (128 x 128, 64 x 512 columns x K) were level with or behind the tile kernel
+    // (5.16 against 5.05 ms per step alone) and were removed in round 4.
     if (K <= 64 && N == 256) *pl = {256, 64, 1};
-    else if (K == 128 && N % 128 == 0 && N <= 1024) *pl = {128, 128, N / 128};
     else if (K > 64 && K <= 256 && N == 64 && (K >= 128 || force_)) *pl = {64, 256, 1};     // 64->64: the tile kernel wins (0.038 vs 0.060 ms)
-    else if (K > 128 && K <= 256 && N % 128 == 0 && N <= 1024) *pl = {128, 256, N / 128};
-    else if (K > 256 && K <= 512 && N % 64 == 0 && N <= 256) *pl = {64, 512, N / 64};
+    else if (K > 128 && K <= 256 && N % 128 == 0 && N <= 1024 && (N == 128 || force_)) *pl = {128, 256, N / 128};
     else return false;
-    if (old_only && !force_ && (pl->slices > 1 || a.transposed || a.bw_x || pl->kmax == 128 || pl->kmax == 512)) return false;
-    if (no_dgrad && (a.transposed || a.bw_x)) return false;
     if (force_) return true;
+    if (a.transposed || a.bw_x) return false;                               // data gradients: level with the tile kernel
     return (int64_t)((a.M + 127) / 128) * pl->slices >= 1024;               // >= 4 tiles per persistent block
 }
 
 // 256-pixel tiles: bf16 uniform-tap launches wide enough for the 128-channel tile whose 256-row grid still fills
-// the chip (2 blocks per CU resident).  IIF_CONV_BM=128|256 forces a choice (experiments).
+// the chip (2 blocks per CU resident).
 inline bool use_bm256(const ConvArgs& a, bool utap, int esz) {
-    static const char* force = getenv("IIF_CONV_BM");
     if (!utap || esz != 2 || a.Cd <= 64 || a.groups > 1) return false;
-    if (force) return atoi(force) == 256;
     // measured (scripts/bm_ab.sh): +13..39 % on K >= 1024 (3x3 at 128/256 channels, 1x1 from 1024 channels) when the
     // 256-row grid still offers >= 1.5 blocks per CU; short K loops and small grids are better off with 128 rows
     const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.Cd + 127) / 128);
@@ -1806,8 +1769,8 @@ inline bool v2_geometry_ok(int N, int H, int W, int Cs, int Cd, int groups = 1) 
     if ((Cs % 32) || (Cd % 64) || H <= 0 || W <= 0 || W > 1022) return false;
     // Measured alone (scripts/bm_conv3x3.py, bs 256): the 64-channel variant (56x56) 0.132 -> 0.102 ms forward, 0.171 -> 0.134
     // data gradient; the persistent 128-channel variant is level with or behind the halo kernel (28x28 0.078 -> 0.098,
-    // 14x14 0.067 -> 0.076, 7x7 0.057 -> 0.066 ms) and stays opt-in (IIF_CONV_V2_WIDE) until its loop is as good as its plan.
-    if ((Cd % 128) == 0 && !g_sw.v2_wide) return false;
+    // 14x14 0.067 -> 0.076, 7x7 0.057 -> 0.066 ms) and was removed in round 4: layers with 128-channel multiples take the halo kernel.
+    if ((Cd % 128) == 0) return false;
     // 256-pixel tiles: a small layer (CIFAR-size images) would leave most CUs without a block (IIF_CONV_V2_FORCE: tests)
     const int HW = H * W;
     if (!g_sw.v2_force && ((int64_t)N * HW + 255) / 256 * (Cd / 64) * groups < 192) return false;
@@ -1819,7 +1782,7 @@ inline bool use_v2(const ConvArgs& a, bool utap, int esz, bool outf32) {
     if (!a.wfrag || g_sw.no_v2 || !utap || esz != 2 || outf32 || a.scatter || a.in_shift != 0) return false;
     if (a.ntaps != 9 || a.R != 3 || a.S != 3 || a.pad != 1 || a.Hs != a.Hd || a.Ws != a.Wd || a.bias) return false;
     if (a.groups > 1) {                 // grouped: 64-channel chunks on the 64-channel variant, blockIdx.y = chunk
-        if (a.Cs != 64 || a.Cd != 64 || a.groups > 65535 || g_sw.no_v2_grouped) return false;
+        if (a.Cs != 64 || a.Cd != 64 || a.groups > 65535) return false;
     } else if (a.spitch != a.Cs || a.dpitch != a.Cd) {
         return false;
     }
@@ -1828,33 +1791,20 @@ inline bool use_v2(const ConvArgs& a, bool utap, int esz, bool outf32) {
 
 template <typename T, bool OUTF32>
 int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
-    static const bool force_v1_ = getenv("IIF_CONV_REGSTAGE") != nullptr;
+    const bool force_v1_ = g_sw.regstage;
     if (!force_v1_ && src_bytes < 0x7f000000LL && use_v2(a, utap, (int)sizeof(T), OUTF32)) {
-        const bool wide = (a.Cd % 128) == 0;
         a.mtiles = (a.M + 255) / 256;
-        a.ntiles = wide ? a.Cd / 128 : a.Cd / 64;
+        a.ntiles = a.Cd / 64;
         if (const int rc = claim_partial_rows(a)) return rc;
         const int64_t blocks2 = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
         if (blocks2 > 0x7fffffff) return IIF_EUNSUPPORTED;
-        const int HWv = a.Hd * a.Wd;
-        const int window = ((256 + a.Wd - 1) / a.Wd + 1 + 2 * (256 / HWv + 1) + 2) * (a.Wd + 2);   // halo rows a tile can need
-        // the 128-channel kernels are persistent: one block per CU walks the tiles (tile index -> the same XCD-aware map)
-        static const int cus2 = [] {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-            return n > 0 ? n : 256;
-        }();
-        const unsigned pgrid = (unsigned)(blocks2 < cus2 ? blocks2 : cus2);
-        if (wide && window <= 512) hipLaunchKernelGGL(conv3x3_v2_kernel, dim3(pgrid), dim3(256), 0, st, a, (unsigned)src_bytes);
-        else if (wide) hipLaunchKernelGGL(conv3x3_v2big_kernel, dim3(pgrid), dim3(256), 0, st, a, (unsigned)src_bytes);
-        else hipLaunchKernelGGL(conv3x3_v2n64_kernel, dim3((unsigned)blocks2, (unsigned)a.groups), dim3(256), 0, st, a, (unsigned)src_bytes);
+        hipLaunchKernelGGL(conv3x3_v2n64_kernel, dim3((unsigned)blocks2, (unsigned)a.groups), dim3(256), 0, st, a, (unsigned)src_bytes);
         IIF_LAUNCH_CHECK();
         return IIF_OK;
     }
     if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_halo(a, utap, (int)sizeof(T), OUTF32)) {
         // measured (scripts/halo_ab.sh): two 128-row blocks per CU win at 28x28 (+8 %), one 256-row block elsewhere
-        static const char* hbm = getenv("IIF_CONV_HALO_BM");
-        const int bm = hbm ? atoi(hbm) : (a.Wd >= 28 ? 128 : 256);
+        const int bm = a.Wd >= 28 ? 128 : 256;
         a.mtiles = (a.M + bm - 1) / bm;
         a.ntiles = (a.Cd + 127) / 128;
         if (const int rc = claim_partial_rows(a)) return rc;
@@ -1887,10 +1837,8 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
             const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
             const dim3 g((unsigned)grid), blk(64 * (4 + STREAM_SW));
             if (sp.bn == 256) hipLaunchKernelGGL((gemm1x1_stream_kernel<256, 64>), g, blk, 0, st, a, sb, wb);
-            else if (sp.bn == 128 && sp.kmax == 128) hipLaunchKernelGGL((gemm1x1_stream_kernel<128, 128>), g, blk, 0, st, a, sb, wb);
             else if (sp.bn == 128) hipLaunchKernelGGL((gemm1x1_stream_kernel<128, 256>), g, blk, 0, st, a, sb, wb);
-            else if (sp.kmax == 256) hipLaunchKernelGGL((gemm1x1_stream_kernel<64, 256>), g, blk, 0, st, a, sb, wb);
-            else hipLaunchKernelGGL((gemm1x1_stream_kernel<64, 512>), g, blk, 0, st, a, sb, wb);
+            else hipLaunchKernelGGL((gemm1x1_stream_kernel<64, 256>), g, blk, 0, st, a, sb, wb);
             IIF_LAUNCH_CHECK();
             return IIF_OK;
         }
@@ -1907,13 +1855,12 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
         return IIF_OK;
     }
     a.mtiles = (a.M + 127) / 128;
-    // (IIF_CONV_FORCE_BN64 = K: experiment, 128x64 tiles / 4 blocks per CU for wider outputs too)
-    const bool narrow = a.Cd <= 64 || (g_sw.force_bn64_k >= 0 && a.ntaps * a.Cs <= g_sw.force_bn64_k);
+    const bool narrow = a.Cd <= 64;
     const int bn = narrow ? 64 : 128;
     a.ntiles = (a.Cd + bn - 1) / bn;
     const int64_t blocks = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
     if (blocks > 0x7fffffff) return IIF_EUNSUPPORTED;
-    static const bool force_v1 = getenv("IIF_CONV_REGSTAGE") != nullptr;
+    const bool force_v1 = g_sw.regstage;
     // LDS-DMA addressing is a 32-bit byte offset with a hardware range check: both operands must be < 2 GiB
     const bool dma = !force_v1 && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL;
     if (a.bn_partial && !dma) return IIF_EUNSUPPORTED;     // partial sums come out of the staged epilogue only
@@ -1924,9 +1871,8 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
     if (dma) {
         const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
         if (utap) {
-            // two-stage / 4-blocks-per-CU variant up to K = IIF_CONV_TWOSTAGE_K (default 2304)
-            const bool shortk = sizeof(T) == 2 && !OUTF32 && a.ntaps * a.Cs <= g_sw.twostage_k && (a.Cd & 7) == 0 && !a.bias &&
-                                !g_sw.no_shortk;
+            // two-stage / 4-blocks-per-CU variant up to K = 2304
+            const bool shortk = sizeof(T) == 2 && !OUTF32 && a.ntaps * a.Cs <= kTwoStageK && (a.Cd & 7) == 0 && !a.bias;
             if constexpr (sizeof(T) == 2 && !OUTF32) {
                 if (shortk) {
                     if (narrow) hipLaunchKernelGGL((conv_igemm_dma_utap_k64_kernel<64>), grid, blk, 0, st, a, sb, wb);
@@ -1958,9 +1904,8 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
 template <typename T, bool OUTF32>
 int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
     ConvArgs a = a0;
-    static const bool no_fast = getenv("IIF_CONV_GENERAL_ADDR") != nullptr;
     const bool dma_ok = !g_sw.regstage && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL;
-    const bool utap = !no_fast && dma_ok && (a.Cs % ET<T>::KE) == 0 && a.R * a.S <= 16 && a.R <= 16 && a.S <= 16;
+    const bool utap = dma_ok && (a.Cs % ET<T>::KE) == 0 && a.R * a.S <= 16 && a.R <= 16 && a.S <= 16;
     a.scatter = 0; a.ds_shift = 0; a.doy = a.dox = 0; a.Hfull = a.Hd; a.Wfull = a.Wd; a.ntaps = 0; a.in_shift = 0;
     if (!utap) return (a.src2 || a.sbias || a.mask_store || a.no_store || a.aff) ? IIF_EUNSUPPORTED : launch_one<T, OUTF32>(a, false, src_bytes, wgt_bytes, st);
     if (!a.transposed || a.sshift == 0) {
@@ -2007,8 +1952,7 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
         }
     // all classes in one launch where each of them would take the 4-blocks-per-CU tile kernel
     if constexpr (sizeof(T) == 2 && !OUTF32) {
-        const bool shortk = a.R * a.S * a.Cs <= g_sw.twostage_k && (a.Cd & 7) == 0 && !a.bias && !g_sw.no_shortk && !g_sw.no_merge_classes &&
-                            a.groups == 1 && ncls > 1 && !g_sw.regstage;
+        const bool shortk = a.R * a.S * a.Cs <= kTwoStageK && (a.Cd & 7) == 0 && !a.bias && a.groups == 1 && ncls > 1 && !g_sw.regstage;
         if (shortk) {
             ConvArgsMC p{};
             p.a = a;
@@ -2074,7 +2018,7 @@ extern "C" int iif_conv3x3_frag_ok(const iif_conv_desc* d) {
     if (d->dtype != IIF_BF16 || d->dst_dtype != IIF_BF16 || d->r != 3 || d->s != 3 || d->stride != 1 || d->pad != 1) return 0;
     if (d->hs != d->hd || d->ws != d->wd) return 0;
     const int g = d->groups > 1 ? d->groups : 1;
-    if (g > 1 && (d->cs != 64 || d->cd != 64 || g_sw.no_v2_grouped)) return 0;
+    if (g > 1 && (d->cs != 64 || d->cd != 64)) return 0;
     if ((int64_t)d->n * d->hs * d->ws * d->cs * g * 2 >= 0x7f000000LL) return 0;
     return v2_geometry_ok(d->n, d->hd, d->wd, d->cs, d->cd, g) ? 1 : 0;
 }

@@ -1001,7 +1001,7 @@ inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_b
     const int tiles = h.ci_tiles * h.co_tiles;
     int splits = splits_req;
     if (splits <= 0) {
-        static const int per_cu = getenv("IIF_WGRAD_HALO_BLOCKS") ? atoi(getenv("IIF_WGRAD_HALO_BLOCKS")) : 2;
+        const int per_cu = 2;
         splits = 256 * per_cu / tiles;
         if (splits < 1) splits = 1;
         const int max_by_work = h.nsteps / 8 > 0 ? h.nsteps / 8 : 1;
@@ -1042,7 +1042,7 @@ inline int launch_wgrad_stem(const WgArgs& a, float* dw, float* ws, int64_t ws_b
     h.nsteps = (int)((vt + 31) / 32);
     int splits = splits_req;
     if (splits <= 0) {
-        static const int per_cu = getenv("IIF_WGRAD_STEM_BLOCKS") ? atoi(getenv("IIF_WGRAD_STEM_BLOCKS")) : 2;
+        const int per_cu = 2;
         splits = 256 * per_cu;
         const int max_by_work = h.nsteps / 8 > 0 ? h.nsteps / 8 : 1;
         if (splits > max_by_work) splits = max_by_work;
@@ -1114,37 +1114,32 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
                  hipStream_t st) {
     constexpr int ROWS = WT<T>::ROWS;
     // 256-channel tiles (8 waves): bf16, dense, >= 256 output channels, the LDS-DMA path
-    static const char* wide_env = getenv("IIF_WGRAD_BC");
-    const bool dma_ok = getenv("IIF_CONV_REGSTAGE") == nullptr && x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL;
+    // (IIF_CONV_REGSTAGE: every launch on the register-staged kernel, the fallback for operands >= 2 GiB; tests)
+    const bool force_v1 = getenv("IIF_CONV_REGSTAGE") != nullptr;       // (read per call: a test flips it)
+    const bool dma_ok = !force_v1 && x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL;
     if constexpr (sizeof(T) == 2) {
-        static const char* halo_env = getenv("IIF_WGRAD_HALO");          // "0": keep the tap-per-tile kernel
-        static const bool no_grouped_halo = getenv("IIF_WGRAD_NO_GROUPED_HALO") != nullptr;
         // dense: channels in 64s; grouped: 64-channel chunks (the nine-tap tile IS a chunk)
         const bool shape = a.groups == 1 ? (a.Cs % 64 == 0 && a.Cd % 64 == 0 && a.xpitch == a.Cs && a.ypitch == a.Cd)
-                                         : (a.Cs == 64 && a.Cd == 64 && a.ldw >= 576 && !no_grouped_halo);
+                                         : (a.Cs == 64 && a.Cd == 64 && a.ldw >= 576);
         const bool halo = dma_ok && shape && a.R == 3 && a.S == 3 && a.sshift == 0 && a.pad == 1 && a.Hs == a.Hd &&
-                          a.Ws == a.Wd && a.Wd + 3 <= 64 && !(halo_env && atoi(halo_env) == 0);
+                          a.Ws == a.Wd && a.Wd + 3 <= 64;
         if (halo) {
             const int rc = launch_wgrad_halo(a, dw, ws, ws_bytes, splits_req, x_bytes, dy_bytes, st);
             if (rc != -100) return rc;
         }
-        static const char* stem_env = getenv("IIF_WGRAD_STEM");          // "0": keep the tap-per-tile kernel
         const bool stem = dma_ok && a.groups == 1 && a.R == 4 && a.S == 4 && a.sshift == 0 && a.pad == 2 && a.Hs == a.Hd &&
-                          a.Ws == a.Wd && a.Cs == 16 && a.Cd == 64 && a.xpitch == 16 && a.ypitch == 64 &&
-                          !(stem_env && atoi(stem_env) == 0);
+                          a.Ws == a.Wd && a.Cs == 16 && a.Cd == 64 && a.xpitch == 16 && a.ypitch == 64;
         if (stem) {
             const int rc = launch_wgrad_stem(a, dw, ws, ws_bytes, splits_req, x_bytes, dy_bytes, st);
             if (rc != -100) return rc;
         }
     }
     if constexpr (sizeof(T) == 2) {
-        static const bool no_1x1 = getenv("IIF_WGRAD_NO_1X1") != nullptr;
-        if (dma_ok && !no_1x1 && a.R == 1 && a.S == 1 && a.sshift == 0 && a.pad == 0 && a.groups == 1 && a.Hs == a.Hd && a.Ws == a.Wd &&
+        if (dma_ok && a.R == 1 && a.S == 1 && a.sshift == 0 && a.pad == 0 && a.groups == 1 && a.Hs == a.Hd && a.Ws == a.Wd &&
             a.xpitch == a.Cs && a.ypitch == a.Cd)
             return launch_wgrad_1x1(a, dw, ws, ws_bytes, splits_req, x_bytes, dy_bytes, st);
     }
     bool wide = sizeof(T) == 2 && dma_ok && a.groups == 1 && a.Cd >= 256 && a.Cd % 256 == 0;
-    if (wide && wide_env) wide = atoi(wide_env) == 256;
     const int bc = wide ? 256 : (a.Cd <= 64 ? 64 : 128);
     a.ktiles = (a.Cd + bc - 1) / bc;
     a.ntiles = (a.K + 127) / 128;
@@ -1156,7 +1151,7 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
         // workgroup gets the same number of steps and there is no tail round
         // blocks per CU: 4 (64-channel tile), 3 (128), and ONE 8-wave block for the 256-channel tile: two per CU write twice
         // the split-K slabs for nothing (step 20.67 -> 20.62 ms at one; 0.75 / 1.25 per CU leave a tail round: 21.2 / 20.8;
-        // scripts/ab_wgrad_slots.sh).  IIF_WGRAD_SLOT_PCT[_256|_128|_64]: experiment knobs, per cent of these.
+        // round 3, scripts removed).
         const int slots = 256 * (bc == 256 ? 1 : (bc == 128 ? 3 : 4));
         splits = slots / (tiles * a.groups);
         if (splits < 1) splits = 1;
@@ -1177,10 +1172,9 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
     a.nsplits = splits;
     const dim3 grid(tiles, splits);
     const dim3 grid1d((unsigned)(tiles * ((splits + 7) / 8) * 8), (unsigned)a.groups);
-    if (a.groups > 1 && !(x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL && getenv("IIF_CONV_REGSTAGE") == nullptr))
+    if (a.groups > 1 && !dma_ok)
         return IIF_EUNSUPPORTED;
-    static const bool force_v1 = getenv("IIF_CONV_REGSTAGE") != nullptr;
-    const bool dma = !force_v1 && x_bytes < 0x7ffffff0LL && dy_bytes < 0x7ffffff0LL;
+    const bool dma = dma_ok;
     if (dma) {
         const unsigned xb = (unsigned)x_bytes, yb = (unsigned)dy_bytes;
         if (bc == 64) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 64>), grid1d, dim3(256), 0, st, a, xb, yb);

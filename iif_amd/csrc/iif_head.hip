@@ -405,16 +405,13 @@ constexpr unsigned kMaxRowBlocks = 2048;      // = partial slots of the single-l
 // configuration cannot do it (streaming kernel with more blocks than workspace slots).
 template <typename T, int MODE>
 int launch_rows(CeArgs a, float* sm_out, int64_t ld_sm, hipStream_t st, bool* inline_reduce = nullptr) {
-    static const char* wpb_env = getenv("IIF_HEAD_WPB");
     // waves per block: every block stages the table once and takes one ticket, so small batches use fewer, fatter blocks.
     // finish_with_ticket's tree needs a power of two <= 4 (sh[256], __launch_bounds__(256)): anything else falls back to 4
-    int wpb = wpb_env ? atoi(wpb_env) : 4;                // measured 1 / 2 / 4: [1024, 1204] 23.2 / 13.3 / 9.5 us, [256, 1000] 9.1 / 7.6 / 6.6 us
-    if (wpb != 1 && wpb != 2 && wpb != 4) wpb = 4;
+    int wpb = 4;                // measured 1 / 2 / 4: [1024, 1204] 23.2 / 13.3 / 9.5 us, [256, 1000] 9.1 / 7.6 / 6.6 us
     const dim3 grid((a.B + wpb - 1) / wpb), block(64 * wpb);
     // register-row kernel: at most 256 CUs x 8 blocks; beyond that a wave walks several rows.  Never more blocks than the
     // single-launch loss workspace has partial slots.
-    static const char* mb_env = getenv("IIF_HEAD_MAXBLOCKS");
-    unsigned maxb = mb_env ? (unsigned)atoi(mb_env) : 1024u;           // 256 / 512 / 1024 / 2048 blocks: [8192, 1204] 25.9 / 23.6 / 26.5 / 35.3 us, [65536, 1000] bf16 0.213 / 0.129 / 0.085 / 0.090 ms
+    unsigned maxb = 1024u;           // 256 / 512 / 1024 / 2048 blocks: [8192, 1204] 25.9 / 23.6 / 26.5 / 35.3 us, [65536, 1000] bf16 0.213 / 0.129 / 0.085 / 0.090 ms
     if (maxb < 1u) maxb = 1u;
     if (maxb > kMaxRowBlocks) maxb = kMaxRowBlocks;
     const dim3 pgrid(grid.x < maxb ? grid.x : maxb);

@@ -499,8 +499,7 @@ int iif_maxpool_bn_forward(const void* x, int dtype, const float* stats, int n, 
     hipStream_t st = as_stream(stream);
     const int64_t tot = (int64_t)n * ho * wo * (c / (dtype == IIF_F32 ? 4 : 8));
     const int cvs = c / (dtype == IIF_F32 ? 4 : 8);
-    static const bool no_fast = getenv("IIF_NO_POOL321") != nullptr;
-    if (!no_fast && k == 3 && stride == 2 && pad == 1 && cvs <= 256 && 256 % cvs == 0 && (int64_t)n * ho < 0x7fffffffLL &&
+    if (k == 3 && stride == 2 && pad == 1 && cvs <= 256 && 256 % cvs == 0 && (int64_t)n * ho < 0x7fffffffLL &&
         (int64_t)n * h * w * c < 0x7fffffffLL) {
         const int rowblocks = (int)((int64_t)n * ho < 16384 ? (int64_t)n * ho : 16384);
         IIF_BY_DTYPE(dtype,

@@ -35,7 +35,7 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 # channels of the space-to-depth stem image: 4 * 3 real, zero padded to 16 (measured: stem forward 0.56 -> 0.26 ms
 # and weight gradient 0.44 -> 0.25 ms against a padding of 32, which would keep one tap per K step)
-S2D_CPAD = int(os.environ.get("IIF_S2D_CPAD", "16"))
+S2D_CPAD = 16
 
 
 def _round_up(v, m):
@@ -646,8 +646,7 @@ class _Plan(object):
         ho, wo = ops.conv_out_hw(h, w, c1.k, c1.k, c1.stride, c1.pad)
         # 7x7/2 stem on even images: 4x4/1 convolution over the 2x2 space-to-depth image (no patch matrix);
         # anything else (CIFAR 3x3 stem, odd sizes): GEMM over gathered patches
-        self.stem_s2d = (c1.k == 7 and c1.stride == 2 and c1.pad == 3 and h % 2 == 0 and w % 2 == 0
-                         and not os.environ.get("IIF_STEM_PATCHES"))
+        self.stem_s2d = c1.k == 7 and c1.stride == 2 and c1.pad == 3 and h % 2 == 0 and w % 2 == 0
         if self.stem_s2d:
             self.patches = E(n, h // 2, w // 2, S2D_CPAD)
         else:
@@ -658,7 +657,7 @@ class _Plan(object):
             u.w = torch.empty((c1.cout, 16 * S2D_CPAD), dtype=dt, device=dev)
             u.dwp = torch.empty((c1.cout, 16 * S2D_CPAD), dtype=torch.float32, device=dev)
         self.stem = u
-        self.pool_fused = net.style == "imagenet" and not os.environ.get("IIF_NO_POOL_FUSE") and net._sync_bn is None
+        self.pool_fused = net.style == "imagenet" and net._sync_bn is None
         if net.style == "imagenet":
             self.pool_hw = ((ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1)
             self.pool_out = E(n, self.pool_hw[0], self.pool_hw[1], c1.cout)
@@ -736,14 +735,14 @@ class _Plan(object):
         mmax = max(u.n * u.ho * u.wo for u in self.units)
         self.bn_ws = ops.bn_workspace(mmax, cmax, dev)
         # ticket words of the single-launch two-stage BN reductions (self-resetting; one set per stream that finalises)
-        self.bn_tickets = torch.zeros(64, dtype=torch.int32, device=dev) if not os.environ.get("IIF_BN_NO_FUSED_FINALIZE") else None
+        self.bn_tickets = torch.zeros(64, dtype=torch.int32, device=dev)
         self.bn_tickets_side = torch.zeros(64, dtype=torch.int32, device=dev) if self.bn_tickets is not None else None
         self.bn_partial = torch.empty(max(((u.n * u.ho * u.wo + 127) // 128) * 2 * u.conv.cout for u in self.units),
                                       dtype=torch.float32, device=dev)
         self.bn_scratch = torch.empty(128 * cmax, dtype=torch.float32, device=dev)
         # the convolutional shortcut of a stage's first block runs on the side stream next to the main branch
         ds_units = [b["ds"] for b in self.blocks if "ds" in b]
-        self.fwd_side = bool(ds_units) and dt == torch.bfloat16 and not os.environ.get("IIF_NO_FWD_SIDE")
+        self.fwd_side = bool(ds_units) and dt == torch.bfloat16
         if self.fwd_side:
             self.bn_partial_side = torch.empty(max(((u.n * u.ho * u.wo + 127) // 128) * 2 * u.conv.cout for u in ds_units),
                                                dtype=torch.float32, device=dev)
@@ -760,10 +759,8 @@ class _Plan(object):
         # backward, 4 passes over that tensor saved, but P sits on the compute stream before the data gradient) - it wins
         # where the tensor is large (>= 1.5e8 elements: the 56 x 56 stage at batch 256); otherwise the producing data gradient
         # still reads conv3's output once for sum g~ xhat (3 passes saved) and P moves to the weight-gradient stream.
-        self.wg_lag = max(2, int(os.environ.get("IIF_WGRAD_LAG", "2")))       # (explained where the side streams are created)
+        self.wg_lag = 2      # blocks the weight-gradient stream may lag (explained where the side streams are created; 3 / 4 / 6 measured level)
         self.alg3_units = set()
-        a3_maxc = min(256, int(os.environ.get("IIF_BN3_ALGEBRA_MAXC", "256")))
-        a3_min = float(os.environ.get("IIF_BN3_ALGEBRA_MIN_ELEMS", "0"))
         self.a3_pure_min = float(os.environ.get("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "1.5e8"))
         if self.fuse_bwd and net._sync_bn is None and not os.environ.get("IIF_NO_BN3_ALGEBRA"):
             for b in self.blocks:
@@ -771,8 +768,8 @@ class _Plan(object):
                     continue
                 u3 = b["units"][-1]
                 cv3 = u3.conv
-                if (cv3.k == 1 and cv3.stride == 1 and cv3.groups == 1 and cv3.cin in (64, 128, 256) and cv3.cin <= a3_maxc and cv3.cout % 64 == 0 and cv3.cout <= 4096
-                        and _dma_ok(u3.x) and u3.n * u3.ho * u3.wo < (1 << 30) and u3.n * u3.ho * u3.wo * cv3.cout >= a3_min):
+                if (cv3.k == 1 and cv3.stride == 1 and cv3.groups == 1 and cv3.cin in (64, 128, 256) and cv3.cout % 64 == 0 and cv3.cout <= 4096
+                        and _dma_ok(u3.x) and u3.n * u3.ho * u3.wo < (1 << 30)):
                     self.alg3_units.add(u3)
         # Two-pass forward (conv3's raw output is never stored): pass 1 = statistics only, pass 2 = the same convolution with
         # BN + identity + ReLU in its epilogue (bit-identical to conv + bn_apply).  Only where backward never needs that
@@ -813,17 +810,15 @@ class _Plan(object):
         self._bwd_ready = False
         self.wg_stream = None
         if dev.type == "cuda" and not os.environ.get("IIF_NO_WGRAD_STREAM"):
-            pr = os.environ.get("IIF_WGRAD_STREAM_PRIORITY")
-            self.wg_stream = torch.cuda.Stream(device=dev) if pr is None else torch.cuda.Stream(device=dev, priority=int(pr))
+            self.wg_stream = torch.cuda.Stream(device=dev)
         self._wg_events = {}
-        self.stem_wgrad_main = self.wg_stream is not None and not os.environ.get("IIF_STEM_WGRAD_SIDE")
+        self.stem_wgrad_main = self.wg_stream is not None
         # own split-K workspace of the stem's weight gradient (it runs on the compute stream next to the side stream's):
         # allocated here, never inside backward (a lazy allocation there would land inside a hipGraph capture)
         self.wg_ws_stem = (torch.empty(64 << 20, dtype=torch.uint8, device=dev)
                            if (self.stem_wgrad_main and self.stem_s2d) else None)
         # blocks the weight-gradient stream may lag behind the compute stream: dx buffers rotate over `wg_lag` slots,
         # block-input gradients over wg_lag + 1, and block b waits for the weight gradients of the blocks >= b + wg_lag
-        assert self.wg_lag == max(2, int(os.environ.get("IIF_WGRAD_LAG", "2")))
         # backward of the convolutional shortcut (BN backward + dgrad + wgrad of 4 blocks) on a third stream
         self.ds_stream = None
         if self.wg_stream is not None and ds_units and dt == torch.bfloat16 and not os.environ.get("IIF_NO_BWD_SIDE"):

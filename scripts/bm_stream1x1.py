@@ -27,7 +27,7 @@ MODES = ("k64", "stream")
 
 
 def mode(m):
-    for k in ("IIF_CONV_NO_STREAM1X1", "IIF_CONV_NO_SHORTK", "IIF_CONV_STREAM1X1_FORCE", "IIF_CONV_STREAM1X1_ALL"):
+    for k in ("IIF_CONV_NO_STREAM1X1", "IIF_CONV_STREAM1X1_FORCE"):
         os.environ.pop(k, None)
     if m == "k64":
         os.environ["IIF_CONV_NO_STREAM1X1"] = "1"

@@ -327,8 +327,8 @@ print(json.dumps({"nt": nt, "m": m, "e_fwd": e_fwd, "e_sum": e_sum, "e_sq": e_sq
     assert abs(hres["digest"] - tres["digest"]) <= 1e-3 * max(1.0, abs(tres["digest"]))
 
 
-V2_CASES = [(4, 128, 28, 28, 128), (3, 256, 14, 14, 256), (7, 512, 7, 7, 512), (2, 64, 56, 56, 64), (2, 128, 9, 11, 256),
-            (1, 64, 5, 30, 192), (40, 64, 5, 5, 128), (3, 128, 17, 13, 64), (5, 64, 14, 14, 320)]
+# (the fragment kernel exists for 64-channel output tiles only since round 4: Cout and Cin = 64 mod 128, both directions)
+V2_CASES = [(2, 64, 56, 56, 64), (1, 64, 5, 30, 192), (5, 64, 14, 14, 320), (6, 192, 9, 11, 64), (40, 64, 5, 5, 64), (3, 192, 17, 13, 192)]
 
 
 def _pack_frag(w2d, rows, taps, k):
@@ -355,7 +355,7 @@ def test_conv3x3_fragment_kernel(case, conv_env):
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()                                    # noqa: E731
     krsc = lambda w_: w_.permute(0, 2, 3, 1).reshape(w_.shape[0], -1).contiguous()          # noqa: E731
     xd, wd = nhwc(x).to(DEV), krsc(wt).to(DEV)
-    conv_env(IIF_CONV_V2_WIDE="1", IIF_CONV_V2_FORCE="1")   # the 128-channel variant is opt-in, small grids are refused (v2_geometry_ok)
+    conv_env(IIF_CONV_V2_FORCE="1")   # small grids are refused otherwise (v2_geometry_ok)
     assert ops.conv3x3_frag_ok(n, h, w, cin, cout, dt) and ops.conv3x3_frag_ok(n, h, w, cout, cin, dt)
     wf = _pack_frag(wd, cout, 9, cin)
     # the layout: fragment (row tile, tap, chunk), lane (row & 15, 8 channels of (lane >> 4))
@@ -375,7 +375,7 @@ def test_conv3x3_fragment_kernel(case, conv_env):
     wtt = krsc(wt.permute(1, 0, 2, 3).contiguous()).to(DEV)
     wtf = _pack_frag(wtt, cin, 9, cout)
     for mode in ("v2", "old"):
-        conv_env(IIF_CONV_NO_V2=None if mode == "v2" else "1", IIF_CONV_HALO_FORCE="1", IIF_CONV_V2_WIDE="1", IIF_CONV_V2_FORCE="1")
+        conv_env(IIF_CONV_NO_V2=None if mode == "v2" else "1", IIF_CONV_HALO_FORCE="1", IIF_CONV_V2_FORCE="1")
         out = torch.full((n, h, w, cout), float("nan"), dtype=dt, device=DEV)
         partial = torch.full((((m + 127) // 128) * 2 * cout,), float("nan"), device=DEV)
         nt = ops.conv_forward_bnstats(xd, wd, 3, 3, 1, 1, out, partial, w_frag=wf)
@@ -528,8 +528,8 @@ def test_stem_s2d_weight_gradient_all_taps_per_block(n, h, w):
 STREAM_CASES = [  # N, Cin, H, W, Cout : every instantiation, ragged last tile, fewer tiles than blocks, many tiles per block
     (3, 64, 20, 23, 256), (2, 256, 17, 19, 64), (2, 256, 24, 24, 128), (1, 64, 9, 7, 64), (2, 32, 40, 40, 256),
     (5, 128, 12, 12, 64), (40, 64, 56, 56, 256), (37, 256, 56, 56, 64),
-    # round 3: N slices of a tile sequence on neighbouring blocks (S = 2, 4, 8), K = 128 and K = 512 residents; both directions
-    # of every bottleneck 1x1 layer of the 28x28 / 14x14 stages (the data gradient of Cin -> Cout runs Cout -> Cin)
+    # N slices of a tile sequence on neighbouring blocks (S = 2, 4, 8) of the 256-channel resident plan; shapes without a plan
+    # (K = 128, K = 512: removed in round 4) run the tile kernel on both sides of the comparison
     (3, 128, 28, 28, 512), (3, 512, 28, 28, 128), (2, 128, 13, 11, 256), (5, 256, 14, 14, 1024), (2, 256, 28, 28, 512),
     (2, 512, 28, 28, 256), (9, 128, 28, 28, 512), (1, 512, 5, 5, 128), (2, 256, 56, 56, 128), (2, 128, 56, 56, 256),
 ]
@@ -770,7 +770,7 @@ def test_two_pass_forward_is_bit_identical_to_conv_then_bn_apply(case, stream, c
     to bf16 in the staging tile exactly as the stored one is."""
     from iif_amd import ops
     if stream:      # the persistent streaming kernel (it shares the staged drain): allowed for these options and forced onto small grids
-        conv_env(IIF_CONV_STREAM_TWOPASS="1", IIF_CONV_STREAM1X1_FORCE="1", IIF_CONV_STREAM1X1_ALL="1")
+        conv_env(IIF_CONV_STREAM1X1_FORCE="1")
     n, hw, c, C = case
     m = n * hw * hw
     g = torch.Generator().manual_seed(11 * c + hw)
@@ -860,3 +860,45 @@ def test_grouped_conv3x3_on_the_fragment_kernel(case, conv_env):
     s2 = out["frag"][4]
     assert (s2[0] - gq.sum(0)).abs().max().item() <= 1e-3 * max(1.0, gq.sum(0).abs().max().item())
     assert (s2[1] - (gq * xhat).sum(0)).abs().max().item() <= 1e-3 * max(1.0, (gq * xhat).sum(0).abs().max().item())
+
+
+# ------------------------------------------------------------------- the register-staged fallback (operands >= 2 GiB)
+@pytest.mark.parametrize("case", [(3, 64, 14, 14, 128, 1, 1), (2, 32, 13, 11, 64, 3, 1), (2, 64, 12, 12, 96, 3, 2)],
+                         ids=lambda c: "%dx%dx%dx%d_to_%d_k%d_s%d" % c)
+def test_register_staged_fallback_kernels(case, conv_env):
+    """IIF_CONV_REGSTAGE=1 puts every launch on the round-1 register-staged kernels — what operands beyond the 32-bit
+    LDS-DMA offsets (>= 2 GiB, batch ~1280 at 224 x 224) fall back to: forward, data gradient and weight gradient against
+    torch, in bf16 tolerances, and against the default (LDS-DMA) kernels."""
+    import torch.nn.functional as F
+    from iif_amd import ops
+    n, cin, h, w, cout, k, stride = case
+    pad = k // 2
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    x = torch.randn(n, cin, h, w, generator=g).to(dt)
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (k * k * cin) ** 0.5).to(dt)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    dy = torch.randn(n, cout, ho, wo, generator=g).to(dt)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()                                    # noqa: E731
+    xd, dyd = nhwc(x).to(DEV), nhwc(dy).to(DEV)
+    wd = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().to(DEV)
+    ldwt = (k * k * cout + 15) // 16 * 16
+    wtt = torch.zeros(cin, ldwt, dtype=dt, device=DEV)
+    ops.weight_transpose(wt.permute(0, 2, 3, 1).reshape(cout, -1).float().to(DEV), cout, cin, k * k, wtt)
+    ref_y = F.conv2d(x.float(), wt.float(), None, stride, pad)
+    ref_dx = torch.nn.grad.conv2d_input(x.shape, wt.float(), dy.float(), stride, pad)
+    ref_dw = torch.nn.grad.conv2d_weight(x.float(), wt.shape, dy.float(), stride, pad)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    got = {}
+    for mode in ("regstage", "default"):
+        conv_env(IIF_CONV_REGSTAGE="1" if mode == "regstage" else None)
+        y = ops.conv_forward(xd, wd, k, k, stride, pad)
+        dx = ops.conv_dgrad(dyd, wtt, k, k, stride, pad, (h, w))
+        dw = ops.conv_wgrad(xd, dyd, k, k, stride, pad, workspace=ws)
+        got[mode] = (y.float().cpu().permute(0, 3, 1, 2), dx.float().cpu().permute(0, 3, 1, 2),
+                     dw.cpu().view(cout, k, k, cin).permute(0, 3, 1, 2))
+    for mode, (y, dx, dw) in got.items():
+        assert (y - ref_y).abs().max().item() <= 2.0 ** -7 * ref_y.abs().max().item(), mode
+        assert (dx - ref_dx).abs().max().item() <= 2.0 ** -7 * ref_dx.abs().max().item(), mode
+        assert (dw - ref_dw).norm().item() <= 1e-4 * ref_dw.norm().item(), mode             # fp32 sums of exact bf16 products
+    assert (got["regstage"][0] - got["default"][0]).abs().max().item() <= 2.0 ** -7 * ref_y.abs().max().item()
