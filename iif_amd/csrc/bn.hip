@@ -634,6 +634,64 @@ int bn_backward_apply_sums_t(const T* gy, const T* ymask, const unsigned char* b
     return IIF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// BN-backward sums of the stem (bn1 -> relu -> 3x3/2 max pool, resnet_pytorch.py:284-287) from the POOLED tensors.
+// The gradient of the stem's BN output is the pooled gradient scattered to the arg-max positions, gated by the ReLU; its
+// column sums do not care where an element lands:
+//     sum g      = sum over pooled elements of gp [out > 0]
+//     sum g xhat = sum over pooled elements of gp [out > 0] xhat(arg max),   xhat = ((out - b) / a - mean) invstd   (out = relu(a x + b) > 0)
+// so the reduction pass over the 4x larger scattered gradient AND the stem output (822 MB, 190 us at batch 256) becomes a pass
+// over two pooled tensors (206 MB).  xhat comes back from the stored pooled value: out carries one rounding of the storage
+// type (2^-9 relative in bf16, the same size as the rounding of the stored x the standard pass starts from).  A channel
+// whose scale a is (numerically) zero has no ReLU-open elements worth speaking of: its second sum is taken as 0.
+// One partial row [2][C] per block, fixed order: deterministic.  Grid <= 512 blocks (bn_backward_t's one-stage finalisation).
+template <typename T>
+__global__ void __launch_bounds__(256) pool_bwd_sums_kernel(const T* gp, const T* out, const float* stats, int64_t npix, int C,
+                                                            int64_t pix_per_block, float* partial) {
+    constexpr int V = VT<T>::V;
+    __shared__ float sh[2][256][V + 1];
+    const int cv = C / V;                                 // channel vectors per pixel (host: 256 % cv == 0)
+    const int vec = threadIdx.x % cv, pl = threadIdx.x / cv, ppb = 256 / cv;
+    const int c0 = vec * V;
+    // xhat = (x - mean) invstd with x = (out - b) / a:  xhat = out * k1 + k0,  k1 = invstd / a,  k0 = -(b / a + mean) invstd
+    float k1[V], k0[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+        const float a = stats[2 * C + c0 + q], bb = stats[3 * C + c0 + q], mean = stats[c0 + q], invstd = stats[C + c0 + q];
+        const float ia = fabsf(a) > 1e-20f ? 1.0f / a : 0.f;
+        k1[q] = invstd * ia;
+        k0[q] = ia != 0.f ? -(bb * ia + mean) * invstd : 0.f;
+    }
+    float s1[V], s2[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    int64_t p1 = p0 + pix_per_block; if (p1 > npix) p1 = npix;
+    for (int64_t p = p0 + pl; p < p1; p += 2 * ppb) {     // two pixels in flight per thread
+        float g0[V], o0[V], g1[V], o1[V];
+        const bool two = p + ppb < p1;
+        const int64_t pb = two ? p + ppb : p;
+        VT<T>::load_nt(gp + p * C + c0, g0); VT<T>::load_nt(out + p * C + c0, o0);
+        VT<T>::load_nt(gp + pb * C + c0, g1); VT<T>::load_nt(out + pb * C + c0, o1);
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const float ga = o0[q] > 0.f ? g0[q] : 0.f;
+            s1[q] += ga; s2[q] = fmaf(ga, fmaf(o0[q], k1[q], k0[q]), s2[q]);
+            const float gb = (two && o1[q] > 0.f) ? g1[q] : 0.f;
+            s1[q] += gb; s2[q] = fmaf(gb, fmaf(o1[q], k1[q], k0[q]), s2[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < V; ++q) { sh[0][threadIdx.x][q] = s1[q]; sh[1][threadIdx.x][q] = s2[q]; }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * C) {                       // (C <= 128 here; one thread per (sum, channel), pixel lanes in order)
+        const int which = threadIdx.x / C, c = threadIdx.x % C;
+        float a = 0.f;
+        for (int j = 0; j < ppb; ++j) a += sh[which][j * cv + c / V][c % V];
+        partial[(int64_t)blockIdx.x * 2 * C + which * C + c] = a;
+    }
+}
+
 inline bool bad_align(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 
 }  // namespace
@@ -747,6 +805,40 @@ int iif_bn_backward_relu_recompute(const void* gy, const void* x, int dtype, int
                                              as_stream(stream), nullptr, 0, true);
     }
     return IIF_EINVAL;
+}
+
+int iif_bn_backward_relu_recompute_pooled(const void* gy, const void* x, int dtype, int64_t m, int c, const float* stats,
+                                          const float* gamma, float* dgamma, float* dbeta, void* dx, void* workspace,
+                                          int64_t workspace_bytes, const void* g_pool, const void* pool_out, int64_t pool_pixels,
+                                          void* stream) {
+    if (!gy || !x || !stats || !gamma || !dgamma || !dbeta || !dx || !workspace || !g_pool || !pool_out || m <= 0 || c <= 0 ||
+        pool_pixels <= 0)
+        return IIF_EINVAL;
+    if (m > 0x7fffff00LL || bad_align(gy) || bad_align(x) || bad_align(dx) || bad_align(g_pool) || bad_align(pool_out)) return IIF_EUNSUPPORTED;
+    const int v = dtype == IIF_F32 ? 4 : 8;
+    if ((dtype != IIF_F32 && dtype != IIF_BF16) || c % v || 256 % (c / v) || 2 * c > 256) return IIF_EUNSUPPORTED;
+    int nblk = (int)(pool_pixels / 64 < 512 ? (pool_pixels + 63) / 64 : 512);
+    const int64_t ppb = (pool_pixels + nblk - 1) / nblk;
+    nblk = (int)((pool_pixels + ppb - 1) / ppb);
+    // the partial rows take the END of the workspace; bn_backward_t gets (and checks) what is in front of them
+    const int64_t row_bytes = (int64_t)nblk * 2 * c * 4;
+    if (row_bytes + 4096 > workspace_bytes) return IIF_EINVAL;
+    float* ws = (float*)workspace;
+    float* rows = ws + (workspace_bytes - row_bytes) / 16 * 4;
+    workspace_bytes = (workspace_bytes - row_bytes) / 16 * 16;
+    hipStream_t st = as_stream(stream);
+    if (dtype == IIF_F32) {
+        hipLaunchKernelGGL(pool_bwd_sums_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)g_pool, (const float*)pool_out, stats,
+                           pool_pixels, c, ppb, rows);
+        IIF_LAUNCH_CHECK();
+        return bn_backward_t<float>((const float*)gy, nullptr, nullptr, (const float*)x, stats, gamma, m, c, dgamma, dbeta, (float*)dx, nullptr,
+                                    ws, workspace_bytes, st, rows, nblk, true);
+    }
+    hipLaunchKernelGGL(pool_bwd_sums_kernel<unsigned short>, dim3(nblk), dim3(256), 0, st, (const unsigned short*)g_pool,
+                       (const unsigned short*)pool_out, stats, pool_pixels, c, ppb, rows);
+    IIF_LAUNCH_CHECK();
+    return bn_backward_t<unsigned short>((const unsigned short*)gy, nullptr, nullptr, (const unsigned short*)x, stats, gamma, m, c, dgamma,
+                                         dbeta, (unsigned short*)dx, nullptr, ws, workspace_bytes, st, rows, nblk, true);
 }
 
 int iif_bn_backward_partials_fused(const void* gy, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,

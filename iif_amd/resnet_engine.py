@@ -1523,6 +1523,7 @@ class _Plan(object):
                 reducer.gradients_ready_from(offs["blocks"][bi])
         # ---- stem
         u = self.stem
+        g_pooled = g
         if net.style == "imagenet":
             dy0 = self._gbuf(("dy0",), u.y.shape)
             _lib.check(_lib.lib().iif_maxpool_backward(_lib.ptr(g), _lib.ptr(self.pool_idx), _lib.dtype_code(g), u.n, u.ho,
@@ -1533,11 +1534,22 @@ class _Plan(object):
             cv, bn = u.conv, u.bn
             m = u.n * u.ho * u.wo
             g2 = g.view(m, cv.cout)
-            _lib.check(_lib.lib().iif_bn_backward_relu_recompute(_lib.ptr(g2), _lib.ptr(u.x), _lib.dtype_code(u.x), m, cv.cout,
-                                                                 _lib.ptr(u.stats), _lib.ptr(bn.weight), _lib.ptr(bn._dgamma),
-                                                                 _lib.ptr(bn._dbeta), _lib.ptr(g2), _lib.ptr(self.bn_ws),
-                                                                 self.bn_ws.numel(), _lib.stream_ptr()),
-                       "iif_bn_backward_relu_recompute")
+            # bf16: the two column sums come from the pooled gradient and the pooled output (a quarter of the elements, no pass
+            # over the scattered gradient and the stem output: 190 -> ~45 us at batch 256); the normalisation pass is unchanged.
+            # fp32 (parity mode) keeps the reduction pass: recovering xhat from the pooled value costs a few ulps that BN
+            # backward amplifies past the 2e-4 the parity tests hold the stem's weight gradient to.
+            if self.dt == torch.float32:
+                _lib.check(_lib.lib().iif_bn_backward_relu_recompute(_lib.ptr(g2), _lib.ptr(u.x), _lib.dtype_code(u.x), m, cv.cout,
+                                                                     _lib.ptr(u.stats), _lib.ptr(bn.weight), _lib.ptr(bn._dgamma),
+                                                                     _lib.ptr(bn._dbeta), _lib.ptr(g2), _lib.ptr(self.bn_ws),
+                                                                     self.bn_ws.numel(), _lib.stream_ptr()),
+                           "iif_bn_backward_relu_recompute")
+            else:
+                _lib.check(_lib.lib().iif_bn_backward_relu_recompute_pooled(
+                    _lib.ptr(g2), _lib.ptr(u.x), _lib.dtype_code(u.x), m, cv.cout, _lib.ptr(u.stats), _lib.ptr(bn.weight),
+                    _lib.ptr(bn._dgamma), _lib.ptr(bn._dbeta), _lib.ptr(g2), _lib.ptr(self.bn_ws), self.bn_ws.numel(), _lib.ptr(g_pooled),
+                    _lib.ptr(self.pool_out), self.pool_out.numel() // cv.cout, _lib.stream_ptr()),
+                    "iif_bn_backward_relu_recompute_pooled")
             self._stem_wgrad(u, g2.view(u.n, u.ho, u.wo, cv.cout))
         else:
             self._unit_backward(u, g, u.y, need_dgrad=False)

@@ -526,3 +526,52 @@ def test_fused_stem_pool_equals_bn_apply_then_maxpool(dt, shape):
     _lib.check(_lib.lib().iif_maxpool_bn_forward(_lib.ptr(x), _lib.dtype_code(x), _lib.ptr(stats), n, h, w, c, 3, 2, 1, _lib.ptr(y),
                                                  _lib.ptr(idx), _lib.stream_ptr()), "iif_maxpool_bn_forward")
     assert torch.equal(y, y_ref) and torch.equal(idx, idx_ref)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_stem_bn_backward_sums_from_the_pooled_tensors(dt):
+    """iif_bn_backward_relu_recompute_pooled: the BN-backward column sums of the stem (bn1 -> relu -> 3x3/2 max pool,
+    resnet_pytorch.py:284-287) taken from the pooled gradient and the pooled output — dgamma, dbeta and dx against the
+    standard route (reduction pass over the scattered gradient and the stem output) on the same tensors."""
+    from iif_amd import _lib, ops
+    n, h, w, c = 3, 18, 22, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, h, w, c, generator=g).to(dt).to(DEV)
+    m = n * h * w
+    gamma = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(c, generator=g) * 0.2).to(DEV)
+    stats = torch.zeros(4, c, device=DEV)
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    ops.bn_forward_stats(x.view(m, c), gamma, beta, rm, rv, stats, ops.bn_workspace(m, c, DEV))
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    pooled = torch.empty(n, ho, wo, c, dtype=dt, device=DEV)
+    idx = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=DEV)
+    L = _lib.lib()
+    _lib.check(L.iif_maxpool_bn_forward(_lib.ptr(x), _lib.dtype_code(x), _lib.ptr(stats), n, h, w, c, 3, 2, 1, _lib.ptr(pooled),
+                                        _lib.ptr(idx), _lib.stream_ptr()), "pool")
+    gp = torch.randn(n, ho, wo, c, generator=g).to(dt).to(DEV)
+    out = {}
+    for mode in ("standard", "pooled"):
+        dy0 = torch.empty(n, h, w, c, dtype=dt, device=DEV)
+        _lib.check(L.iif_maxpool_backward(_lib.ptr(gp), _lib.ptr(idx), _lib.dtype_code(gp), n, h, w, c, 3, 2, 1, _lib.ptr(dy0),
+                                          _lib.stream_ptr()), "pool bwd")
+        dgam, dbet = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+        ws = ops.bn_workspace(m, c, DEV)
+        if mode == "standard":
+            _lib.check(L.iif_bn_backward_relu_recompute(_lib.ptr(dy0), _lib.ptr(x), _lib.dtype_code(x), m, c, _lib.ptr(stats), _lib.ptr(gamma),
+                                                        _lib.ptr(dgam), _lib.ptr(dbet), _lib.ptr(dy0), _lib.ptr(ws), ws.numel(),
+                                                        _lib.stream_ptr()), "std")
+        else:
+            _lib.check(L.iif_bn_backward_relu_recompute_pooled(_lib.ptr(dy0), _lib.ptr(x), _lib.dtype_code(x), m, c, _lib.ptr(stats),
+                                                               _lib.ptr(gamma), _lib.ptr(dgam), _lib.ptr(dbet), _lib.ptr(dy0), _lib.ptr(ws),
+                                                               ws.numel(), _lib.ptr(gp), _lib.ptr(pooled), n * ho * wo, _lib.stream_ptr()),
+                       "pooled")
+        out[mode] = (dgam.cpu(), dbet.cpu(), dy0.float().cpu())
+    tol = 2e-5 if dt == torch.float32 else 4e-3          # bf16: the pooled value carries one more rounding than the stored x
+    ref = out["standard"]
+    got = out["pooled"]
+    # sum g: the same terms in another order; in bf16 the scattered gradient of a pixel that is the arg max of several windows
+    # was rounded to bf16 once more than the pooled gradients themselves
+    assert (got[1] - ref[1]).abs().max().item() <= (3.2e-5 if dt == torch.float32 else 2e-3) * max(1.0, ref[1].abs().max().item())
+    assert (got[0] - ref[0]).norm().item() <= tol * ref[0].norm().item()
+    assert (got[2] - ref[2]).norm().item() <= tol * ref[2].norm().item()
