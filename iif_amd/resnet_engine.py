@@ -763,13 +763,20 @@ class _Plan(object):
         self.alg3_units = set()
         self.a3_pure_min = float(os.environ.get("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "1.5e8"))
         if self.fuse_bwd and net._sync_bn is None and not os.environ.get("IIF_NO_BN3_ALGEBRA"):
-            for b in self.blocks:
+            for bi, b in enumerate(self.blocks[:-1]):
                 if "se" in b or "sc" in b or len(b["units"]) != 3:
                     continue
                 u3 = b["units"][-1]
                 cv3 = u3.conv
-                if (cv3.k == 1 and cv3.stride == 1 and cv3.groups == 1 and cv3.cin in (64, 128, 256) and cv3.cout % 64 == 0 and cv3.cout <= 4096
-                        and _dma_ok(u3.x) and u3.n * u3.ho * u3.wo < (1 << 30)):
+                # the route is taken only if the producer of this block's output gradient - the next block's conv1 data
+                # gradient - can store it gated and emit the sums (decided here, so that the Gram matrix of a unit is only
+                # ever computed for a unit that will use it)
+                nxt = self.blocks[bi + 1]
+                f = nxt["units"][0]
+                producer = ("se" not in nxt and f.conv.k == 1 and f.conv.stride == 1 and f.conv.groups == 1 and _dma_ok(f.x)
+                            and _dma_ok(nxt["inp"]))
+                if (producer and cv3.k == 1 and cv3.stride == 1 and cv3.groups == 1 and cv3.cin in (64, 128, 256) and cv3.cout % 64 == 0
+                        and cv3.cout <= 4096 and _dma_ok(u3.x) and u3.n * u3.ho * u3.wo < (1 << 30)):
                     self.alg3_units.add(u3)
         # Two-pass forward (conv3's raw output is never stored): pass 1 = statistics only, pass 2 = the same convolution with
         # BN + identity + ReLU in its epilogue (bit-identical to conv + bn_apply).  Only where backward never needs that
@@ -1320,7 +1327,7 @@ class _Plan(object):
         def work():
             ops.conv_wgrad(a2, a2, 1, 1, 1, 0, ldw=cv.ldw, out=A["gram"].view(-1)[:cv.cin * cv.ldw].view(cv.cin, cv.ldw),
                            workspace=A["ws_gram"])
-            ops.bn_stats_sums(a2.view(-1, cv.cin), A["csum"][:, :cv.cin], A["ws_sum"])
+            ops.bn_stats_sums(a2.view(-1, cv.cin), A["csum"].view(-1)[:2 * cv.cin].view(2, cv.cin), A["ws_sum"])
         st = self.ds_stream if self.ds_stream is not None else self.wg_stream
         if st is None:
             work()
@@ -1349,7 +1356,7 @@ class _Plan(object):
         if pure:
             ops.conv_wgrad(u.src, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=self.a3_ws)
         wt = A["wt"][:c * (C + c)].view(c, C + c)
-        coef = A["coef"][:, :C]
+        coef = A["coef"].view(-1)[:3 * C].view(3, C)
         ops.bn3_algebra_prep(P if pure else None, wb, c, self.bw_partial, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt,
                              A["bias"][:c], A["scr"], A["tickets"])
         # the weight gradient needs Gram / colsum (issued a block ahead) and nothing on the critical path needs it
@@ -1358,7 +1365,7 @@ class _Plan(object):
         def finish_dw():
             if not pure:
                 ops.conv_wgrad(u.src, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=self.wg_ws if self.wg_stream is not None else self.a3_ws)
-            ops.bn3_algebra_dw(P, wb, c, Ag["gram"].view(-1)[:c * cv.ldw].view(c, cv.ldw), Ag["csum"][0, :c], coef, cv._g2d)
+            ops.bn3_algebra_dw(P, wb, c, Ag["gram"].view(-1)[:c * cv.ldw].view(c, cv.ldw), Ag["csum"].view(-1)[:c], coef, cv._g2d)
         if self.wg_stream is None:
             finish_dw()
         else:

@@ -648,3 +648,42 @@ def test_fused_step_plain_ce_with_class_weights_weighted_mean(mix):
     ref.backward()
     assert relerr(loss, ref) <= 1e-4
     assert relerr(net._saved.dlogits[:, :C], lg.grad) <= 1e-4
+
+
+def test_bf16_loss_curve_of_the_default_routes_against_the_standard_backward(monkeypatch):
+    """The DEFAULT bf16 configuration at the benchmark's image size (224 x 224, batch 64: the 56 x 56 stage takes the algebraic
+    BN3 backward with sum g~ y from P = g~^T a2 — sums of the UNROUNDED conv3 output, csrc/bn3_algebra.hip — the other stages
+    the producer's sums, the stem its pooled sums) against the same network with every BN backward on the standard
+    reduction passes: six SGD steps on the damped initialisation.  The two differ by bf16 roundings only; the bound catches a
+    drift of either route (measured: <= 1.3e-3 over the six steps; bound 5e-3)."""
+    from iif_amd.custom import IIFLoss
+    arch, C, B, hw = "resnet50", 1000, 64, 224
+    counts = [max(int(1280 * (5 / 1280) ** (i / (C - 1.0))), 1) for i in range(C)]
+    x, y = _data(B, hw, counts, seed=77)
+    xd, yd = x.to(DEV), y.to(DEV)
+    crit = IIFLoss(DS(counts), variant="raw")
+    curves = {}
+    # (batch 64 instead of 256: the threshold between the two algebra variants scaled with it, so the 56 x 56 stage takes
+    # "sums from P" and the other stages the producer's sums, as at the benchmark's size)
+    monkeypatch.setenv("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "5e7")
+    for mode in ("default", "standard"):
+        if mode == "standard":
+            monkeypatch.setenv("IIF_NO_BN3_ALGEBRA", "1")
+            monkeypatch.setenv("IIF_NO_BWD_FUSE", "1")
+        net, sd = _build(arch, C, torch.bfloat16)
+        net.load_state_dict(damp_residual_branches(sd, arch))
+        net.train()
+        losses = []
+        for it in range(6):
+            loss, _ = net.loss_and_backward(xd, yd, crit)
+            net.sgd_step(0.002, 0.9, 1e-4)
+            losses.append(float(loss.item()))
+        if mode == "default":
+            plan = net._saved
+            assert len(plan.alg3_units) == 13 and any(plan._a3_is_pure(u) for u in plan.alg3_units) \
+                and not all(plan._a3_is_pure(u) for u in plan.alg3_units)               # the mixed configuration
+        curves[mode] = losses
+        del net
+    for a, b in zip(curves["default"], curves["standard"]):
+        assert abs(a - b) <= 5e-3 * abs(b), (curves["default"], curves["standard"])
+    assert curves["default"][-1] < curves["default"][0]              # (lr 0.002: the raw IIF recipe descends smoothly)
