@@ -173,10 +173,19 @@ __device__ __forceinline__ RowCoef row_coef(const CeArgs& a, int row) {
 // A wave walks rows wave_id, wave_id + n_waves, ...  The IIF table sits in LDS (one copy per block, <= 8 KB) and the
 // next row's logits are already in flight while the current row is reduced and stored (6-8 waves per SIMD at
 // C = 1000 / 1204; a register-held table cost 110 VGPRs = half the occupancy).
-// (launch bound: 16 row values per lane = C <= 1024 fit 72 registers, i.e. 7 waves per SIMD, when the allocator is told so)
+// Round 4 (the bf16 row loop was instruction-bound: 374 VALU instructions and 5 dependent loads per row, 148 branches in the
+// kernel): only the LAST chunk of a row can be ragged, so chunks 0 .. NCH-2 carry no column test at all; the lanes of the last
+// chunk that own no column hold -inf (and the table 1.0) there, so the arithmetic needs no per-element select either; the row's
+// target comes from a scalar load one row ahead, and the target logit from the row's own registers (v_readlane) instead
+// of a dependent global load after the reduction (plain CE: no mixup, no row / class weights - otherwise row_coef).
+// (launch bound: 16 row values per lane = C <= 1024 fit 80 registers, i.e. 6 waves per SIMD, when the allocator is told so; at 7 the
+// round-4 loop spills 9-14 registers)
 template <typename T, int NCH, int MODE>
-__global__ void __launch_bounds__(256, (NCH * RowIo<T>::V <= 16 ? 7 : 1)) row_reg_kernel(CeArgs a, float* sm_out, int64_t ld_sm) {
+__global__ void __launch_bounds__(256, (NCH * RowIo<T>::V <= 16 ? 6 : 1)) row_reg_kernel(CeArgs a, float* sm_out, int64_t ld_sm) {
     constexpr int V = RowIo<T>::V;                     // columns per lane and chunk: 16 bytes of T
+    constexpr int EPD = V / 4;                         // elements per dword of the raw vector
+    constexpr unsigned NEG = sizeof(T) == 2 ? 0xFF80FF80u : 0xFF800000u;       // -inf in every element of a dword
+    constexpr int JL = NCH - 1;                        // the only chunk that can be ragged
     __shared__ __attribute__((aligned(16))) float tab_s[NCH * 64 * V];
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
@@ -184,28 +193,37 @@ __global__ void __launch_bounds__(256, (NCH * RowIo<T>::V <= 16 ? 7 : 1)) row_re
     int row = blockIdx.x * wpb + (threadIdx.x >> 6);
     constexpr int DEPTH = RowIo<T>::DEPTH;            // rows in flight per wave
     typename RowIo<T>::Raw xr[DEPTH][NCH];
-    // columns of chunk j that exist for this lane: V, or 4 on the tail of a bf16 row with C % 8 == 4, or 0
-    // (recomputed where needed, 2 VALU: kept in registers it costs one wave per SIMD at C = 1000)
-    const int cl = a.C - lane * V;
-    auto nvf = [&](int j) { const int left = cl - j * 64 * V; return left >= V ? V : (left > 0 ? left : 0); };
+    // columns of the last chunk that exist for this lane: V, or 4 on the tail of a bf16 row with C % 8 == 4, or 0
+    const int left = a.C - (JL * 64 + lane) * V;
+    const int nl = left >= V ? V : (left > 0 ? left : 0);
+    const bool half_tail = (a.C % V) != 0;            // block-uniform: some lane's last vector is an 8-byte half (bf16, C % 8 == 4)
     auto load_row = [&](int r, typename RowIo<T>::Raw (&dst)[NCH]) {
         const T* xp = static_cast<const T*>(a.x) + (int64_t)r * a.ldx;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j)
-            { const int n = nvf(j); if (n > 0) dst[j] = RowIo<T>::load_raw(xp + (j * 64 + lane) * V, n); }
+        for (int j = 0; j < JL; ++j) dst[j] = RowIo<T>::load_raw(xp + (j * 64 + lane) * V, V);
+        if (half_tail) {                               // rare shape: per-lane access width
+            if (nl > 0) dst[JL] = RowIo<T>::load_raw(xp + (JL * 64 + lane) * V, nl);
+        } else {                                       // unconditional: a lane without columns re-reads the row's first vector
+            dst[JL] = RowIo<T>::load_raw(xp + (nl > 0 ? (JL * 64 + lane) * V : 0), V);
+        }
+    };
+    auto mask_tail = [&](typename RowIo<T>::Raw& t) {  // -inf into the columns that do not exist
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q * EPD >= nl) t[q] = __builtin_bit_cast(decltype(t[q] + t[q]), NEG);
     };
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (row + d * nwaves < a.B) load_row(row + d * nwaves, xr[d]);        // wave-uniform: in flight while the table is staged
     // table -> LDS in 16-byte pieces, all loads of a thread issued before the first LDS write (a scalar loop cost a
-    // single-wave block 20 dependent round trips to L2: 22 us at [1024, 1204])
+    // single-wave block 20 dependent round trips to L2: 22 us at [1024, 1204]); columns >= C hold 1.0 (-inf * 1 = -inf)
     {
         constexpr int V4 = NCH * 16 * V;                   // float4 pieces of the padded table
         f32x4 tv[(V4 + 63) / 64];
 #pragma unroll
         for (int q = 0; q < (V4 + 63) / 64; ++q) {
             const int i = threadIdx.x + q * blockDim.x;
-            tv[q] = (i < V4 && i * 4 < a.C) ? *reinterpret_cast<const f32x4*>(a.tab + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            tv[q] = (i < V4 && i * 4 < a.C) ? *reinterpret_cast<const f32x4*>(a.tab + i * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
         }
 #pragma unroll
         for (int q = 0; q < (V4 + 63) / 64; ++q) {
@@ -214,21 +232,47 @@ __global__ void __launch_bounds__(256, (NCH * RowIo<T>::V <= 16 ? 7 : 1)) row_re
         }
     }
     __syncthreads();
+    const bool plain = MODE == 0 && !a.tb && !a.roww && !a.clsw;      // block-uniform: the training loss of classification/train.py
+    // the row's target one row ahead, through the scalar cache (the row index is wave-uniform)
+    int64_t ta_next = 0;
+    if (plain && row < a.B) ta_next = a.ta[__builtin_amdgcn_readfirstlane(row)];
     float wave_loss = 0.f;
     for (; row < a.B; row += nwaves) {
         asm volatile("" ::: "memory");            // keep the table reads in LDS: hoisted into registers they halve the occupancy
         const T* x = static_cast<const T*>(a.x) + (int64_t)row * a.ldx;
+        const int64_t ta_cur = ta_next;
+        if (plain && row + nwaves < a.B) ta_next = a.ta[__builtin_amdgcn_readfirstlane(row + nwaves)];
+        mask_tail(xr[0][JL]);
+        // plain CE: the target logit out of the row's registers (lane, chunk and element are wave-uniform)
+        float xt = 0.f;
+        bool t_ok = false;
+        if (plain) {
+            t_ok = ta_cur != a.ignore && ta_cur >= 0 && ta_cur < a.C;
+            const int t = t_ok ? (int)ta_cur : 0;
+            const int tj = __builtin_amdgcn_readfirstlane(t / (64 * V)), tl = __builtin_amdgcn_readfirstlane((t / V) & 63);
+            const int te = __builtin_amdgcn_readfirstlane(t % V);
+            unsigned w = 0;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (tj == j && te / EPD == q) {
+                        const auto el = xr[0][j][q];          // by value: bit_cast of a vector-element lvalue reads element 0
+                        w = __builtin_amdgcn_readlane(__builtin_bit_cast(unsigned, el), tl);
+                    }
+            if constexpr (sizeof(T) == 2) xt = (te & 1) ? __uint_as_float(w & 0xffff0000u) : bf16_bits_to_f32(w & 0xffffu);
+            else xt = __uint_as_float(w);
+        }
         float z[NCH][V];
         float m = -INFINITY;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const float* tp = tab_s + (j * 64 + lane) * V;
-            const int n = nvf(j);
             float xv[V];
             RowIo<T>::unpack(xr[0][j], xv);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                z[j][e] = e < n ? xv[e] * tp[e] : -INFINITY;
+                z[j][e] = xv[e] * tp[e];
                 m = fmaxf(m, z[j][e]);
             }
         }
@@ -256,7 +300,7 @@ __global__ void __launch_bounds__(256, (NCH * RowIo<T>::V <= 16 ? 7 : 1)) row_re
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 const int c0 = (j * 64 + lane) * V;
-                const int n = nvf(j);
+                const int n = j < JL ? V : nl;
 #pragma unroll
                 for (int e = 0; e < V; e += 4)
                     if (e < n) *reinterpret_cast<f32x4*>(o + c0 + e) = f32x4{z[j][e] * inv_s, z[j][e + 1] * inv_s, z[j][e + 2] * inv_s, z[j][e + 3] * inv_s};
@@ -264,10 +308,19 @@ __global__ void __launch_bounds__(256, (NCH * RowIo<T>::V <= 16 ? 7 : 1)) row_re
             continue;
         }
         const float lse = m + kLn2 * fast_log2(s);
-        const RowCoef rc = row_coef(a, row);
+        RowCoef rc;
         float r = 0.f;
-        if (rc.ta >= 0) r += rc.wa * (lse - Io<T>::load1(x + rc.ta) * tab_s[rc.ta]);
-        if (rc.tb >= 0) r += rc.wb * (lse - Io<T>::load1(x + rc.tb) * tab_s[rc.tb]);
+        if (plain) {
+            rc.rw = 1.0f; rc.tb = -1; rc.wb = 0.f;
+            rc.ta = t_ok ? ta_cur : -1;
+            rc.wa = t_ok ? 1.0f : 0.0f;
+            if (!t_ok && ta_cur != a.ignore && a.status && lane == 0) atomicExch(a.status, 1);
+            if (t_ok) r = lse - xt * tab_s[(int)ta_cur];
+        } else {
+            rc = row_coef(a, row);
+            if (rc.ta >= 0) r += rc.wa * (lse - Io<T>::load1(x + rc.ta) * tab_s[rc.ta]);
+            if (rc.tb >= 0) r += rc.wb * (lse - Io<T>::load1(x + rc.tb) * tab_s[rc.tb]);
+        }
         if (lane == 0) a.loss_row[row] = rc.rw * r;
         wave_loss += rc.rw * r;
         if (a.dx == nullptr) continue;
@@ -278,8 +331,8 @@ __global__ void __launch_bounds__(256, (NCH * RowIo<T>::V <= 16 ? 7 : 1)) row_re
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c0 = (j * 64 + lane) * V;
-            const int n = nvf(j);
-            if (n > 0) {
+            const int n = j < JL ? V : nl;
+            if (j < JL || n > 0) {
                 const float* tp = tab_s + c0;
                 float p[V];
 #pragma unroll
