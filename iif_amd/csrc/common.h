@@ -50,3 +50,9 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// conv_stem.hip: the space-to-depth stem (4 x 4 taps over 16 padded channels -> 64, bf16) with BN partial sums; the
+// convolution entry routes to it when the geometry fits (IIF_EUNSUPPORTED otherwise: the general kernel runs)
+bool iif_stem4x4_ok(int N, int H, int W);
+int iif_stem4x4_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
+                       int N, int H, int W, hipStream_t st);

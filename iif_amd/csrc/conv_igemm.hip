@@ -1907,6 +1907,12 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
     const bool dma_ok = !g_sw.regstage && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL;
     const bool utap = dma_ok && (a.Cs % ET<T>::KE) == 0 && a.R * a.S <= 16 && a.R <= 16 && a.S <= 16;
     a.scatter = 0; a.ds_shift = 0; a.doy = a.dox = 0; a.Hfull = a.Hd; a.Wfull = a.Wd; a.ntaps = 0; a.in_shift = 0;
+    if constexpr (sizeof(T) == 2 && !OUTF32) {      // the stem in its space-to-depth form has a kernel of its own (conv_stem.hip)
+        if (dma_ok && !a.transposed && a.sshift == 0 && a.R == 4 && a.S == 4 && a.pad == 2 && a.Cs == 16 && a.spitch == 16 &&
+            a.Cd == 64 && a.dpitch == 64 && a.groups == 1 && a.ldw == 256 && a.Hs == a.Hd && a.Ws == a.Wd && !a.res && !a.bias && !a.bw_x &&
+            !a.src2 && !a.sbias && !a.mask_store && !a.no_store && !a.aff && iif_stem4x4_ok(a.N, a.Hd, a.Wd))
+            return iif_stem4x4_launch(a.src, a.wgt, a.dst, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.N, a.Hd, a.Wd, st);
+    }
     if (!utap) return (a.src2 || a.sbias || a.mask_store || a.no_store || a.aff) ? IIF_EUNSUPPORTED : launch_one<T, OUTF32>(a, false, src_bytes, wgt_bytes, st);
     if (!a.transposed || a.sshift == 0) {
         for (int r = 0; r < a.R; ++r)

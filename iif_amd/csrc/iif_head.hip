@@ -169,7 +169,7 @@ __device__ __forceinline__ RowCoef row_coef(const CeArgs& a, int row) {
 }
 
 // ------------------------------------------------ register-resident row (C%4==0)
-// MODE 0: CE loss + gradient, MODE 1: softmax output (fp32)
+// MODE 0: CE loss + gradient, MODE 1: softmax output (fp32), MODE 2: MODE 0 without mixup, row / class weights and half vectors
 // A wave walks rows wave_id, wave_id + n_waves, ...  The IIF table sits in LDS (one copy per block, <= 8 KB) and the
 // next row's logits are already in flight while the current row is reduced and stored (6-8 waves per SIMD at
 // C = 1000 / 1204; a register-held table cost 110 VGPRs = half the occupancy).
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256, (NCH * RowIo<T>::V <= 16 ? 6 : 1)) row_re
     // columns of the last chunk that exist for this lane: V, or 4 on the tail of a bf16 row with C % 8 == 4, or 0
     const int left = a.C - (JL * 64 + lane) * V;
     const int nl = left >= V ? V : (left > 0 ? left : 0);
-    const bool half_tail = (a.C % V) != 0;            // block-uniform: some lane's last vector is an 8-byte half (bf16, C % 8 == 4)
+    const bool half_tail = MODE != 2 && (a.C % V) != 0;     // block-uniform: some lane's last vector is an 8-byte half (bf16, C % 8 == 4)
     auto load_row = [&](int r, typename RowIo<T>::Raw (&dst)[NCH]) {
         const T* xp = static_cast<const T*>(a.x) + (int64_t)r * a.ldx;
 #pragma unroll
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256, (NCH * RowIo<T>::V <= 16 ? 6 : 1)) row_re
         }
     }
     __syncthreads();
-    const bool plain = MODE == 0 && !a.tb && !a.roww && !a.clsw;      // block-uniform: the training loss of classification/train.py
+    constexpr bool plain = MODE == 2;                   // the training loss of classification/train.py
     // the row's target one row ahead, through the scalar cache (the row index is wave-uniform)
     int64_t ta_next = 0;
     if (plain && row < a.B) ta_next = a.ta[__builtin_amdgcn_readfirstlane(row)];
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(256, (NCH * RowIo<T>::V <= 16 ? 6 : 1)) row_re
             }
         }
     }
-    if (MODE == 0) finish_with_ticket(a, wave_loss);
+    if (MODE != 1) finish_with_ticket(a, wave_loss);
 }
 
 // -------------------------------------------- streaming row (any C / alignment)
@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(256) row_stream_kernel(CeArgs a, float* sm_out
             }
         }
     }
-    if (MODE == 0) finish_with_ticket(a, wave_loss);
+    if (MODE != 1) finish_with_ticket(a, wave_loss);
 }
 
 // fixed-order sum of the per-row losses: one 256-thread block, deterministic
@@ -464,15 +464,20 @@ int launch_rows(CeArgs a, float* sm_out, int64_t ld_sm, hipStream_t st, bool* in
     const dim3 grid((a.B + wpb - 1) / wpb), block(64 * wpb);
     // register-row kernel: at most 256 CUs x 8 blocks; beyond that a wave walks several rows.  Never more blocks than the
     // single-launch loss workspace has partial slots.
-    unsigned maxb = 1024u;           // 256 / 512 / 1024 / 2048 blocks: [8192, 1204] 25.9 / 23.6 / 26.5 / 35.3 us, [65536, 1000] bf16 0.213 / 0.129 / 0.085 / 0.090 ms
+    // blocks of the register-row kernel, round-4 loop at [65536, 1000] (512 / 768 / 1024 / 1536 / 2048 blocks):
+    //   bf16 3.55 / 4.32 / 4.60 / 4.84 / 4.67 TB/s, fp32 5.22 / 5.01 / 4.98 / 4.93 / 4.82 TB/s ([8192, 1204] fp32: 512 best as well)
+    unsigned maxb = sizeof(T) == 2 ? 1536u : 512u;
     if (maxb < 1u) maxb = 1u;
     if (maxb > kMaxRowBlocks) maxb = kMaxRowBlocks;
     const dim3 pgrid(grid.x < maxb ? grid.x : maxb);
     // rows in 16-byte lane vectors: 4 fp32 / 8 bf16 columns; a bf16 row may end on a half vector (C % 8 == 4: 1204)
     constexpr int V = RowIo<T>::V;
     bool vec = (a.C % 4 == 0) && (a.C <= 2048) && (a.ldx % V == 0) && aligned(a.x, 16) && aligned(a.tab, 16);
-    if (MODE == 0 && a.dx) vec = vec && (a.lddx % V == 0) && aligned(a.dx, 16);
+    if (MODE != 1 && a.dx) vec = vec && (a.lddx % V == 0) && aligned(a.dx, 16);
     if (MODE == 1) vec = vec && (ld_sm % 4 == 0) && aligned(sm_out, 16);
+    if constexpr (MODE == 0) {       // plain CE on whole 16-byte vectors: the loop without mixup / weights / half tails
+        if (vec && !a.tb && !a.roww && !a.clsw && a.C % V == 0) return launch_rows<T, 2>(a, sm_out, ld_sm, st, inline_reduce);
+    }
     if (vec) {
         const int nch = (a.C + 64 * V - 1) / (64 * V);
         if (nch <= 1) hipLaunchKernelGGL((row_reg_kernel<T, 1, MODE>), pgrid, block, 0, st, a, sm_out, ld_sm);

@@ -948,8 +948,16 @@ class _Plan(object):
         return u
 
     # ---------------------------------------------------------------- weights
-    def prepare_weights(self, need_transposed):
+    def prepare_weights(self, need_transposed, part="all"):
+        """Low-precision / transposed / fragment-packed copies of the fp32 master weights.  part = "stem": only the stem's
+        packed matrix; "rest": everything else (forward() runs that on the idle weight-gradient stream under the stem)."""
         net = self.net
+        if part != "rest":
+            for u in self.units:
+                if u.s2d:
+                    ops.stem_s2d_pack(u.conv._w2d, u.conv.cout, u.conv.cin, u.conv.k, S2D_CPAD, u.w)
+            if part == "stem":
+                return
         if self.lp_arena is not None:
             ops.cast(net._arena, self.lp_arena)
         if need_transposed and self.wt_n:
@@ -960,9 +968,7 @@ class _Plan(object):
             ops.pack_fragments(self.wt_arena, self.frag_bwd[0], self.frag_bwd[2], self.frag_bwd[1], self.frag_arena)
         for u in self.units:
             cv = u.conv
-            if u.s2d:
-                ops.stem_s2d_pack(cv._w2d, cv.cout, cv.cin, cv.k, S2D_CPAD, u.w)
-            elif cv.groups > 1:
+            if not u.s2d and cv.groups > 1:
                 ops.group_pack(cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.w)
                 if need_transposed:
                     ops.group_pack(cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.wt, transposed=True)
@@ -1042,7 +1048,20 @@ class _Plan(object):
 
     def forward(self, img, training):
         net = self.net
-        self.prepare_weights(training)
+        prep_done = None
+        if training and self.wg_stream is not None and self.stem_s2d:
+            # The stem needs only its own packed matrix: the cast / transposes / fragment packs of every other layer
+            # (~90 us of small launches) run on the weight-gradient stream, idle at the start of a step, under the stem.
+            self.prepare_weights(training, "stem")
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.wg_stream):
+                self.wg_stream.wait_event(ev)
+                self.prepare_weights(training, "rest")
+                prep_done = torch.cuda.Event()
+                prep_done.record()
+        else:
+            self.prepare_weights(training)
         c1 = net.conv1
         if self.stem_s2d:
             ops.space_to_depth_nchw(img, S2D_CPAD, self.patches)
@@ -1050,6 +1069,8 @@ class _Plan(object):
             ops.im2col_nchw(img, c1.k, c1.k, c1.stride, c1.pad, c1.ldw, self.dt, out=self.patches)
         u = self.stem
         x2 = self._conv_bn(u, training)
+        if prep_done is not None:
+            torch.cuda.current_stream().wait_event(prep_done)
         if self.pool_fused:
             # bn1 + relu + maxpool in one pass over the raw stem output: the stem's activation is never stored
             _lib.check(_lib.lib().iif_maxpool_bn_forward(_lib.ptr(u.x), _lib.dtype_code(u.x), _lib.ptr(u.stats), u.n, u.ho, u.wo,

@@ -1,6 +1,11 @@
-# generic in-step A/B: scripts/ab_env.sh VAR [runs]   (default bench step with VAR unset, then VAR=1, alternating)
-var=$1; runs=${2:-2}
-for i in $(seq $runs); do for v in 0 1; do
-  if [ $v = 1 ]; then export $var=1; else unset $var; fi
-  timeout -k 10 200 python bench.py --no-cpu-baseline --no-fp32-step --no-kernel-events --steps 30 --warmup 8 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$var=$v', d['ms_per_step'])" || exit 1
-done; done
+#!/bin/bash
+# A/B of environment settings on the working tree in ONE gpurun call:  scripts/ab_env.sh rounds "ENV1=.. ENV2=.." "ENV3=.." ...
+# ("-" = no extra environment)
+rounds=$1; shift
+for i in $(seq $rounds); do
+  for e in "$@"; do
+    [ "$e" = "-" ] && ee="" || ee="$e"
+    echo -n "[$e] "
+    env $ee timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-fp32-step --no-kernel-events 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
+  done
+done

@@ -524,6 +524,37 @@ def test_stem_s2d_weight_gradient_all_taps_per_block(n, h, w):
         assert (dw.double().cpu() - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-6), (n, h, w, splits)
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 112, 112), (3, 16, 16), (5, 96, 96), (1, 128, 128), (2, 80, 80), (40, 112, 112), (2, 17, 23), (1, 256, 256)])
+def test_stem_s2d_forward_window_kernel(n, h, w):
+    """The stem in its space-to-depth form (4x4 / stride 1 / pad 2 top-left, 16 -> 64 channels, output size = input size;
+    classification/resnet_pytorch.py:196-197 after the 2x2 sub-pixel split): stem4x4_kernel (window of a 128-pixel tile in LDS,
+    weights in registers, one partial row per block) against an fp64 evaluation of the same bf16 operands, and its batch-norm
+    partial sums against the sums of the values it stored.  (2, 17, 23) and (1, 256, 256) do not fit it and run the general
+    kernel through the same entry point."""
+    import torch.nn.functional as F
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(n * 1000 + w)
+    x = torch.randn(n, h, w, 16, generator=g).bfloat16()
+    wt = (torch.randn(64, 256, generator=g) * 0.1).bfloat16()
+    xp = F.pad(x.double().permute(0, 3, 1, 2), (2, 1, 2, 1))
+    ref = F.conv2d(xp, wt.double().view(64, 4, 4, 16).permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    out = torch.full((n, h, w, 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    partial = torch.full((max(4096, (n * h * w + 127) // 128 + 8), 2, 64), float("nan"), device=DEV)
+    nt = ops.conv_forward_bnstats(x.to(DEV), wt.to(DEV), 4, 4, 1, 2, out, partial)
+    got = out.double().cpu()
+    assert not torch.isnan(got).any()
+    assert (got - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    ps = partial[:nt].double().sum(0).cpu()
+    flat = got.view(-1, 64)
+    s1, s2 = flat.sum(0), (flat * flat).sum(0)
+    assert nt > 0 and not torch.isnan(ps).any()
+    assert (ps[0] - s1).abs().max().item() <= 1e-5 * max(1.0, flat.abs().sum(0).max().item())
+    assert (ps[1] - s2).abs().max().item() <= 1e-5 * s2.max().item()
+    # without statistics: the same stored values
+    out2 = ops.conv_forward(x.to(DEV), wt.to(DEV), 4, 4, 1, 2, out_hw=(h, w))
+    assert torch.equal(out2, out)
+
+
 # ------------------------------------------------------------------------------------------- streaming 1x1 kernel
 STREAM_CASES = [  # N, Cin, H, W, Cout : every instantiation, ragged last tile, fewer tiles than blocks, many tiles per block
     (3, 64, 20, 23, 256), (2, 256, 17, 19, 64), (2, 256, 24, 24, 128), (1, 64, 9, 7, 64), (2, 32, 40, 40, 256),

@@ -160,6 +160,30 @@ def _ce_raw(pred, table, ta, tb=None, lam=1.0, rw=None, cw=None, ignore=-100, sc
     return rc, loss, rows, d, st
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [100, 1000, 1208])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_every_column_as_the_target(C, dt):
+    """The plain-CE loop takes the target logit out of the row's registers (lane, chunk and element of the
+    column): one row per target column, per-row losses against the closed form on the same (rounded) logits.
+    (classification/utils.py:357-361: loss = CE(pred * iif[variant], target))"""
+    dev = _dev()
+    g = torch.Generator().manual_seed(C)
+    pred = (torch.randn(C, C, generator=g) * 3).to(dt)
+    table = torch.rand(C, generator=g) * 4 + 0.5
+    tgt = torch.arange(C)
+    rc, loss, rows, d, st = _ce_raw(pred.to(dev), table.to(dev), tgt.to(dev), scale=1.0 / C)
+    assert rc == 0 and int(st.item()) == 0
+    z = pred.double() * table.double()
+    ref = torch.logsumexp(z, 1) - z[tgt, tgt]
+    assert ((rows.cpu().double() - ref).abs() <= 1e-5 * ref.abs() + 1e-5).all()
+    p = torch.softmax(z, 1)
+    p[tgt, tgt] -= 1.0
+    ref_d = p * table.double() / C
+    tol = 2.0 ** -8 if dt == torch.bfloat16 else 1e-5
+    assert ((d.float().cpu().double() - ref_d).abs() <= tol * ref_d.abs() + 1e-9).all()
+
+
 def test_cabi_ignore_index_row_weights_status():
     dev = _dev()
     B, C = 64, 1204
