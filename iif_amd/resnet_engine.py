@@ -815,8 +815,19 @@ class _Plan(object):
         self.wg_ws = torch.empty(min(16 * wmax * 4, 512 << 20), dtype=torch.uint8, device=dev)
         self._grad_pool = {}
         self._bwd_ready = False
+        # Side streams (weight gradients, shortcut branch) pay when the kernels are long enough to hide the events that tie the
+        # streams together; a small step is bound by the host's enqueue time and each cross-stream event adds to it.  Measured
+        # (scripts/ab_side_small.sh, ms per step with / without): ResNet32 32x32 bs 128 3.24 / 2.52, bs 256 3.24 / 3.33, bs 512
+        # 4.20 / 5.05; ResNet50 224 bs 16 6.74 / 6.01, bs 64 7.85 / 9.01; ResNet18 224 bs 64 2.94 / 3.19.  The crossover sits at
+        # ~5e6 convolution-output elements per layer and step.  IIF_SIDE_STREAMS=1 / 0 (or IIF_NO_WGRAD_STREAM=1) force either.
+        side = os.environ.get("IIF_SIDE_STREAMS")
+        if os.environ.get("IIF_NO_WGRAD_STREAM"):
+            side = "0"
+        if side is None:
+            per_unit = sum(u.n * u.ho * u.wo * u.conv.cout for u in self.units) / max(len(self.units), 1)
+            side = "1" if per_unit >= 5e6 else "0"
         self.wg_stream = None
-        if dev.type == "cuda" and not os.environ.get("IIF_NO_WGRAD_STREAM"):
+        if dev.type == "cuda" and side != "0":
             self.wg_stream = torch.cuda.Stream(device=dev)
         self._wg_events = {}
         self.stem_wgrad_main = self.wg_stream is not None
