@@ -352,7 +352,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--per-shape", action="store_true", help="print the per-shape conv table to stderr")
-    ap.add_argument("--event-every", type=int, default=10, help="bracket the conv launches of every n-th timed step")
+    ap.add_argument("--event-every", type=int, default=20, help="bracket the conv launches of every n-th timed step")
     ap.add_argument("--trace-loss", action="store_true", help="record the loss of every step (one tiny copy per step)")
     ap.add_argument("--force-reducer", action="store_true", help="drive the bucketed all-reduce path even with one rank")
     ap.add_argument("--reduce-mode", default="allreduce", choices=["allreduce", "rs_ag"],
