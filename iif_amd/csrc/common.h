@@ -56,3 +56,12 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 bool iif_stem4x4_ok(int N, int H, int W);
 int iif_stem4x4_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
                        int N, int H, int W, hipStream_t st);
+
+// conv_regw.hip: 1x1 / stride 1 forward or data gradient with the weights in registers (narrow -> wide layers), bf16, BN partial
+// sums; with an epilogue descriptor the data-gradient options of staged_drain (residual / its bits / gated store / upstream sums)
+struct iif_regw_epilogue {
+    const void* res; const unsigned char* res_bits; const void* bw_x; const unsigned char* bw_bits; const float* bw_stats; int mask_store;
+};
+bool iif_regw1x1_ok(int M, int K, int N, int epi);
+int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
+                       int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, hipStream_t st);

@@ -1692,7 +1692,7 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
 //   IIF_CONV_NO_HALO / IIF_CONV_HALO_FORCE   3x3 halo kernel off / also on small grids
 //   IIF_CONV_NO_V2 / IIF_CONV_V2_FORCE       3x3 fragment kernel (64 channels) off / also on small grids
 struct ConvSwitches {
-    bool no_stream, force_stream, regstage, no_v2, no_halo, force_halo, v2_force;
+    bool no_stream, force_stream, regstage, no_v2, no_halo, force_halo, v2_force, no_regw;
     static ConvSwitches read() {
         ConvSwitches c;
         c.no_stream = getenv("IIF_CONV_NO_STREAM1X1") != nullptr;
@@ -1702,6 +1702,7 @@ struct ConvSwitches {
         c.no_halo = getenv("IIF_CONV_NO_HALO") != nullptr;
         c.v2_force = getenv("IIF_CONV_V2_FORCE") != nullptr;
         c.force_halo = getenv("IIF_CONV_HALO_FORCE") != nullptr;
+        c.no_regw = getenv("IIF_CONV_NO_REGW") != nullptr;
         return c;
     }
 };
@@ -1911,7 +1912,21 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
         if (dma_ok && !a.transposed && a.sshift == 0 && a.R == 4 && a.S == 4 && a.pad == 2 && a.Cs == 16 && a.spitch == 16 &&
             a.Cd == 64 && a.dpitch == 64 && a.groups == 1 && a.ldw == 256 && a.Hs == a.Hd && a.Ws == a.Wd && !a.res && !a.bias && !a.bw_x &&
             !a.src2 && !a.sbias && !a.mask_store && !a.no_store && !a.aff && iif_stem4x4_ok(a.N, a.Hd, a.Wd))
-            return iif_stem4x4_launch(a.src, a.wgt, a.dst, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.N, a.Hd, a.Wd, st);
+        {
+            const int rc = iif_stem4x4_launch(a.src, a.wgt, a.dst, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.N, a.Hd, a.Wd, st);
+            if (rc != IIF_EUNSUPPORTED) return rc;
+        }
+        // narrow -> wide 1x1 layers: weights in registers (conv_regw.hip)
+        const bool epi = a.res || a.res_bits || a.bw_x || a.bw_bits || a.mask_store;
+        if (dma_ok && !g_sw.no_regw && a.R == 1 && a.S == 1 && a.sshift == 0 && a.pad == 0 && a.groups == 1 && a.spitch == a.Cs && a.dpitch == a.Cd &&
+            a.Hs == a.Hd && a.Ws == a.Wd && !a.bias && !a.src2 && !a.sbias && !a.no_store && !a.aff && (!epi || a.bn_partial) &&
+            iif_regw1x1_ok(a.M, a.Cs, a.Cd, epi))
+        {
+            const iif_regw_epilogue e{a.res, a.res_bits, a.bw_x, a.bw_bits, a.bw_stats, a.mask_store};
+            const int rc = iif_regw1x1_launch(a.src, a.wgt, a.dst, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.M, a.Cs, a.Cd, a.spitch,
+                                              a.ldw, a.dpitch, epi ? &e : nullptr, st);
+            if (rc != IIF_EUNSUPPORTED) return rc;
+        }
     }
     if (!utap) return (a.src2 || a.sbias || a.mask_store || a.no_store || a.aff) ? IIF_EUNSUPPORTED : launch_one<T, OUTF32>(a, false, src_bytes, wgt_bytes, st);
     if (!a.transposed || a.sshift == 0) {

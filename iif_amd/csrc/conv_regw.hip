@@ -1,0 +1,295 @@
+// 1x1 / stride 1 convolution forward (bf16) for the narrow -> wide layers of a bottleneck (conv3: K = c -> N = 4c;
+// classification/resnet_pytorch.py:160-161) with the WEIGHTS IN REGISTERS and the batch-norm partial sums of the stored output.
+//
+// Why (round 4): the 128 x 128 tile kernel runs these launches at 3.3 TB/s.  A block of it lives ~12 us for
+// 32 KB in and 32 KB out, re-fetches its weight tile from L2 through the LDS-DMA path (one weight byte per activation byte) and
+// re-reads the activation tile once per N tile.  Here a persistent block of eight waves owns ALL (or a 256-column slice) of the
+// output channels: wave w keeps the MFMA fragments of its CW columns x K in registers for the whole launch (K x CW x 2 B / 64
+// lanes = 64 VGPRs), so the DMA path carries the activation rows only, each exactly once; every wave multiplies the whole
+// 64-row tile (fragment reads out of a double-buffered LDS tile, one barrier per tile, the next tile in flight) and drains its own
+// 64 x CW block through a wave-private LDS transpose into 16-byte stores; the per-channel (sum, sum of squares) accumulate in
+// registers over the block's tiles: ONE partial row per tile sequence.  The N slices of a sequence sit on blocks b, b + 8, ... of
+// one XCD and share the activation tile through that L2.  Accumulation order over K is the tile kernel's (K steps of 32,
+// ascending): the stored values are bit-identical to it.
+#include "common.h"
+
+namespace {
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct RegwArgs {
+    const unsigned char* src; const unsigned char* wgt; unsigned char* dst; float* bn_partial;
+    int M, mtiles, spitch, ldw, Cd, dpitch, bn_row0, S;
+    // EPI kernels only (the epilogue options of conv_igemm.hip's staged_drain, same arithmetic, same meaning):
+    const unsigned char* res; const unsigned char* res_bits; const unsigned char* bw_x; const unsigned char* bw_bits;
+    const float* bw_stats; int mask_store;
+};
+
+__device__ __forceinline__ int swz64(int row) { return (row >> 1) & 2; }      // as conv_igemm.hip's swz: 64-byte LDS rows
+
+// EPI: the data-gradient epilogue (residual gated by its ReLU bits, store gated by the upstream block's ReLU bits, upstream
+// BN-backward sums with or without the upstream x).  Everything a tile's epilogue reads from memory is requested ONE TILE AHEAD
+// into registers (the MFMA phase of a tile is a fraction of a microsecond: nothing to hide a load behind), unconditionally (an
+// operand the launch does not have is read from one dummy line), 10 registers per staged 16-byte vector.
+template <int KK, int CW, int MT, bool EPI>
+__global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsigned src_bytes) {
+    constexpr int NK = KK / 32, CB = CW / 16, RB = MT / 16;
+    constexpr int SLAB = MT * 64, TILE = NK * SLAB;       // NK slabs of [MT rows x 64 B]
+    constexpr int NAP = NK * RB / 8;                       // 1-KB DMA pieces (16 rows of a slab) per wave and tile
+    constexpr int PITCH = CW * 2 + 16, STG = MT * PITCH;
+    constexpr int LPR = CW / 8, RPI = 64 / LPR, NST = MT / RPI;      // lanes per staged row, rows per store instruction, stores per tile
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert((NK * RB) % 8 == 0 && MT % RPI == 0 && 2 * TILE + 8 * STG <= 160 * 1024, "shape");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * TILE + 8 * STG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fc = lane >> 4;
+    const int S = a.S;
+    const int xcd = (int)blockIdx.x & 7, bi = (int)blockIdx.x >> 3;
+    const int slice = bi % S, seq = (bi / S) * 8 + xcd;
+    const int G = (int)gridDim.x / S;                      // tile sequences
+    const int n0 = slice * 8 * CW + wave * CW;             // this wave's first output channel
+    const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src), 0, src_bytes, 0x00020000);
+
+    auto issue_tile = [&](int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < NAP; ++i) {
+            const int q = wave + 8 * i, ks = q / RB, p = q % RB;
+            const int row = p * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ swz64(row);
+            const int m = t * MT + row;
+            const unsigned off = m < a.M ? ((unsigned)m * (unsigned)a.spitch + (unsigned)(ks * 32 + chunk * 8)) * 2u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(smem + buf * TILE + ks * SLAB + p * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    // epilogue operands of one tile: vector k of this lane = row k * RPI + lane / LPR, channels n0 + (lane % LPR) * 8 ..
+    const unsigned char* const dummy = a.wgt;
+    const bool has_res = EPI && a.res != nullptr, has_rb = EPI && a.res_bits != nullptr, has_bx = EPI && a.bw_x != nullptr;
+    const bool has_bb = EPI && a.bw_bits != nullptr;
+    constexpr int NOP = EPI ? NST : 1;
+    auto load_ops = [&](int t, u32x4 (&r)[NOP], u32x4 (&x)[NOP], unsigned (&rbv)[NOP], unsigned (&mbv)[NOP]) {
+        if constexpr (EPI) {
+            const size_t base = ((size_t)t * MT * a.dpitch + n0) * 2;
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const size_t o = base + ((size_t)(k * RPI + lane / LPR) * a.dpitch + (lane % LPR) * 8) * 2;
+                r[k] = *reinterpret_cast<const u32x4*>(has_res ? a.res + o : dummy);
+                x[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(has_bx ? a.bw_x + o : dummy));
+                rbv[k] = *(has_rb ? a.res_bits + (o >> 4) : dummy);
+                mbv[k] = *(has_bb ? a.bw_bits + (o >> 4) : dummy);
+            }
+        }
+    };
+    u32x4 c_res[NOP], c_x[NOP], n_res[NOP], n_x[NOP];
+    unsigned c_rb[NOP], c_mb[NOP], n_rb[NOP], n_mb[NOP];
+    float bmean[8], bistd[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bmean[q] = 0.f; bistd[q] = 0.f; }
+    if (has_bx) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[n0 + (lane % LPR) * 8 + q]; bistd[q] = a.bw_stats[a.dpitch + n0 + (lane % LPR) * 8 + q]; }
+    }
+    int tile = seq;
+    if (tile < a.mtiles) { issue_tile(tile, 0); load_ops(tile, c_res, c_x, c_rb, c_mb); }
+    u32x4 wreg[NK][CB];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+            wreg[ks][cb] = *reinterpret_cast<const u32x4*>(a.wgt + ((size_t)(n0 + cb * 16 + fr) * a.ldw + ks * 32 + fc * 8) * 2);
+    // The weights (and the first tile's epilogue operands) are made to ARRIVE here: left pending, the compiler's wait-count pass
+    // merges "weights still in flight" into the loop and waits for them in front of every MFMA group - vmcnt(15) ... vmcnt(0),
+    // which in steady state are waits for the NEXT tile's prefetch.
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) asm volatile("" : "+v"(wreg[ks][cb]));
+    if constexpr (EPI) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) asm volatile("" : "+v"(c_res[k]), "+v"(c_x[k]), "+v"(c_rb[k]), "+v"(c_mb[k]));
+    }
+    int xo[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { const int row = rb * 16 + fr; xo[rb] = row * 64 + ((fc ^ swz64(row)) << 4); }
+    float bs[8], bq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bs[q] = 0.f; bq[q] = 0.f; }
+    unsigned char* const stg = smem + 2 * TILE + wave * STG;
+    int buf = 0;
+    bool first = true;
+    for (; tile < a.mtiles; tile += G, buf ^= 1) {
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");     // the previous tile's stores may stay in flight
+        first = false;
+        __builtin_amdgcn_s_barrier();
+        if (tile + G < a.mtiles) { issue_tile(tile + G, buf ^ 1); load_ops(tile + G, n_res, n_x, n_rb, n_mb); }
+        const unsigned char* Ab = smem + buf * TILE;
+        f32x4 acc[CB][RB];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            u32x4 xf[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) xf[rb] = *reinterpret_cast<const u32x4*>(Ab + ks * SLAB + xo[rb]);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[ks][cb]),
+                                                                         __builtin_bit_cast(bf16x8, xf[rb]), acc[cb][rb], 0, 0, 0);
+        }
+        // lane holds channels cb * 16 + fc * 4 + {0..3} of row rb * 16 + fr
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                u32x2 w;
+                w.x = pack_bf16x2(acc[cb][rb].x, acc[cb][rb].y);
+                w.y = pack_bf16x2(acc[cb][rb].z, acc[cb][rb].w);
+                *reinterpret_cast<u32x2*>(stg + (rb * 16 + fr) * PITCH + (cb * 16 + fc * 4) * 2) = w;
+            }
+        unsigned char* const dcol = a.dst + ((size_t)tile * MT * a.dpitch + n0) * 2;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int row = k * RPI + lane / LPR, chunk = lane % LPR;
+            u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * PITCH + chunk * 16);
+            if constexpr (EPI) {                        // (the arithmetic of staged_drain, element for element)
+                if (has_res) {
+                    const u32x4 rr = c_res[k];
+                    const unsigned rb = has_rb ? c_rb[k] : 0xffu;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16_bits_to_f32(v[q] & 0xffffu) + ((rb >> (2 * q)) & 1u ? bf16_bits_to_f32(rr[q] & 0xffffu) : 0.f);
+                        const float hi = __uint_as_float(v[q] & 0xffff0000u) + ((rb >> (2 * q + 1)) & 1u ? __uint_as_float(rr[q] & 0xffff0000u) : 0.f);
+                        v[q] = pack_bf16x2(lo, hi);
+                    }
+                }
+                const unsigned mb = has_bb ? c_mb[k] : 0xffu;
+                if (a.mask_store) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned lo = (mb >> (2 * q)) & 1u ? (v[q] & 0xffffu) : 0u;
+                        const unsigned hi = (mb >> (2 * q + 1)) & 1u ? (v[q] & 0xffff0000u) : 0u;
+                        v[q] = lo | hi;
+                        if (!has_bx) { bs[2 * q] += bf16_bits_to_f32(lo); bs[2 * q + 1] += __uint_as_float(hi); }
+                    }
+                }
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dcol + ((size_t)row * a.dpitch + chunk * 8) * 2));
+                if (has_bx) {
+                    const u32x4 xv = c_x[k];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float glo = (mb >> (2 * q)) & 1u ? bf16_bits_to_f32(v[q] & 0xffffu) : 0.f;
+                        const float ghi = (mb >> (2 * q + 1)) & 1u ? __uint_as_float(v[q] & 0xffff0000u) : 0.f;
+                        const float xlo = (bf16_bits_to_f32(xv[q] & 0xffffu) - bmean[2 * q]) * bistd[2 * q];
+                        const float xhi = (__uint_as_float(xv[q] & 0xffff0000u) - bmean[2 * q + 1]) * bistd[2 * q + 1];
+                        bs[2 * q] += glo; bq[2 * q] += glo * xlo;
+                        bs[2 * q + 1] += ghi; bq[2 * q + 1] += ghi * xhi;
+                    }
+                } else if (!a.mask_store) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16_bits_to_f32(v[q] & 0xffffu), hi = __uint_as_float(v[q] & 0xffff0000u);
+                        bs[2 * q] += lo; bq[2 * q] = fmaf(lo, lo, bq[2 * q]);
+                        bs[2 * q + 1] += hi; bq[2 * q + 1] = fmaf(hi, hi, bq[2 * q + 1]);
+                    }
+                }
+            } else {
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dcol + ((size_t)row * a.dpitch + chunk * 8) * 2));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = bf16_bits_to_f32(v[q] & 0xffffu), hi = __uint_as_float(v[q] & 0xffff0000u);
+                    bs[2 * q] += lo; bq[2 * q] = fmaf(lo, lo, bq[2 * q]);
+                    bs[2 * q + 1] += hi; bq[2 * q + 1] = fmaf(hi, hi, bq[2 * q + 1]);
+                }
+            }
+        }
+        if constexpr (EPI) {
+#pragma unroll
+            for (int k = 0; k < NST; ++k) { c_res[k] = n_res[k]; c_x[k] = n_x[k]; c_rb[k] = n_rb[k]; c_mb[k] = n_mb[k]; }
+        }
+    }
+    if (a.bn_partial == nullptr || seq >= G) return;
+    // lanes that share the channel chunk (lane % LPR); every wave owns its own columns of the sequence's partial row
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) { bs[q] += __shfl_xor(bs[q], o, 64); bq[q] += __shfl_xor(bq[q], o, 64); }
+    }
+    if (lane < LPR) {
+        float* p = a.bn_partial + (int64_t)(a.bn_row0 + seq) * 2 * a.dpitch + n0 + lane * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { p[q] = bs[q]; p[a.dpitch + q] = bq[q]; }
+    }
+}
+}  // namespace
+
+// (K, N) -> (columns per wave, rows per tile): the block's 8 waves x CW columns are one N slice, S = N / (8 CW) slices.
+// epi: launches with epilogue operands take 32 columns per wave at most (10 registers per staged vector, two tiles' worth).
+static bool regw_plan(int K, int N, bool epi, int* cw, int* mt) {
+    if (K == 64 && N == 256 && epi) { *cw = 32; *mt = 64; return true; }
+    if (K == 128 && N == 512) { *cw = epi ? 32 : 64; *mt = 64; return true; }
+    if (K == 256 && N == 1024) { *cw = 32; *mt = 64; return true; }
+    if (K == 512 && N == 2048 && !epi) { *cw = 16; *mt = 64; return true; }       // (with epilogue operands: 77 against 69 us)
+    // (the wide -> narrow shapes are level with the tile kernels alone, 59.3 / 60.1 and 43.1 / 42.8 us, and level to +0.05 ms in the step)
+    if (K == 512 && N == 128 && !epi) { *cw = 16; *mt = 64; return true; }
+    if (K == 1024 && N == 256 && !epi) { *cw = 16; *mt = 32; return true; }
+    return false;
+}
+
+bool iif_regw1x1_ok(int M, int K, int N, int epi) {
+    int cw, mt;
+    if (M <= 0 || (int64_t)M * K * 2 >= 0x7f000000LL || !regw_plan(K, N, epi != 0, &cw, &mt)) return false;
+    return M % mt == 0;
+}
+
+int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
+                       int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, hipStream_t st) {
+    const bool epi = e != nullptr;
+    if (!src || !wgt || !dst || !iif_regw1x1_ok(M, K, N, epi)) return IIF_EUNSUPPORTED;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n > 0 ? n : 256;
+    }();
+    int cw = 0, mt = 0;
+    regw_plan(K, N, epi, &cw, &mt);
+    const int S = N / (8 * cw);
+    RegwArgs a{(const unsigned char*)src, (const unsigned char*)wgt, (unsigned char*)dst, bn_partial, M, M / mt, spitch, ldw, N, dpitch,
+               bn_row0, S, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (epi) {
+        a.res = (const unsigned char*)e->res; a.res_bits = e->res_bits; a.bw_x = (const unsigned char*)e->bw_x; a.bw_bits = e->bw_bits;
+        a.bw_stats = e->bw_stats; a.mask_store = e->mask_store;
+    }
+    const int unit = 8 * S;
+    int grid = cus / unit * unit;
+    const int need = (a.mtiles + 7) / 8 * unit;
+    if (need < grid) grid = need;
+    // one partial row per tile sequence, never more rows than the tile kernels write (ceil(M / 128): what callers size for)
+    const int rows128 = (M + 127) / 128;
+    if (bn_partial && grid / S > rows128) grid = rows128 / 8 * unit;
+    if (grid < unit) return IIF_EUNSUPPORTED;
+    const int G = grid / S;
+    if (bn_partial) {
+        if ((long long)(bn_row0 + G) * 2 * dpitch > bn_cap) return IIF_EINVAL;
+        if (rows_out) *rows_out = bn_row0 + G;
+    }
+    const unsigned sb = (unsigned)((int64_t)M * spitch * 2);
+    const dim3 g((unsigned)grid), b(512);
+#define IIF_REGW(KK, CW, MT, EP) hipLaunchKernelGGL((gemm1x1_regw_kernel<KK, CW, MT, EP>), g, b, 0, st, a, sb)
+    if (epi) {
+        if (K == 64) IIF_REGW(64, 32, 64, true);
+        else if (K == 128) IIF_REGW(128, 32, 64, true);
+        else IIF_REGW(256, 32, 64, true);
+    } else {
+        if (K == 128) IIF_REGW(128, 64, 64, false);
+        else if (K == 256) IIF_REGW(256, 32, 64, false);
+        else if (K == 512) IIF_REGW(512, 16, 64, false);
+        else IIF_REGW(1024, 16, 32, false);
+    }
+#undef IIF_REGW
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}

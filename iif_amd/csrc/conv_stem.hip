@@ -186,7 +186,9 @@ int iif_stem4x4_launch(const void* src, const void* wgt, void* dst, float* bn_pa
                N * H * W / SBM, 64, bn_row0};
     int grid = 2 * cus / 8 * 8;                          // two blocks per CU, whole groups of 8 (one per XCD)
     const int need = (a.ntiles + 7) / 8 * 8;
-    if (need < grid) grid = need;
+    if (need < grid) grid = need;                       // (never more partial rows than the tile kernels' ceil(M / 128) = ntiles)
+    if (bn_partial && grid > a.ntiles) grid = a.ntiles / 8 * 8;
+    if (grid < 8) return IIF_EUNSUPPORTED;
     if (bn_partial) {
         if ((long long)(bn_row0 + grid) * 2 * a.dpitch > bn_cap) return IIF_EINVAL;
         if (rows_out) *rows_out = bn_row0 + grid;

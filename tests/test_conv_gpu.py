@@ -421,7 +421,11 @@ def test_conv3x3_fragment_kernel(case, conv_env):
 
 @pytest.mark.parametrize("case", [(4, 64, 14, 14, 128, 1, 1, True, True), (4, 128, 14, 14, 64, 3, 1, False, False),
                                   (3, 64, 16, 16, 128, 3, 2, False, True), (3, 256, 16, 16, 512, 1, 2, True, False),
-                                  (8, 256, 28, 28, 128, 3, 1, False, True), (2, 64, 15, 13, 128, 3, 2, False, True)])
+                                  (8, 256, 28, 28, 128, 3, 1, False, True), (2, 64, 15, 13, 128, 3, 2, False, True),
+                                  # narrow -> wide 1x1 with M % 64 == 0: the weights-in-registers kernel (conv_regw.hip, EPI)
+                                  (4, 256, 16, 16, 64, 1, 1, True, True), (8, 512, 16, 16, 128, 1, 1, False, True),
+                                  (16, 1024, 16, 16, 256, 1, 1, True, False), (64, 2048, 8, 8, 512, 1, 1, True, True),
+                                  (40, 512, 28, 28, 128, 1, 1, True, True)])
 def test_dgrad_emits_upstream_bn_backward_sums(case):
     """iif_conv_igemm_dgrad_bnbwd: the data gradient (stride 1 and the 4 parity classes of stride 2, with and without
     residual) plus per-tile (sum g, sum g*xhat) of the upstream unit, g = stored gradient gated by its ReLU bits."""
@@ -553,6 +557,37 @@ def test_stem_s2d_forward_window_kernel(n, h, w):
     # without statistics: the same stored values
     out2 = ops.conv_forward(x.to(DEV), wt.to(DEV), 4, 4, 1, 2, out_hw=(h, w))
     assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("case", [(16, 16, 128, 512), (16, 16, 256, 1024), (64, 8, 512, 2048), (16, 16, 512, 128), (16, 16, 1024, 256),
+                                  (37, 28, 128, 512), (3, 16, 128, 512)],
+                         ids=lambda c: "%dx%dx%d_%d_%d" % (c[0], c[1], c[1], c[2], c[3]))
+def test_forward_1x1_weights_in_registers_equals_the_tile_kernel(case, conv_env):
+    """conv_regw.hip (persistent blocks, weight fragments in registers, one partial row per tile sequence) against the tile
+    kernels through the same entry point: stored values bit-identical (same K order), batch-norm sums equal to 1e-6;
+    (3, 16, ..) has too few rows for it and runs the tile kernel on both sides."""
+    from iif_amd import ops
+    n, hw, k, c = case
+    g = torch.Generator().manual_seed(k + c + n)
+    x = torch.randn(n, hw, hw, k, generator=g).bfloat16().to(DEV)
+    wt = (torch.randn(c, k, generator=g) / k ** 0.5).bfloat16().to(DEV)
+    m = n * hw * hw
+    res = []
+    for off in (False, True):
+        conv_env(IIF_CONV_NO_REGW="1" if off else None)
+        out = torch.full((n, hw, hw, c), float("nan"), dtype=torch.bfloat16, device=DEV)
+        partial = torch.full(((m + 127) // 128 + 8, 2, c), float("nan"), device=DEV)
+        nt = ops.conv_forward_bnstats(x, wt, 1, 1, 1, 0, out, partial.view(-1))
+        plain = ops.conv_forward(x, wt, 1, 1, 1, 0)
+        assert torch.equal(plain, out)
+        res.append((out, partial[:nt].double().sum(0).cpu(), nt))
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][2] <= (m + 127) // 128
+    flat = res[0][0].double().cpu().view(m, c)
+    ref = torch.stack([flat.sum(0), (flat * flat).sum(0)])
+    for _, ps, _ in res:
+        assert not torch.isnan(ps).any()
+        assert (ps - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
 
 
 # ------------------------------------------------------------------------------------------- streaming 1x1 kernel
@@ -747,7 +782,10 @@ def test_bn3_backward_by_algebra(case, from_p):
     assert rel(da.view(m, c), ref_da) <= 1e-2
 
 
-@pytest.mark.parametrize("case", [(2, 14, 64, 256), (3, 11, 128, 512)], ids=lambda c: "%dx%dx%d_%d_%d" % (c[0], c[1], c[1], c[2], c[3]))
+@pytest.mark.parametrize("case", [(2, 14, 64, 256), (3, 11, 128, 512),
+                                  # M % 64 == 0: the weights-in-registers kernel (conv_regw.hip, EPI), one to sixteen N slices
+                                  (4, 16, 64, 256), (8, 16, 128, 512), (4, 32, 256, 1024), (16, 16, 512, 2048), (33, 32, 128, 512)],
+                         ids=lambda c: "%dx%dx%d_%d_%d" % (c[0], c[1], c[1], c[2], c[3]))
 def test_dgrad_masked_store_and_column_sums(case):
     """iif_conv_igemm_dgrad_masksum: the conv1 data gradient (+ ReLU-gated residual) stored already gated by the upstream
     block's ReLU bits, per-tile column sums of the stored tensor in the partial rows; bit-identical to the plain data gradient
