@@ -64,4 +64,4 @@ struct iif_regw_epilogue {
 };
 bool iif_regw1x1_ok(int M, int K, int N, int epi);
 int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
-                       int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, hipStream_t st);
+                       int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, int no_store, hipStream_t st);

@@ -1919,12 +1919,12 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
         // narrow -> wide 1x1 layers: weights in registers (conv_regw.hip)
         const bool epi = a.res || a.res_bits || a.bw_x || a.bw_bits || a.mask_store;
         if (dma_ok && !g_sw.no_regw && a.R == 1 && a.S == 1 && a.sshift == 0 && a.pad == 0 && a.groups == 1 && a.spitch == a.Cs && a.dpitch == a.Cd &&
-            a.Hs == a.Hd && a.Ws == a.Wd && !a.bias && !a.src2 && !a.sbias && !a.no_store && !a.aff && (!epi || a.bn_partial) &&
+            a.Hs == a.Hd && a.Ws == a.Wd && !a.bias && !a.src2 && !a.sbias && !a.aff && (!epi || (a.bn_partial && !a.no_store)) &&
             iif_regw1x1_ok(a.M, a.Cs, a.Cd, epi))
         {
             const iif_regw_epilogue e{a.res, a.res_bits, a.bw_x, a.bw_bits, a.bw_stats, a.mask_store};
             const int rc = iif_regw1x1_launch(a.src, a.wgt, a.dst, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.M, a.Cs, a.Cd, a.spitch,
-                                              a.ldw, a.dpitch, epi ? &e : nullptr, st);
+                                              a.ldw, a.dpitch, epi ? &e : nullptr, a.no_store, st);
             if (rc != IIF_EUNSUPPORTED) return rc;
         }
     }

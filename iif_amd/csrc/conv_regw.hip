@@ -22,6 +22,7 @@ struct RegwArgs {
     // EPI kernels only (the epilogue options of conv_igemm.hip's staged_drain, same arithmetic, same meaning):
     const unsigned char* res; const unsigned char* res_bits; const unsigned char* bw_x; const unsigned char* bw_bits;
     const float* bw_stats; int mask_store;
+    int no_store;          // forward only: the tile is rounded and summed exactly as if it were stored, and dropped (two-pass forward)
 };
 
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 2; }      // as conv_igemm.hip's swz: 64-byte LDS rows
@@ -118,6 +119,7 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
     bool first = true;
     for (; tile < a.mtiles; tile += G, buf ^= 1) {
         if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (!EPI && a.no_store) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no stores behind the DMA to count over)
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");     // the previous tile's stores may stay in flight
         first = false;
         __builtin_amdgcn_s_barrier();
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
                     }
                 }
             } else {
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dcol + ((size_t)row * a.dpitch + chunk * 8) * 2));
+                if (!a.no_store) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dcol + ((size_t)row * a.dpitch + chunk * 8) * 2));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float lo = bf16_bits_to_f32(v[q] & 0xffffu), hi = __uint_as_float(v[q] & 0xffff0000u);
@@ -246,8 +248,9 @@ bool iif_regw1x1_ok(int M, int K, int N, int epi) {
 }
 
 int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
-                       int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, hipStream_t st) {
+                       int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, int no_store, hipStream_t st) {
     const bool epi = e != nullptr;
+    if (epi && no_store) return IIF_EUNSUPPORTED;
     if (!src || !wgt || !dst || !iif_regw1x1_ok(M, K, N, epi)) return IIF_EUNSUPPORTED;
     static const int cus = [] {
         int dev = 0, n = 0;
@@ -258,7 +261,7 @@ int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_pa
     regw_plan(K, N, epi, &cw, &mt);
     const int S = N / (8 * cw);
     RegwArgs a{(const unsigned char*)src, (const unsigned char*)wgt, (unsigned char*)dst, bn_partial, M, M / mt, spitch, ldw, N, dpitch,
-               bn_row0, S, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+               bn_row0, S, nullptr, nullptr, nullptr, nullptr, nullptr, 0, no_store};
     if (epi) {
         a.res = (const unsigned char*)e->res; a.res_bits = e->res_bits; a.bw_x = (const unsigned char*)e->bw_x; a.bw_bits = e->bw_bits;
         a.bw_stats = e->bw_stats; a.mask_store = e->mask_store;

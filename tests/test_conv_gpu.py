@@ -637,9 +637,9 @@ def test_stream1x1_forward_stats_and_dgrad_epilogues(case, conv_env):
 
     def run(force):
         if force:
-            conv_env(IIF_CONV_STREAM1X1_FORCE="1", IIF_CONV_NO_STREAM1X1=None)
+            conv_env(IIF_CONV_STREAM1X1_FORCE="1", IIF_CONV_NO_STREAM1X1=None, IIF_CONV_NO_REGW="1")    # (this test: streaming against tile kernel)
         else:
-            conv_env(IIF_CONV_STREAM1X1_FORCE=None, IIF_CONV_NO_STREAM1X1="1")
+            conv_env(IIF_CONV_STREAM1X1_FORCE=None, IIF_CONV_NO_STREAM1X1="1", IIF_CONV_NO_REGW="1")
         out = torch.full((n, h, w, cout), float("nan"), dtype=dt, device=DEV)
         partial = torch.full((((m + 127) // 128) * 2 * cout,), float("nan"), device=DEV)
         nt = ops.conv_forward_bnstats(xd, wd, 1, 1, 1, 0, out, partial)
@@ -677,9 +677,9 @@ def test_stream1x1_forward_stats_and_dgrad_epilogues(case, conv_env):
     bits2 = torch.randint(0, 256, (m * cin // 8,), dtype=torch.uint8, generator=g).to(DEV)
     for force in (True, False):
         if force:
-            conv_env(IIF_CONV_STREAM1X1_FORCE="1", IIF_CONV_NO_STREAM1X1=None)
+            conv_env(IIF_CONV_STREAM1X1_FORCE="1", IIF_CONV_NO_STREAM1X1=None, IIF_CONV_NO_REGW="1")    # (this test: streaming against tile kernel)
         else:
-            conv_env(IIF_CONV_STREAM1X1_FORCE=None, IIF_CONV_NO_STREAM1X1="1")
+            conv_env(IIF_CONV_STREAM1X1_FORCE=None, IIF_CONV_NO_STREAM1X1="1", IIF_CONV_NO_REGW="1")
         dx = ops.conv_dgrad(dyd, wtt, 1, 1, 1, 0, (h, w), res=res.view(n, h, w, cin).to(DEV), res_bits=bits)
         out2 = torch.full((n, h, w, cin), float("nan"), dtype=dt, device=DEV)
         partial = torch.full(((m + 127) // 128 + 8, 2, cin), float("nan"), device=DEV)
