@@ -65,3 +65,8 @@ struct iif_regw_epilogue {
 bool iif_regw1x1_ok(int M, int K, int N, int epi);
 int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
                        int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, int no_store, hipStream_t st);
+// 3x3 / stride 1 / pad 1, C -> C channels (64, 128), forward or data gradient (explicit tap list), optional upstream BN-backward sums
+bool iif_regw3x3_ok(int N, int H, int W, int C);
+int iif_regw3x3_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
+                       int N, int H, int W, int C, int ldw, const signed char* tap_dy, const signed char* tap_dx, const unsigned char* tap_w,
+                       const void* bw_x, const unsigned char* bw_bits, const float* bw_stats, hipStream_t st);

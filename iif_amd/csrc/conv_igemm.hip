@@ -1793,6 +1793,16 @@ inline bool use_v2(const ConvArgs& a, bool utap, int esz, bool outf32) {
 template <typename T, bool OUTF32>
 int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipStream_t st) {
     const bool force_v1_ = g_sw.regstage;
+    if constexpr (sizeof(T) == 2 && !OUTF32) {          // 3x3 with the weights in registers (conv_regw.hip): 64 -> 64 channels
+        if (!force_v1_ && !g_sw.no_regw && utap && src_bytes < 0x7f000000LL && a.ntaps == 9 && a.R == 3 && a.S == 3 && a.pad == 1 &&
+            a.Hs == a.Hd && a.Ws == a.Wd && a.groups == 1 && a.Cs == a.Cd && a.spitch == a.Cs && a.dpitch == a.Cd && !a.scatter &&
+            a.in_shift == 0 && !a.res && !a.res_bits && !a.bias && !a.mask_store && !a.src2 && !a.sbias && !a.no_store && !a.aff &&
+            a.Cs == 64 && (!(a.bw_x || a.bw_bits) || a.bn_partial) && iif_regw3x3_ok(a.N, a.Hd, a.Wd, a.Cs)) {
+            const int rc = iif_regw3x3_launch(a.src, a.wgt, a.dst, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.N, a.Hd, a.Wd, a.Cs, a.ldw,
+                                              a.tap_dy, a.tap_dx, a.tap_w, a.bw_x, a.bw_bits, a.bw_stats, st);
+            if (rc != IIF_EUNSUPPORTED) return rc;
+        }
+    }
     if (!force_v1_ && src_bytes < 0x7f000000LL && use_v2(a, utap, (int)sizeof(T), OUTF32)) {
         a.mtiles = (a.M + 255) / 256;
         a.ntiles = a.Cd / 64;

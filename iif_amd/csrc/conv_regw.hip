@@ -296,3 +296,285 @@ int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_pa
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }
+
+// =====================================================================================================================
+// 3x3 / stride 1 / pad 1, 64 -> 64 channels (conv2 of the 56 x 56 bottlenecks, forward and data gradient;
+// classification/resnet_pytorch.py:156-158) with the weights in registers.
+//
+// The window kernels run these layers at ~20 % of the matrix pipe: conv3x3_v2n64 fetches four weight fragments per K step
+// straight from L2 (46 cycles each to a lone wave) and, like every raster-order tile, pulls a window of 2.3-3.6 x the tile's
+// pixels through the LDS-DMA path (a 128-pixel run of a 56-wide image touches 4 rows + 2 halo rows of 58), which is what bounds it:
+// the CU's DMA fill rate, ~8.5 B/clk.  Here
+//   * a tile is an 8 x 8 pixel SQUARE: its window is 10 x 10 pixels (1.56 x), one 1-KB DMA piece per wave and 32-channel chunk;
+//     window rows are a compile-time function of the lane (no per-tile divisions), padding = out-of-range DMA lanes;
+//   * the nine taps' fragments of a wave's 32 output channels x all 64 input channels stay in registers for the whole launch
+//     (9 x 64 x 32 x 2 B / 64 lanes = 144 VGPRs): the only memory instructions of the tap loop are the fragment reads, 0.5 KB of
+//     LDS per MFMA; four waves = 2 column slices x 2 pixel groups of 32, TWO blocks per CU;
+//   * persistent blocks, a tile's whole window two tiles ahead in a three-slot ring (counted vmcnt, always the same number of
+//     instructions per tile), two barriers per tile; the tile leaves through a block-wide staged transpose (whole 128-byte lines,
+//     16 B per lane) with the BN sums - or, for the data gradient, the upstream BN-backward sums - on the way; ONE partial row
+//     per block.  K order = chunk-major, tap-minor, as conv3x3_v2n64.
+//   Measured alone at [256, 56, 56, 64] (scripts/bm_regw3.py): forward + sums 67 us (conv3x3_v2n64: 102), data gradient + upstream
+//   sums 128 (134); stages on the way: raster 128-pixel tiles 98 us (window DMA-bound), 8 x 8 tiles with eight waves 84 -> 78 us.
+namespace {
+struct Regw3Args {
+    const unsigned char* src; const unsigned char* wgt; unsigned char* dst; float* bn_partial;
+    const unsigned char* bw_x; const unsigned char* bw_bits; const float* bw_stats;
+    int N, H, W, M, ntiles, tiles_x, tiles_per_image, ldw, bn_row0;
+    unsigned m_tpi, m_tx;          // magic multipliers of tiles_per_image and tiles_x
+    signed char tap_dy[9], tap_dx[9]; unsigned char tap_w[9];
+};
+
+__device__ __forceinline__ int fdiv22(int x, float rd) { return (int)(((float)x + 0.5f) * rd); }      // exact for x < 2^22
+
+// magic-number division of a wave-uniform index on the scalar unit (q = floor(t / d) for t < 2^32 / d): the float-reciprocal form costs
+// four VALU instructions per use even for uniform operands, and the tile bookkeeping below was a third of this kernel's VALU time
+__device__ __forceinline__ unsigned udiv_magic(unsigned t, unsigned m) { return m ? __umulhi(t, m) : t; }      // m = 0: divisor 1
+
+template <bool EPI>
+__global__ void __launch_bounds__(256, 2) conv3x3_regw64_kernel(Regw3Args a, unsigned src_bytes) {
+    constexpr int C = 64, CW = 32, NCH = 2, CB = 2, PB = 2, TS = 8, WS = TS + 2;      // tile side, window side
+    constexpr int HR = 128, CHB = HR * 64, SLOT = NCH * CHB, NSLOT = 3;         // window: 100 pixels in 8 pieces of 16 per 32-channel chunk
+    constexpr int PITCH = C * 2 + 16, STG = 64 * PITCH;
+    constexpr int NDMA = 2 * NCH;                                               // DMA instructions per wave and tile (pieces w and w + 4)
+    constexpr int NV = 2;                                                       // staged 16-byte vectors per thread and tile
+    constexpr int NOPS = EPI ? 2 * NV : 0;                                      // epilogue operand loads per thread and tile
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * SLOT + STG + 4 * 2 * C * 4];
+    unsigned char* const stage = smem + NSLOT * SLOT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fc = lane >> 4;
+    const int slice = wave & 1, pgrp = wave >> 1;                               // 32 output channels x 32 pixels (four tile rows)
+    const int n0 = slice * CW, px0 = pgrp * 32;
+    const int H = a.H, W = a.W;
+    const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src), 0, src_bytes, 0x00020000);
+
+    // tiles of this block: a contiguous range per XCD
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int t8 = (a.ntiles + 7) >> 3;
+    const int tend = (xcd + 1) * t8 < a.ntiles ? (xcd + 1) * t8 : a.ntiles;
+    int tile = xcd * t8 + jb;
+    auto tile_origin = [&](int t, int& n, int& y0, int& x0) {                  // scalar unit
+        const unsigned tt = (unsigned)__builtin_amdgcn_readfirstlane(t);
+        const unsigned nn = udiv_magic(tt, a.m_tpi), r = tt - nn * (unsigned)a.tiles_per_image;
+        const unsigned ty = udiv_magic(r, a.m_tx), tx = r - ty * (unsigned)a.tiles_x;
+        n = (int)nn; y0 = (int)ty * TS; x0 = (int)tx * TS;
+    };
+
+    // this lane's two window pixels (pieces w and w + 4: pixels 16 w .. and 64 + 16 w ..; the last piece is all padding)
+    int wyx[2][2], dch[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int hrl = 16 * (wave + 4 * i) + (lane >> 2);
+        wyx[i][0] = hrl < WS * WS ? hrl / WS : -100;              // (a window row nobody has: out of range for every tile)
+        wyx[i][1] = hrl - (hrl / WS) * WS;
+        dch[i] = ((lane & 3) ^ swz64(hrl)) * 16;
+    }
+    // The window of tile t goes out two tiles ahead, ALWAYS NDMA instructions per wave (a tile past the range is all out-of-range
+    // lanes: zeros into a slot nobody reads), because the waits below count instructions.
+    auto issue_window = [&](int t, int slot) {
+        int n, y0, x0;
+        tile_origin(t < tend ? t : tile, n, y0, x0);
+        const bool livet = t < tend;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int yy = y0 - 1 + wyx[i][0], xx = x0 - 1 + wyx[i][1];
+            const bool ok = livet && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const unsigned off = ok ? (unsigned)((n * H + yy) * W + xx) * (unsigned)(C * 2) + (unsigned)dch[i] : OOB;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(smem + slot * SLOT + c * CHB + (wave + 4 * i) * 1024), 16, off,
+                                                         (unsigned)(c * 64), 0, 0);
+        }
+    };
+    issue_window(tile, 0);
+    issue_window(tile + per_xcd, 1);
+    u32x4 wreg[9][NCH][CB];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+                wreg[t][c][cb] = *reinterpret_cast<const u32x4*>(a.wgt + ((size_t)(n0 + cb * 16 + fr) * a.ldw + a.tap_w[t] * C + c * 32 + fc * 8) * 2);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) asm volatile("" : "+v"(wreg[t][c][cb]));      // arrive here (see gemm1x1_regw_kernel)
+    // fragment addresses: pixel p of the tile sits at window row (p / 8 + 1) * 10 + p % 8 + 1; a tap adds dy * 10 + dx
+    int faddr[PB][9];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const int p = px0 + pb * 16 + fr, hb = ((p >> 3) + 1) * WS + (p & 7) + 1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hr = hb + a.tap_dy[t] * WS + a.tap_dx[t];
+            faddr[pb][t] = hr * 64 + ((fc ^ swz64(hr)) << 4);
+        }
+    }
+    float bs[8], bq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bs[q] = 0.f; bq[q] = 0.f; }
+    const unsigned char* const dummy = a.wgt;
+    const bool has_bx = EPI && a.bw_x != nullptr, has_bb = EPI && a.bw_bits != nullptr;
+    const int vchunk = tid & 7, vrow = tid >> 3;                    // this thread's staged vectors: tile pixels vrow and vrow + 32
+    float bmean[8], bistd[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bmean[q] = 0.f; bistd[q] = 0.f; }
+    if (has_bx) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[vchunk * 8 + q]; bistd[q] = a.bw_stats[C + vchunk * 8 + q]; }
+    }
+    int slot = 0;
+    bool first = true;
+    for (; tile < tend; tile += per_xcd, slot = slot == NSLOT - 1 ? 0 : slot + 1) {
+        // Vector-memory instructions per wave, in issue order (D = a tile's NDMA window pieces, ops = its NOPS operand loads, st = its
+        // NV stores):  .. (j-2): D(j) ops(j-2) st(j-2) | (j-1): D(j+1) ops(j-1) st(j-1) | (j): ..   D(j) has NDMA + 2 NOPS + 2 NV younger.
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 2 * NOPS + 2 * NV) : "memory");
+        first = false;
+        __builtin_amdgcn_s_barrier();                              // the window has landed for every wave; the slot of tile j - 1 is free
+        issue_window(tile + 2 * per_xcd, slot == 0 ? NSLOT - 1 : slot - 1);
+        int n, y0, x0;
+        tile_origin(tile, n, y0, x0);
+        size_t vo[NV];
+        u32x4 ox[NV];
+        unsigned ob[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int p = vrow + 32 * i;
+            vo[i] = ((size_t)((n * H + y0 + (p >> 3)) * W + x0 + (p & 7)) * C + vchunk * 8) * 2;
+            if (EPI) {                                             // the tile's epilogue operands, unconditionally
+                ox[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(has_bx ? a.bw_x + vo[i] : dummy));
+                ob[i] = *(has_bb ? a.bw_bits + (vo[i] >> 4) : dummy);
+            }
+        }
+        f32x4 acc[CB][PB];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) acc[cb][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const unsigned char* Ab = smem + slot * SLOT + c * CHB;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                u32x4 xf[PB];
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) xf[pb] = *reinterpret_cast<const u32x4*>(Ab + faddr[pb][t]);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb)
+                        acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[t][c][cb]),
+                                                                             __builtin_bit_cast(bf16x8, xf[pb]), acc[cb][pb], 0, 0, 0);
+            }
+        }
+        // ---- the tile leaves through the block's staging buffer: lane holds channels n0 + cb*16 + fc*4 + {0..3} of tile pixel px0 + pb*16 + fr
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                u32x2 w;
+                w.x = pack_bf16x2(acc[cb][pb].x, acc[cb][pb].y);
+                w.y = pack_bf16x2(acc[cb][pb].z, acc[cb][pb].w);
+                *reinterpret_cast<u32x2*>(stage + (px0 + pb * 16 + fr) * PITCH + (n0 + cb * 16 + fc * 4) * 2) = w;
+            }
+        // (not __syncthreads(): that also waits for vmcnt(0), i.e. for the windows just requested two tiles ahead)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stage + (vrow + 32 * i) * PITCH + vchunk * 16);
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + vo[i]));
+            if (EPI && has_bx) {
+                const unsigned mb = has_bb ? ob[i] : 0xffu;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float glo = (mb >> (2 * q)) & 1u ? bf16_bits_to_f32(v[q] & 0xffffu) : 0.f;
+                    const float ghi = (mb >> (2 * q + 1)) & 1u ? __uint_as_float(v[q] & 0xffff0000u) : 0.f;
+                    const float xlo = (bf16_bits_to_f32(ox[i][q] & 0xffffu) - bmean[2 * q]) * bistd[2 * q];
+                    const float xhi = (__uint_as_float(ox[i][q] & 0xffff0000u) - bmean[2 * q + 1]) * bistd[2 * q + 1];
+                    bs[2 * q] += glo; bq[2 * q] += glo * xlo;
+                    bs[2 * q + 1] += ghi; bq[2 * q + 1] += ghi * xhi;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = bf16_bits_to_f32(v[q] & 0xffffu), hi = __uint_as_float(v[q] & 0xffff0000u);
+                    bs[2 * q] += lo; bq[2 * q] = fmaf(lo, lo, bq[2 * q]);
+                    bs[2 * q + 1] += hi; bq[2 * q + 1] = fmaf(hi, hi, bq[2 * q + 1]);
+                }
+            }
+        }
+    }
+    if (a.bn_partial == nullptr) return;
+    // lanes of a wave that share the channel chunk (lane % 8), then the four waves through LDS: fixed order, one row per block
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { bs[q] += __shfl_xor(bs[q], o, 64); bq[q] += __shfl_xor(bq[q], o, 64); }
+    }
+    float* const scratch = reinterpret_cast<float*>(stage + STG);           // [4 waves][2][C]
+    __syncthreads();
+    if (lane < 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            scratch[(wave * 2 + 0) * C + lane * 8 + q] = bs[q];
+            scratch[(wave * 2 + 1) * C + lane * 8 + q] = bq[q];
+        }
+    }
+    __syncthreads();
+    if (tid < C) {
+        float s2 = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s2 += scratch[(w * 2 + 0) * C + tid]; q2 += scratch[(w * 2 + 1) * C + tid]; }
+        float* p = a.bn_partial + (int64_t)(a.bn_row0 + blockIdx.x) * 2 * C + tid;
+        p[0] = s2; p[C] = q2;
+    }
+}
+}  // namespace
+
+bool iif_regw3x3_ok(int N, int H, int W, int C) {
+    if (C != 64 || N <= 0 || H <= 0 || W <= 0 || (H % 8) || (W % 8)) return false;
+    return (int64_t)N * H * W < (1 << 22) && (int64_t)N * H * W * C * 2 < 0x7f000000LL;
+}
+
+int iif_regw3x3_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
+                       int N, int H, int W, int C, int ldw, const signed char* tap_dy, const signed char* tap_dx, const unsigned char* tap_w,
+                       const void* bw_x, const unsigned char* bw_bits, const float* bw_stats, hipStream_t st) {
+    if (!src || !wgt || !dst || !iif_regw3x3_ok(N, H, W, C)) return IIF_EUNSUPPORTED;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n > 0 ? n : 256;
+    }();
+    Regw3Args a{};
+    a.src = (const unsigned char*)src; a.wgt = (const unsigned char*)wgt; a.dst = (unsigned char*)dst; a.bn_partial = bn_partial;
+    a.bw_x = (const unsigned char*)bw_x; a.bw_bits = bw_bits; a.bw_stats = bw_stats;
+    a.N = N; a.H = H; a.W = W; a.M = N * H * W; a.tiles_x = W / 8; a.tiles_per_image = (H / 8) * (W / 8);
+    a.ntiles = N * a.tiles_per_image; a.ldw = ldw; a.bn_row0 = bn_row0;
+    for (int t = 0; t < 9; ++t) { a.tap_dy[t] = tap_dy[t]; a.tap_dx[t] = tap_dx[t]; a.tap_w[t] = tap_w[t]; }
+    a.m_tpi = a.tiles_per_image == 1 ? 0u : (unsigned)(((1ull << 32) + a.tiles_per_image - 1) / a.tiles_per_image);
+    a.m_tx = a.tiles_x == 1 ? 0u : (unsigned)(((1ull << 32) + a.tiles_x - 1) / a.tiles_x);
+    int grid = 2 * cus / 8 * 8;                                          // two four-wave blocks per CU
+    const int need = (a.ntiles + 7) / 8 * 8;
+    if (need < grid) grid = need;
+    const int rows128 = (a.M + 127) / 128;
+    if (bn_partial && grid > rows128) grid = rows128 / 8 * 8;            // never more partial rows than the tile kernels' ceil(M / 128)
+    if (grid < 8) return IIF_EUNSUPPORTED;
+    if (bn_partial) {
+        if ((long long)(bn_row0 + grid) * 2 * C > bn_cap) return IIF_EINVAL;
+        if (rows_out) *rows_out = bn_row0 + grid;
+    }
+    const unsigned sb = (unsigned)((int64_t)a.M * C * 2);
+    const bool epi = bw_x != nullptr || bw_bits != nullptr;
+    const dim3 g((unsigned)grid), b(256);
+    if (epi) hipLaunchKernelGGL(conv3x3_regw64_kernel<true>, g, b, 0, st, a, sb);
+    else hipLaunchKernelGGL(conv3x3_regw64_kernel<false>, g, b, 0, st, a, sb);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}

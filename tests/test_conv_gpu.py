@@ -355,7 +355,7 @@ def test_conv3x3_fragment_kernel(case, conv_env):
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()                                    # noqa: E731
     krsc = lambda w_: w_.permute(0, 2, 3, 1).reshape(w_.shape[0], -1).contiguous()          # noqa: E731
     xd, wd = nhwc(x).to(DEV), krsc(wt).to(DEV)
-    conv_env(IIF_CONV_V2_FORCE="1")   # small grids are refused otherwise (v2_geometry_ok)
+    conv_env(IIF_CONV_V2_FORCE="1", IIF_CONV_NO_REGW="1")   # small grids are refused otherwise (v2_geometry_ok); this test: fragment vs window kernels
     assert ops.conv3x3_frag_ok(n, h, w, cin, cout, dt) and ops.conv3x3_frag_ok(n, h, w, cout, cin, dt)
     wf = _pack_frag(wd, cout, 9, cin)
     # the layout: fragment (row tile, tap, chunk), lane (row & 15, 8 channels of (lane >> 4))
@@ -375,7 +375,7 @@ def test_conv3x3_fragment_kernel(case, conv_env):
     wtt = krsc(wt.permute(1, 0, 2, 3).contiguous()).to(DEV)
     wtf = _pack_frag(wtt, cin, 9, cout)
     for mode in ("v2", "old"):
-        conv_env(IIF_CONV_NO_V2=None if mode == "v2" else "1", IIF_CONV_HALO_FORCE="1", IIF_CONV_V2_FORCE="1")
+        conv_env(IIF_CONV_NO_V2=None if mode == "v2" else "1", IIF_CONV_HALO_FORCE="1", IIF_CONV_V2_FORCE="1", IIF_CONV_NO_REGW="1")
         out = torch.full((n, h, w, cout), float("nan"), dtype=dt, device=DEV)
         partial = torch.full((((m + 127) // 128) * 2 * cout,), float("nan"), device=DEV)
         nt = ops.conv_forward_bnstats(xd, wd, 3, 3, 1, 1, out, partial, w_frag=wf)
@@ -588,6 +588,55 @@ def test_forward_1x1_weights_in_registers_equals_the_tile_kernel(case, conv_env)
     for _, ps, _ in res:
         assert not torch.isnan(ps).any()
         assert (ps - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("n,hw", [(4, 16), (5, 24), (16, 56), (3, 56), (64, 8), (2, 20)])
+def test_conv3x3_64_channels_weights_in_registers(n, hw, conv_env):
+    """conv_regw.hip, 3x3 / stride 1 / pad 1 over 64 -> 64 channels on 8 x 8 pixel tiles (weights in registers, window through a
+    three-slot LDS ring): forward with batch-norm sums and the data gradient with the upstream BN-backward sums, against fp64
+    references of the same bf16 operands and against the window / tile kernels through the same entry points.  (2, 20): the
+    image side is not a multiple of 8, the other kernels run on both sides."""
+    import torch.nn.functional as F
+    from iif_amd import ops
+    c = 64
+    g = torch.Generator().manual_seed(n * 100 + hw)
+    x = torch.randn(n, hw, hw, c, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5).bfloat16()
+    wk = w.permute(0, 2, 3, 1).reshape(c, 9 * c).contiguous().to(DEV)                   # [cout][r][s][cin]
+    wt = w.permute(1, 2, 3, 0).reshape(c, 9 * c).contiguous().to(DEV)                   # [cin][r][s][cout]: the data gradient's operand
+    upx = torch.randn(n, hw, hw, c, generator=g).bfloat16().to(DEV)
+    bits = torch.randint(0, 256, (n * hw * hw * c // 8,), dtype=torch.uint8, generator=g).to(DEV)
+    stats = torch.zeros(4, c)
+    stats[0] = torch.randn(c, generator=g) * 0.1
+    stats[1] = torch.rand(c, generator=g) + 0.5
+    m = n * hw * hw
+    ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+    refd = F.conv_transpose2d(x.double().cpu().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+    got = {}
+    for off in (False, True):
+        conv_env(IIF_CONV_NO_REGW="1" if off else None)
+        out = torch.full((n, hw, hw, c), float("nan"), dtype=torch.bfloat16, device=DEV)
+        partial = torch.full(((m + 127) // 128 + 8, 2, c), float("nan"), device=DEV)
+        nt = ops.conv_forward_bnstats(x, wk, 3, 3, 1, 1, out, partial.view(-1))
+        dx = torch.full((n, hw, hw, c), float("nan"), dtype=torch.bfloat16, device=DEV)
+        partial2 = torch.full(((m + 127) // 128 + 8, 2, c), float("nan"), device=DEV)
+        nt2 = ops.conv_dgrad_bnbwd(x, wt, 3, 3, 1, 1, (hw, hw), dx, upx, bits, stats.to(DEV), partial2.view(-1))
+        assert nt <= (m + 127) // 128 and nt2 <= (m + 127) // 128
+        assert (out.double().cpu() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+        assert (dx.double().cpu() - refd).abs().max().item() <= 2.0 ** -7 * refd.abs().max().item()
+        flat = out.double().cpu().view(m, c)
+        ps = partial[:nt].double().sum(0).cpu()
+        assert (ps[0] - flat.sum(0)).abs().max().item() <= 1e-6 * flat.abs().sum(0).max().item()
+        assert (ps[1] - (flat * flat).sum(0)).abs().max().item() <= 1e-6 * (flat * flat).sum(0).max().item()
+        gq = dx.double().cpu().view(m, c) * ((bits.cpu().view(-1, 1).int() >> torch.arange(8).view(1, 8)) & 1).view(m, c)
+        xhat = (upx.double().cpu().view(m, c) - stats[0].double()) * stats[1].double()
+        ps2 = partial2[:nt2].double().sum(0).cpu()
+        assert (ps2[0] - gq.sum(0)).abs().max().item() <= 1e-5 * gq.abs().sum(0).max().item()
+        assert (ps2[1] - (gq * xhat).sum(0)).abs().max().item() <= 1e-5 * (gq * xhat).abs().sum(0).max().item()
+        got[off] = (out, dx)
+    # the two routes order the K loop differently (chunk-major here, tap-major in the tile kernels): equal to a bf16 rounding
+    assert (got[False][0].float() - got[True][0].float()).abs().max().item() <= 2.0 ** -6 * ref.abs().max().item()
+    assert (got[False][1].float() - got[True][1].float()).abs().max().item() <= 2.0 ** -6 * refd.abs().max().item()
 
 
 # ------------------------------------------------------------------------------------------- streaming 1x1 kernel
