@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_regw64_kernel(Regw3Args a, uns
     constexpr int NV = 2;                                                       // staged 16-byte vectors per thread and tile
     constexpr int NOPS = EPI ? 2 * NV : 0;                                      // epilogue operand loads per thread and tile
     constexpr unsigned OOB = 0x80000000u;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * SLOT + STG + 4 * 2 * C * 4];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * SLOT + STG + 4 * 2 * C * 4 + 2 * C * 4];
     unsigned char* const stage = smem + NSLOT * SLOT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -421,13 +421,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_regw64_kernel(Regw3Args a, uns
     const unsigned char* const dummy = a.wgt;
     const bool has_bx = EPI && a.bw_x != nullptr, has_bb = EPI && a.bw_bits != nullptr;
     const int vchunk = tid & 7, vrow = tid >> 3;                    // this thread's staged vectors: tile pixels vrow and vrow + 32
-    float bmean[8], bistd[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { bmean[q] = 0.f; bistd[q] = 0.f; }
-    if (has_bx) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[vchunk * 8 + q]; bistd[q] = a.bw_stats[C + vchunk * 8 + q]; }
-    }
+    // the upstream statistics wait in LDS (behind the partial-sum scratch): 16 registers less in a kernel that has none to spare
+    float* const ustat = reinterpret_cast<float*>(stage + STG + 4 * 2 * C * 4);          // [2][C]: mean, invstd
+    if (has_bx && tid < 2 * C) ustat[tid] = a.bw_stats[tid];
     int slot = 0;
     bool first = true;
     for (; tile < tend; tile += per_xcd, slot = slot == NSLOT - 1 ? 0 : slot + 1) {
@@ -492,6 +488,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_regw64_kernel(Regw3Args a, uns
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + vo[i]));
             if (EPI && has_bx) {
                 const unsigned mb = has_bb ? ob[i] : 0xffu;
+                float bmean[8], bistd[8];
+#pragma unroll
+                for (int q = 0; q < 8; q += 4) {
+                    const f32x4 m4 = *reinterpret_cast<const f32x4*>(ustat + vchunk * 8 + q), s4 = *reinterpret_cast<const f32x4*>(ustat + C + vchunk * 8 + q);
+                    bmean[q] = m4.x; bmean[q + 1] = m4.y; bmean[q + 2] = m4.z; bmean[q + 3] = m4.w;
+                    bistd[q] = s4.x; bistd[q + 1] = s4.y; bistd[q + 2] = s4.z; bistd[q + 3] = s4.w;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float glo = (mb >> (2 * q)) & 1u ? bf16_bits_to_f32(v[q] & 0xffffu) : 0.f;
