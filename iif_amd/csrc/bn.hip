@@ -89,17 +89,22 @@ __device__ __forceinline__ void reduce_partials(const float* partial, int nblk, 
     constexpr int LN = 256 / CB;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        // 4 rows in flight per lane (the loads are independent; the sums keep their fixed order)
-        int r = ln;
-        for (; r + 3 * LN < nblk; r += 4 * LN) {
-            const float a0 = partial[(int64_t)r * 2 * C + c], b0 = partial[(int64_t)r * 2 * C + C + c];
-            const float a1 = partial[(int64_t)(r + LN) * 2 * C + c], b1 = partial[(int64_t)(r + LN) * 2 * C + C + c];
-            const float a2 = partial[(int64_t)(r + 2 * LN) * 2 * C + c], b2 = partial[(int64_t)(r + 2 * LN) * 2 * C + C + c];
-            const float a3 = partial[(int64_t)(r + 3 * LN) * 2 * C + c], b3 = partial[(int64_t)(r + 3 * LN) * 2 * C + C + c];
-            a += a0; a += a1; a += a2; a += a3;
-            b += b0; b += b1; b += b2; b += b3;
+        // 16 rows in flight per lane, requested unconditionally from a clamped row and masked afterwards (a conditional or
+        // run-time-counted load is waited for on its own); the sums keep the order of the 4-deep loop: rows ln, ln + LN, ...
+        // Round 4: the register-weight convolutions hand over <= 256 rows, i.e. two round trips here instead of eight.
+        for (int r0 = ln; r0 < nblk; r0 += 16 * LN) {
+            float av[16], bv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = r0 + i * LN;
+                const int64_t o = (int64_t)(rr < nblk ? rr : r0) * 2 * C + c;
+                av[i] = partial[o]; bv[i] = partial[o + C];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (r0 + i * LN < nblk) { a += av[i]; b += bv[i]; }
+            }
         }
-        for (; r < nblk; r += LN) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
     }
     sh[ln * CB + cl] = a; sh[256 + ln * CB + cl] = b;
     __syncthreads();
