@@ -312,25 +312,21 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T*
 // load a dependent round trip costs 3-5 us, so the depth of this chain is what the small reduction launches take
 // (4 in flight: 17 us per launch inside the step).  The order of the additions is the one the 4-deep loop had.
 __device__ __forceinline__ void lane_sums(const float* partial, int C, int c, int r, int r1, double& a, double& b) {
-    for (; r + 56 < r1; r += 64) {
-        float av[8], bv[8];
+    // 16 rows (stride 8) per batch, requested unconditionally from a clamped row and masked afterwards: a slice of <= 128 rows is
+    // ONE round trip (round 3: 8 + 4 + 1 in flight in three loops; a slice of 98 rows took three trips and a serial tail)
+    for (int r0 = r; r0 < r1; r0 += 128) {
+        float av[16], bv[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            av[i] = partial[(int64_t)(r + 8 * i) * 2 * C + c];
-            bv[i] = partial[(int64_t)(r + 8 * i) * 2 * C + C + c];
+        for (int i = 0; i < 16; ++i) {
+            const int rr = r0 + 8 * i;
+            const int64_t o = (int64_t)(rr < r1 ? rr : r0) * 2 * C + c;
+            av[i] = partial[o]; bv[i] = partial[o + C];
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { a += av[i]; b += bv[i]; }
+        for (int i = 0; i < 16; ++i) {
+            if (r0 + 8 * i < r1) { a += av[i]; b += bv[i]; }
+        }
     }
-    for (; r + 24 < r1; r += 32) {
-        const float a0 = partial[(int64_t)r * 2 * C + c], b0 = partial[(int64_t)r * 2 * C + C + c];
-        const float a1 = partial[(int64_t)(r + 8) * 2 * C + c], b1 = partial[(int64_t)(r + 8) * 2 * C + C + c];
-        const float a2 = partial[(int64_t)(r + 16) * 2 * C + c], b2 = partial[(int64_t)(r + 16) * 2 * C + C + c];
-        const float a3 = partial[(int64_t)(r + 24) * 2 * C + c], b3 = partial[(int64_t)(r + 24) * 2 * C + C + c];
-        a += a0; a += a1; a += a2; a += a3;
-        b += b0; b += b1; b += b2; b += b3;
-    }
-    for (; r < r1; r += 8) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
 }
 
 // Stage 1 for many partial rows: slice `blockIdx.y` of the rows is summed (double, fixed order) by 32 channels
@@ -375,6 +371,13 @@ __global__ void __launch_bounds__(256) bn_reduce_finalize_kernel(const float* pa
     const int r0 = blockIdx.y * rows_per_slice;
     int r1 = r0 + rows_per_slice; if (r1 > nblk) r1 = nblk;
     double a = 0.0, b = 0.0;
+    // what the finishing block needs besides the sums travels with the first batch of loads, not in a round trip of its own
+    float pre_ga = 0.f, pre_b = 0.f, pre_rm = 0.f, pre_rv = 0.f;
+    if (ln == 0 && c < C) {
+        pre_ga = gamma[c];
+        pre_b = MODE == 0 ? beta_or_stats[c] : beta_or_stats[C + c];
+        if (MODE == 0 && o1) { pre_rm = o1[c]; pre_rv = o2[c]; }
+    }
     if (c < C) {
         lane_sums(partial, C, c, r0 + ln, r1, a, b);
     }
@@ -429,16 +432,16 @@ __global__ void __launch_bounds__(256) bn_reduce_finalize_kernel(const float* pa
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float ga = gamma[c], be = beta_or_stats[c];
+        const float ga = pre_ga, be = pre_b;
         const float k = ga * invstd;
         o0[c] = (float)mean; o0[C + c] = invstd; o0[2 * C + c] = k; o0[3 * C + c] = be - (float)mean * k;
         if (o1) {
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            o1[c] = (1.f - momentum) * o1[c] + momentum * (float)mean;
-            o2[c] = (1.f - momentum) * o2[c] + momentum * (float)unbiased;
+            o1[c] = (1.f - momentum) * pre_rm + momentum * (float)mean;
+            o2[c] = (1.f - momentum) * pre_rv + momentum * (float)unbiased;
         }
     } else {                                            // o0 = dgamma, o1 = dbeta, o2 = coef[3][C]
-        const float ga = gamma[c], invstd = beta_or_stats[C + c];
+        const float ga = pre_ga, invstd = pre_b;
         o0[c] = (float)q;
         o1[c] = (float)s;
         o2[c] = ga * invstd;
