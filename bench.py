@@ -240,7 +240,7 @@ def profiled_traffic():
                 step_mb += float(row[4])
             except ValueError:
                 continue
-            if any(t in row[0] for t in ("conv_igemm", "conv_wgrad", "conv3x3_", "conv4x4_", "gemm1x1_stream")):
+            if any(t in row[0] for t in ("conv_igemm", "conv_wgrad", "conv3x3_", "conv4x4_", "gemm1x1_", "wgrad1x1_", "stem4x4")):
                 mb += float(row[4]); launches += float(row[1])
     if launches <= 0:
         return None
