@@ -87,7 +87,7 @@ SIGNATURES = {
     "iif_fasa_generate": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "iif_conv_igemm_dgrad_bnbwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "iif_bn_backward_partials": [_P, _P, _P, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P],
-    "iif_maxpool_bn_forward": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "iif_maxpool_bn_forward": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "iif_bn_backward_relu_recompute": [_P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _L, _P],
     "iif_bn_backward_relu_recompute_pooled": [_P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P],
     "iif_rowmap_forward": [_P, _I, _I, _I, _L, _I, _F, _F, _P, _I, _L, _P, _P],

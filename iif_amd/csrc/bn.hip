@@ -149,15 +149,20 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partial, 
 
 // relu_bits (nullable): one byte per channel vector, bit k = [pre-activation k > 0].  The backward passes read
 // this byte instead of the 16-byte activated vector: 1/16 of the mask traffic.
-template <typename T, bool RELU, int RES>   // RES 0: none, 1: + r, 2: + a2*r + b2
+// Loop form (round 5, scripts/micro/stream_rw.hip: this pass's shape on 411 MB tensors): a resident grid striding over the
+// tensor one vector per trip ran at 5.4 TB/s - the stores of blocks that have drifted apart land in DRAM pages 16 MB apart
+// (a write-only sweep of the same form: 4.2 TB/s at 4 096 blocks, 6.1 at 16 384); ONE trip per thread over U vectors 256 apart
+// (the same channel vector, so the coefficients are still loaded once), every load requested before the first use,
+// non-temporal loads and stores: 6.6 TB/s.  The grid is as large as the tensor; IIF_BN_GRID_CAP brings the loop back.
+template <typename T, bool RELU, int RES, int U, bool NTS>   // RES 0: none, 1: + r, 2: + a2*r + b2
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* x, const float* stats, const T* r, const float* stats2,
                                                        T* y, int64_t total_vec, int cv, int C, unsigned char* relu_bits) {
     constexpr int V = VT<T>::V;
-    // cv divides the grid stride (host guarantees it when cv divides 256): a thread keeps ONE channel vector for all
-    // its rows, so the 2 x V (4 x V with a normalised residual) coefficients are loaded once, not per 16-byte vector
+    // cv divides 256: a thread keeps ONE channel vector for all its vectors (a block's trips start 256 U apart), so the
+    // 2 x V (4 x V with a normalised residual) coefficients are loaded once, not per 16-byte vector
     const bool fixed = (256 % cv) == 0;
     float ca[V], cb[V], ra[V], rb[V];
-    int c0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cv) * V;
+    int c0 = (int)(threadIdx.x % cv) * V;
     if (fixed) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -165,29 +170,42 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* x, const float* 
             if (RES == 2) { ra[k] = stats2[2 * C + c0 + k]; rb[k] = stats2[3 * C + c0 + k]; }
         }
     }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
-        if (!fixed) {
-            c0 = (int)(i % cv) * V;
+    for (int64_t base = (int64_t)blockIdx.x * (256 * U) + threadIdx.x; base < total_vec; base += (int64_t)gridDim.x * (256 * U)) {
+        u32x4 xr[U], rr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                     // (a vector past the end reads the trip's first one again)
+            const int64_t i = base + 256 * u < total_vec ? base + 256 * u : base;
+            xr[u] = VT<T>::raw_nt(x + i * V);
+            if (RES) rr[u] = VT<T>::raw_nt(r + i * V);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + 256 * u;
+            if (!fixed) {
+                c0 = (int)(i % cv) * V;
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    ca[k] = stats[2 * C + c0 + k]; cb[k] = stats[3 * C + c0 + k];
+                    if (RES == 2) { ra[k] = stats2[2 * C + c0 + k]; rb[k] = stats2[3 * C + c0 + k]; }
+                }
+            }
+            float v[V], w[V];
+            VT<T>::unpack(xr[u], v);
+            if (RES) VT<T>::unpack(rr[u], w);
+            unsigned bits = 0;
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-                ca[k] = stats[2 * C + c0 + k]; cb[k] = stats[3 * C + c0 + k];
-                if (RES == 2) { ra[k] = stats2[2 * C + c0 + k]; rb[k] = stats2[3 * C + c0 + k]; }
+                float t = fmaf(ca[k], v[k], cb[k]);   // one rounding, as vec fmadd
+                if (RES == 1) t += w[k];
+                if (RES == 2) t += fmaf(ra[k], w[k], rb[k]);
+                bits |= (t > 0.f ? 1u : 0u) << k;
+                v[k] = RELU ? fmaxf(t, 0.f) : t;
+            }
+            if (i < total_vec) {
+                VT<T>::template store_as<NTS>(y + i * V, v);
+                if (RELU && relu_bits) relu_bits[i] = (unsigned char)bits;
             }
         }
-        float v[V], w[V];
-        VT<T>::load_nt(x + i * V, v);
-        if (RES) VT<T>::load_nt(r + i * V, w);
-        unsigned bits = 0;
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            float t = fmaf(ca[k], v[k], cb[k]);   // one rounding, as vec fmadd
-            if (RES == 1) t += w[k];
-            if (RES == 2) t += fmaf(ra[k], w[k], rb[k]);
-            bits |= (t > 0.f ? 1u : 0u) << k;
-            v[k] = RELU ? fmaxf(t, 0.f) : t;
-        }
-        VT<T>::store(y + i * V, v);
-        if (RELU && relu_bits) relu_bits[i] = (unsigned char)bits;
     }
 }
 
@@ -265,14 +283,14 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* parti
     coef[2 * C + c] = (float)(s2 / count) * invstd;
 }
 
-template <typename T, int MASK, bool GMOUT>
+template <typename T, int MASK, bool GMOUT, int U, bool NTS>      // (loop form: see bn_apply_kernel)
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T* ymask, const unsigned char* bits, const T* x,
                                                            const float* stats, const float* coef, T* dx, T* gm,
                                                            int64_t total_vec, int cv, int C) {
     constexpr int V = VT<T>::V;
     const bool fixed = (256 % cv) == 0;          // see bn_apply_kernel: one channel vector per thread
     float k1[V], k2[V], k3[V], mu[V], aa[V], bb[V];
-    int c0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cv) * V;
+    int c0 = (int)(threadIdx.x % cv) * V;
     if (fixed) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -280,31 +298,46 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T*
             if (MASK == 3) { aa[k] = stats[2 * C + c0 + k]; bb[k] = stats[3 * C + c0 + k]; }
         }
     }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
-        if (!fixed) {
-            c0 = (int)(i % cv) * V;
+    for (int64_t base = (int64_t)blockIdx.x * (256 * U) + threadIdx.x; base < total_vec; base += (int64_t)gridDim.x * (256 * U)) {
+        u32x4 gr[U], xr[U], yr[U];
+        unsigned mbv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                     // in place (dx == g_) is fine: a thread reads all its vectors before it writes any
+            const int64_t i = base + 256 * u < total_vec ? base + 256 * u : base;
+            gr[u] = VT<T>::raw_nt(g_ + i * V);
+            xr[u] = VT<T>::raw_nt(x + i * V);
+            if (MASK == 1) yr[u] = VT<T>::raw(ymask + i * V);
+            mbv[u] = MASK == 2 ? bits[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + 256 * u;
+            if (!fixed) {
+                c0 = (int)(i % cv) * V;
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    k1[k] = coef[c0 + k]; k2[k] = coef[C + c0 + k]; k3[k] = coef[2 * C + c0 + k]; mu[k] = stats[c0 + k];
+                    if (MASK == 3) { aa[k] = stats[2 * C + c0 + k]; bb[k] = stats[3 * C + c0 + k]; }
+                }
+            }
+            float dy[V], xv[V], yv[V];
+            VT<T>::unpack(gr[u], dy);
+            VT<T>::unpack(xr[u], xv);
+            if (MASK == 1) VT<T>::unpack(yr[u], yv);
+            const unsigned mb = mbv[u];
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-                k1[k] = coef[c0 + k]; k2[k] = coef[C + c0 + k]; k3[k] = coef[2 * C + c0 + k]; mu[k] = stats[c0 + k];
-                if (MASK == 3) { aa[k] = stats[2 * C + c0 + k]; bb[k] = stats[3 * C + c0 + k]; }
+                const bool on = MASK == 0 ? true : (MASK == 1 ? yv[k] > 0.f : (MASK == 2 ? ((mb >> k) & 1u) != 0
+                                                                                                : fmaf(aa[k], xv[k], bb[k]) > 0.f));
+                const float d = on ? dy[k] : 0.f;
+                dy[k] = d;
+                xv[k] = k1[k] * (d - k2[k] - (xv[k] - mu[k]) * k3[k]);
+            }
+            if (i < total_vec) {
+                VT<T>::template store_as<NTS>(dx + i * V, xv);
+                if (GMOUT) VT<T>::template store_as<false>(gm + i * V, dy);
             }
         }
-        float dy[V], xv[V], yv[V];
-        VT<T>::load_nt(g_ + i * V, dy);
-        VT<T>::load_nt(x + i * V, xv);
-        if (MASK == 1) VT<T>::load(ymask + i * V, yv);
-        unsigned mb = 0;
-        if (MASK == 2) mb = bits[i];
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const bool on = MASK == 0 ? true : (MASK == 1 ? yv[k] > 0.f : (MASK == 2 ? ((mb >> k) & 1u) != 0
-                                                                                            : fmaf(aa[k], xv[k], bb[k]) > 0.f));
-            const float d = on ? dy[k] : 0.f;
-            dy[k] = d;
-            xv[k] = k1[k] * (d - k2[k] - (xv[k] - mu[k]) * k3[k]);
-        }
-        VT<T>::store(dx + i * V, xv);
-        if (GMOUT) VT<T>::store(gm + i * V, dy);
     }
 }
 
@@ -478,10 +511,17 @@ inline int launch_bn_finalize(const float* partial, int nblk, int C, double coun
     return IIF_OK;
 }
 
-inline int stream_blocks(int64_t total_vec) {
-    constexpr int cap = 4096;
-    const int64_t b = (total_vec + 255) / 256;
-    return (int)(b < cap ? b : cap);
+// grid of the two normalisation passes: one trip per thread over U vectors (U = 4 where that still leaves >= 2 048 blocks);
+// IIF_BN_GRID_CAP=<blocks> caps the grid (the kernels then loop), IIF_BN_PLAIN_STORES=1 turns the non-temporal stores off
+struct StreamGrid { int blocks, u; bool nts; };
+inline StreamGrid stream_grid(int64_t total_vec) {
+    static const int64_t cap = [] { const char* e = getenv("IIF_BN_GRID_CAP"); return e ? atoll(e) : (1LL << 30); }();
+    static const bool nts = getenv("IIF_BN_PLAIN_STORES") == nullptr;
+    static const int umax = [] { const char* e = getenv("IIF_BN_UNROLL"); return e ? atoi(e) : 4; }();
+    int u = total_vec >= (int64_t)4 * 256 * 2048 ? 4 : (total_vec >= (int64_t)2 * 256 * 2048 ? 2 : 1);
+    if (u > umax) u = umax;
+    const int64_t b = (total_vec + 256 * u - 1) / (256 * u);
+    return StreamGrid{(int)(b < cap ? b : cap), u, nts};
 }
 
 template <typename T>
@@ -501,12 +541,17 @@ int bn_apply_t(const T* x, const float* stats, const T* r, const float* stats2, 
     constexpr int V = VT<T>::V;
     const int cv = C / V;
     const int64_t tv = M * cv;
-    const dim3 grid(stream_blocks(tv)), blk(256);
+    const StreamGrid sg = stream_grid(tv);
+    const dim3 grid(sg.blocks), blk(256);
     const int res = r ? (stats2 ? 2 : 1) : 0;
-#define IIF_APPLY(RL, RS) hipLaunchKernelGGL((bn_apply_kernel<T, RL, RS>), grid, blk, 0, st, x, stats, r, stats2, y, tv, cv, C, relu_bits)
+#define IIF_APPLY3(RL, RS, UU, NT) hipLaunchKernelGGL((bn_apply_kernel<T, RL, RS, UU, NT>), grid, blk, 0, st, x, stats, r, stats2, y, tv, cv, C, relu_bits)
+#define IIF_APPLY2(RL, RS, UU) do { if (sg.nts) IIF_APPLY3(RL, RS, UU, true); else IIF_APPLY3(RL, RS, UU, false); } while (0)
+#define IIF_APPLY(RL, RS) do { if (sg.u == 4) IIF_APPLY2(RL, RS, 4); else if (sg.u == 2) IIF_APPLY2(RL, RS, 2); else IIF_APPLY2(RL, RS, 1); } while (0)
     if (relu) { if (res == 0) IIF_APPLY(true, 0); else if (res == 1) IIF_APPLY(true, 1); else IIF_APPLY(true, 2); }
     else { if (res == 0) IIF_APPLY(false, 0); else if (res == 1) IIF_APPLY(false, 1); else IIF_APPLY(false, 2); }
 #undef IIF_APPLY
+#undef IIF_APPLY2
+#undef IIF_APPLY3
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }
@@ -561,13 +606,18 @@ int bn_backward_t(const T* gy, const T* ymask, const unsigned char* bits, const 
     IIF_LAUNCH_CHECK();
     const int cv = C / V;
     const int64_t tv = M * cv;
-    const dim3 agrid(stream_blocks(tv));
-#define IIF_BAPPLY(MK, GO) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MK, GO>), agrid, blk, 0, st, gy, ymask, bits, x, stats, coef, dx, gm, tv, cv, C)
+    const StreamGrid sg = stream_grid(tv);
+    const dim3 agrid(sg.blocks);
+#define IIF_BAPPLY3(MK, GO, UU, NT) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MK, GO, UU, NT>), agrid, blk, 0, st, gy, ymask, bits, x, stats, coef, dx, gm, tv, cv, C)
+#define IIF_BAPPLY2(MK, GO, UU) do { if (sg.nts) IIF_BAPPLY3(MK, GO, UU, true); else IIF_BAPPLY3(MK, GO, UU, false); } while (0)
+#define IIF_BAPPLY(MK, GO) do { if (sg.u == 4) IIF_BAPPLY2(MK, GO, 4); else if (sg.u == 2) IIF_BAPPLY2(MK, GO, 2); else IIF_BAPPLY2(MK, GO, 1); } while (0)
     if (recompute) { if (gm) IIF_BAPPLY(3, true); else IIF_BAPPLY(3, false); }
     else if (bits) { if (gm) IIF_BAPPLY(2, true); else IIF_BAPPLY(2, false); }
     else if (ymask) { if (gm) IIF_BAPPLY(1, true); else IIF_BAPPLY(1, false); }
     else { if (gm) IIF_BAPPLY(0, true); else IIF_BAPPLY(0, false); }
 #undef IIF_BAPPLY
+#undef IIF_BAPPLY2
+#undef IIF_BAPPLY3
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }
@@ -632,43 +682,45 @@ int bn_backward_apply_sums_t(const T* gy, const T* ymask, const unsigned char* b
     IIF_LAUNCH_CHECK();
     const int cv = C / V;
     const int64_t tv = M * cv;
-    const dim3 agrid(stream_blocks(tv));
-#define IIF_BAPPLY(MK, GO) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MK, GO>), agrid, blk, 0, st, gy, ymask, bits, x, stats, coef, dx, gm, tv, cv, C)
+    const StreamGrid sg = stream_grid(tv);
+    const dim3 agrid(sg.blocks);
+#define IIF_BAPPLY3(MK, GO, UU, NT) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MK, GO, UU, NT>), agrid, blk, 0, st, gy, ymask, bits, x, stats, coef, dx, gm, tv, cv, C)
+#define IIF_BAPPLY2(MK, GO, UU) do { if (sg.nts) IIF_BAPPLY3(MK, GO, UU, true); else IIF_BAPPLY3(MK, GO, UU, false); } while (0)
+#define IIF_BAPPLY(MK, GO) do { if (sg.u == 4) IIF_BAPPLY2(MK, GO, 4); else if (sg.u == 2) IIF_BAPPLY2(MK, GO, 2); else IIF_BAPPLY2(MK, GO, 1); } while (0)
     if (bits) { if (gm) IIF_BAPPLY(2, true); else IIF_BAPPLY(2, false); }
     else if (ymask) { if (gm) IIF_BAPPLY(1, true); else IIF_BAPPLY(1, false); }
     else { if (gm) IIF_BAPPLY(0, true); else IIF_BAPPLY(0, false); }
 #undef IIF_BAPPLY
+#undef IIF_BAPPLY2
+#undef IIF_BAPPLY3
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// BN-backward sums of the stem (bn1 -> relu -> 3x3/2 max pool, resnet_pytorch.py:284-287) from the POOLED tensors.
+// BN-backward sums of the stem (bn1 -> relu -> 3x3/2 max pool, resnet_pytorch.py:284-287) from POOLED tensors.
 // The gradient of the stem's BN output is the pooled gradient scattered to the arg-max positions, gated by the ReLU; its
 // column sums do not care where an element lands:
-//     sum g      = sum over pooled elements of gp [out > 0]
-//     sum g xhat = sum over pooled elements of gp [out > 0] xhat(arg max),   xhat = ((out - b) / a - mean) invstd   (out = relu(a x + b) > 0)
+//     sum g      = sum over pooled elements of gp [a x* + b > 0]
+//     sum g xhat = sum over pooled elements of gp [a x* + b > 0] (x* - mean) invstd,      x* = the RAW stem output at the arg max
 // so the reduction pass over the 4x larger scattered gradient AND the stem output (822 MB, 190 us at batch 256) becomes a pass
-// over two pooled tensors (206 MB).  xhat comes back from the stored pooled value: out carries one rounding of the storage
-// type (2^-9 relative in bf16, the same size as the rounding of the stored x the standard pass starts from).  A channel
-// whose scale a is (numerically) zero has no ReLU-open elements worth speaking of: its second sum is taken as 0.
+// over two pooled tensors (206 MB).  x* is stored by the fused forward pool (iif_maxpool_bn_forward, pool_x: +103 MB written
+// per step) - round 4 recovered xhat from the pooled ACTIVATION instead, xhat = ((out - b) / a - mean) invstd, whose error is
+// 2^-9 |xhat + beta / gamma|: noise for a channel with a small gain against its shift (round-4 advice).  With x* every term
+// is the term of the standard pass (same mask test, same (x - mean) * invstd), only the order of the additions differs.
 // One partial row [2][C] per block, fixed order: deterministic.  Grid <= 512 blocks (bn_backward_t's one-stage finalisation).
 template <typename T>
-__global__ void __launch_bounds__(256) pool_bwd_sums_kernel(const T* gp, const T* out, const float* stats, int64_t npix, int C,
+__global__ void __launch_bounds__(256) pool_bwd_sums_kernel(const T* gp, const T* px, const float* stats, int64_t npix, int C,
                                                             int64_t pix_per_block, float* partial) {
     constexpr int V = VT<T>::V;
     __shared__ float sh[2][256][V + 1];
     const int cv = C / V;                                 // channel vectors per pixel (host: 256 % cv == 0)
     const int vec = threadIdx.x % cv, pl = threadIdx.x / cv, ppb = 256 / cv;
     const int c0 = vec * V;
-    // xhat = (x - mean) invstd with x = (out - b) / a:  xhat = out * k1 + k0,  k1 = invstd / a,  k0 = -(b / a + mean) invstd
-    float k1[V], k0[V];
+    float aa[V], bb[V], mean[V], istd[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
-        const float a = stats[2 * C + c0 + q], bb = stats[3 * C + c0 + q], mean = stats[c0 + q], invstd = stats[C + c0 + q];
-        const float ia = fabsf(a) > 1e-20f ? 1.0f / a : 0.f;
-        k1[q] = invstd * ia;
-        k0[q] = ia != 0.f ? -(bb * ia + mean) * invstd : 0.f;
+        aa[q] = stats[2 * C + c0 + q]; bb[q] = stats[3 * C + c0 + q]; mean[q] = stats[c0 + q]; istd[q] = stats[C + c0 + q];
     }
     float s1[V], s2[V];
 #pragma unroll
@@ -676,17 +728,17 @@ __global__ void __launch_bounds__(256) pool_bwd_sums_kernel(const T* gp, const T
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     int64_t p1 = p0 + pix_per_block; if (p1 > npix) p1 = npix;
     for (int64_t p = p0 + pl; p < p1; p += 2 * ppb) {     // two pixels in flight per thread
-        float g0[V], o0[V], g1[V], o1[V];
+        float g0[V], x0[V], g1[V], x1[V];
         const bool two = p + ppb < p1;
         const int64_t pb = two ? p + ppb : p;
-        VT<T>::load_nt(gp + p * C + c0, g0); VT<T>::load_nt(out + p * C + c0, o0);
-        VT<T>::load_nt(gp + pb * C + c0, g1); VT<T>::load_nt(out + pb * C + c0, o1);
+        VT<T>::load_nt(gp + p * C + c0, g0); VT<T>::load_nt(px + p * C + c0, x0);
+        VT<T>::load_nt(gp + pb * C + c0, g1); VT<T>::load_nt(px + pb * C + c0, x1);
 #pragma unroll
-        for (int q = 0; q < V; ++q) {
-            const float ga = o0[q] > 0.f ? g0[q] : 0.f;
-            s1[q] += ga; s2[q] = fmaf(ga, fmaf(o0[q], k1[q], k0[q]), s2[q]);
-            const float gb = (two && o1[q] > 0.f) ? g1[q] : 0.f;
-            s1[q] += gb; s2[q] = fmaf(gb, fmaf(o1[q], k1[q], k0[q]), s2[q]);
+        for (int q = 0; q < V; ++q) {                     // mask and xhat exactly as bn_bwd_reduce_kernel<T, 3> forms them
+            const float ga = fmaf(aa[q], x0[q], bb[q]) > 0.f ? g0[q] : 0.f;
+            s1[q] += ga; s2[q] += ga * ((x0[q] - mean[q]) * istd[q]);
+            const float gb = (two && fmaf(aa[q], x1[q], bb[q]) > 0.f) ? g1[q] : 0.f;
+            s1[q] += gb; s2[q] += gb * ((x1[q] - mean[q]) * istd[q]);
         }
     }
 #pragma unroll
@@ -817,12 +869,12 @@ int iif_bn_backward_relu_recompute(const void* gy, const void* x, int dtype, int
 
 int iif_bn_backward_relu_recompute_pooled(const void* gy, const void* x, int dtype, int64_t m, int c, const float* stats,
                                           const float* gamma, float* dgamma, float* dbeta, void* dx, void* workspace,
-                                          int64_t workspace_bytes, const void* g_pool, const void* pool_out, int64_t pool_pixels,
+                                          int64_t workspace_bytes, const void* g_pool, const void* pool_x, int64_t pool_pixels,
                                           void* stream) {
-    if (!gy || !x || !stats || !gamma || !dgamma || !dbeta || !dx || !workspace || !g_pool || !pool_out || m <= 0 || c <= 0 ||
+    if (!gy || !x || !stats || !gamma || !dgamma || !dbeta || !dx || !workspace || !g_pool || !pool_x || m <= 0 || c <= 0 ||
         pool_pixels <= 0)
         return IIF_EINVAL;
-    if (m > 0x7fffff00LL || bad_align(gy) || bad_align(x) || bad_align(dx) || bad_align(g_pool) || bad_align(pool_out)) return IIF_EUNSUPPORTED;
+    if (m > 0x7fffff00LL || bad_align(gy) || bad_align(x) || bad_align(dx) || bad_align(g_pool) || bad_align(pool_x)) return IIF_EUNSUPPORTED;
     const int v = dtype == IIF_F32 ? 4 : 8;
     if ((dtype != IIF_F32 && dtype != IIF_BF16) || c % v || 256 % (c / v) || 2 * c > 256) return IIF_EUNSUPPORTED;
     int nblk = (int)(pool_pixels / 64 < 512 ? (pool_pixels + 63) / 64 : 512);
@@ -836,14 +888,14 @@ int iif_bn_backward_relu_recompute_pooled(const void* gy, const void* x, int dty
     workspace_bytes = (workspace_bytes - row_bytes) / 16 * 16;
     hipStream_t st = as_stream(stream);
     if (dtype == IIF_F32) {
-        hipLaunchKernelGGL(pool_bwd_sums_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)g_pool, (const float*)pool_out, stats,
+        hipLaunchKernelGGL(pool_bwd_sums_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)g_pool, (const float*)pool_x, stats,
                            pool_pixels, c, ppb, rows);
         IIF_LAUNCH_CHECK();
         return bn_backward_t<float>((const float*)gy, nullptr, nullptr, (const float*)x, stats, gamma, m, c, dgamma, dbeta, (float*)dx, nullptr,
                                     ws, workspace_bytes, st, rows, nblk, true);
     }
     hipLaunchKernelGGL(pool_bwd_sums_kernel<unsigned short>, dim3(nblk), dim3(256), 0, st, (const unsigned short*)g_pool,
-                       (const unsigned short*)pool_out, stats, pool_pixels, c, ppb, rows);
+                       (const unsigned short*)pool_x, stats, pool_pixels, c, ppb, rows);
     IIF_LAUNCH_CHECK();
     return bn_backward_t<unsigned short>((const unsigned short*)gy, nullptr, nullptr, (const unsigned short*)x, stats, gamma, m, c, dgamma,
                                          dbeta, (unsigned short*)dx, nullptr, ws, workspace_bytes, st, rows, nblk, true);

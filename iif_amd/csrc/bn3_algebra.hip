@@ -24,56 +24,6 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
-// 64 x 64 output tile (4 x 4 per thread) of  Out[r][q] = sum_k L(r, k) R(k, q),  k staged through LDS 32 at a time.
-// LF(row, k) / RF(k, col) return 0 outside the problem.  After every staged chunk `each(k0)` runs with the chunk still in LDS
-// (rs[k][col] = R(k0 + k, q0 + col)).
-constexpr int kTP = 68;                                  // LDS row pitch in floats: 16-byte aligned rows, conflict-free float4 reads
-template <typename LF, typename RF, typename EF>
-__device__ __forceinline__ void tile_gemm64(int kbeg, int K, LF lf, RF rf, EF each, float (&acc)[4][4], float (*ls)[kTP],
-                                            float (*rs)[kTP]) {
-    const int tj = (threadIdx.x >> 4) * 4, ti = (threadIdx.x & 15) * 4;
-#pragma unroll
-    for (int a_ = 0; a_ < 4; ++a_)
-#pragma unroll
-        for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] = 0.f;
-    for (int k0 = kbeg; k0 < K; k0 += 64) {
-        // TWO chunks' loads in flight before the first LDS write: on a loaded memory system a round trip costs 3-5 us and the
-        // arithmetic of a chunk 0.5 us, so the depth of the dependent chain is what a launch takes
-        float lv[2][8], rv[2][8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int q = threadIdx.x + t * 256;
-                lv[h][t] = lf(q & 63, k0 + 32 * h + (q >> 6));      // (lf / rf return 0 past K)
-                rv[h][t] = rf(k0 + 32 * h + (q >> 6), q & 63);
-            }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (k0 + 32 * h >= K) break;
-            __syncthreads();                             // the previous chunk has been consumed
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int q = threadIdx.x + t * 256;
-                ls[q >> 6][q & 63] = lv[h][t];
-                rs[q >> 6][q & 63] = rv[h][t];
-            }
-            __syncthreads();
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) {
-                const float4 l4 = *reinterpret_cast<const float4*>(&ls[r][tj]);
-                const float4 r4 = *reinterpret_cast<const float4*>(&rs[r][ti]);
-                const float l_[4] = {l4.x, l4.y, l4.z, l4.w}, r_[4] = {r4.x, r4.y, r4.z, r4.w};
-#pragma unroll
-                for (int a_ = 0; a_ < 4; ++a_)
-#pragma unroll
-                    for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] += l_[a_] * r_[b_];
-            }
-            each(k0 + 32 * h);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Everything between the producer's partial rows and the stacked-weights data gradient in ONE launch (+ the slab sum below):
 // round 3 ran four dependent launches here (slice sums, coefficients, c x c products, slab sum: 50-90 us per block inside the
@@ -95,6 +45,12 @@ __device__ __forceinline__ s16x4 tr_read_lds(const unsigned char* p) {       // 
 __device__ __forceinline__ void lds_fence() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+}
+// halves of a fragment stay separate values until they are joined BEHIND the fence (TrPair / tr_join in conv_wgrad.hip)
+struct TrPair { s16x4 lo, hi; };
+__device__ __forceinline__ s16x8 tr_join(TrPair& p) {
+    asm volatile("" : "+v"(p.lo), "+v"(p.hi));
+    return s16x8{p.lo.x, p.lo.y, p.lo.z, p.lo.w, p.hi.x, p.hi.y, p.hi.z, p.hi.w};
 }
 // byte offset of logical byte column colb of row `row` in a [rows][rb] tile: conflict-free for the transposing reads
 __device__ __forceinline__ int swz_addr(int row, int colb, int rb) {
@@ -269,22 +225,23 @@ __global__ void __launch_bounds__(256) bn3_prep_kernel(const float* P, int ldp, 
         float* const out = slab + (int64_t)g * c * c;
         constexpr int nb = c / 16;
         for (int ib = wv; ib < nb; ib += 4) {
-            s16x8 af[2];
+            TrPair ap[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const s16x4 lo = tr_read_lds(WT + swz_addr(kb * 32 + 4 * gq + q, (ib * 16 + 4 * pp) * 2, rb));
-                const s16x4 hi = tr_read_lds(WT + swz_addr(kb * 32 + 16 + 4 * gq + q, (ib * 16 + 4 * pp) * 2, rb));
-                af[kb] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                ap[kb].lo = tr_read_lds(WT + swz_addr(kb * 32 + 4 * gq + q, (ib * 16 + 4 * pp) * 2, rb));
+                ap[kb].hi = tr_read_lds(WT + swz_addr(kb * 32 + 16 + 4 * gq + q, (ib * 16 + 4 * pp) * 2, rb));
             }
+            lds_fence();
+            const s16x8 af[2] = {tr_join(ap[0]), tr_join(ap[1])};
             for (int jb = 0; jb < nb; ++jb) {
-                s16x8 bf[2];
+                TrPair bp[2];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    const s16x4 lo = tr_read_lds(BT + swz_addr(kb * 32 + 4 * gq + q, (jb * 16 + 4 * pp) * 2, rb));
-                    const s16x4 hi = tr_read_lds(BT + swz_addr(kb * 32 + 16 + 4 * gq + q, (jb * 16 + 4 * pp) * 2, rb));
-                    bf[kb] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    bp[kb].lo = tr_read_lds(BT + swz_addr(kb * 32 + 4 * gq + q, (jb * 16 + 4 * pp) * 2, rb));
+                    bp[kb].hi = tr_read_lds(BT + swz_addr(kb * 32 + 16 + 4 * gq + q, (jb * 16 + 4 * pp) * 2, rb));
                 }
                 lds_fence();
+                const s16x8 bf[2] = {tr_join(bp[0]), tr_join(bp[1])};
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[0]), __builtin_bit_cast(bf16x8, bf[0]), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[1]), __builtin_bit_cast(bf16x8, bf[1]), acc, 0, 0, 0);
@@ -317,29 +274,80 @@ __global__ void __launch_bounds__(256) bn3_gm_finish_kernel(const float* slab, c
     if (q < c) bias[q] = sb;
 }
 
-// dW[ch][j] = A P[ch][j] + B sum_i W[ch][i] Gram[i][j] + D csum[j].  Grid (C / 64, c / 64).
+// dW[ch][j] = A P[ch][j] + B sum_i W[ch][i] Gram[i][j] + D csum[j].  Grid (C / 64, c / 32); c in {64, 128, 256}.
+// Round 4's form staged K through LDS 64 at a time with element-wise global loads (a lane per matrix ROW: 64 lines per wave
+// instruction) - four dependent memory round trips for a few MFLOP, 39 us alone and 13 launches per step on the weight-gradient
+// stream.  Here a block requests EVERYTHING it will read before it waits once: its 64 x c tile of W (16 bytes per lane along
+// the rows), the c x 32 panel of Gram, its P values, coefficients and column sums; both operands go to LDS as they are (W rows
+// with a pitch of c + 8 halves: the four row groups of a wave read four different bank quarters), and a thread multiplies
+// 4 channels x 2 columns four k at a time (one 8-byte read per row, one per Gram row).  Same order of additions as before (i
+// ascending, one multiply and one add per term): bit-identical values.
+template <int c>
 __global__ void __launch_bounds__(256) bn3_dw_kernel(const float* P, int ldp, const unsigned short* W, int ldw, const float* gram,
-                                                     int ldg, const float* csum, const float* coef, int C, int c, float* dW,
-                                                     int lddw) {
-    __shared__ __attribute__((aligned(16))) float ls[32][kTP], rs[32][kTP];
-    const int ch0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
-    float acc[4][4];
-    tile_gemm64(
-        0, c,
-        [&](int row, int i) { return (ch0 + row < C && i < c) ? bf16_bits_to_f32(W[(int64_t)(ch0 + row) * ldw + i]) : 0.f; },
-        [&](int i, int col) { return (i < c && j0 + col < c) ? gram[(int64_t)i * ldg + j0 + col] : 0.f; },
-        [](int) {}, acc, ls, rs);
-    const int tj = (threadIdx.x >> 4) * 4, ti = (threadIdx.x & 15) * 4;
+                                                     int ldg, const float* csum, const float* coef, int C, float* dW, int lddw) {
+    constexpr int WP = c + 8;                             // W tile pitch in halves
+    constexpr int CPR = c / 8;                            // 16-byte pieces per W row
+    constexpr int NW = 64 * CPR / 256;                    // pieces per thread: 2 / 4 / 8
+    constexpr int NG = c * 8 / 256;                       // Gram panel (c rows x 128 bytes): 2 / 4 / 8 pieces per thread
+    __shared__ __attribute__((aligned(16))) unsigned short wsm[64 * WP];
+    __shared__ __attribute__((aligned(16))) float gsm[c * 32];
+    const int t = threadIdx.x, ch0 = blockIdx.x * 64, j0 = blockIdx.y * 32;
+    u32x4 wv[NW], gv[NG];
 #pragma unroll
-    for (int a_ = 0; a_ < 4; ++a_) {
-        const int ch = ch0 + tj + a_;
-        if (ch >= C) continue;
-        const float A = coef[ch], B = coef[C + ch], D = coef[2 * C + ch];
+    for (int p = 0; p < NW; ++p) {
+        const int q = t + 256 * p, row = q / CPR, col = q % CPR;
+        const int ch = ch0 + row < C ? ch0 + row : C - 1;
+        wv[p] = *reinterpret_cast<const u32x4*>(W + (int64_t)ch * ldw + col * 8);
+    }
 #pragma unroll
-        for (int b_ = 0; b_ < 4; ++b_) {
-            const int j = j0 + ti + b_;
-            if (j < c) dW[(int64_t)ch * lddw + j] = A * P[(int64_t)ch * ldp + j] + B * acc[a_][b_] + D * csum[j];
+    for (int p = 0; p < NG; ++p) {
+        const int q = t + 256 * p, i = q >> 3, col = q & 7;
+        gv[p] = *reinterpret_cast<const u32x4*>(gram + (int64_t)i * ldg + j0 + col * 4);
+    }
+    const int tch = (t >> 4) * 4, tj = (t & 15) * 2;
+    float2 pv[4];
+    float A[4], B[4], D[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ch = ch0 + tch + r < C ? ch0 + tch + r : C - 1;
+        pv[r] = *reinterpret_cast<const float2*>(P + (int64_t)ch * ldp + j0 + tj);
+        A[r] = coef[ch]; B[r] = coef[C + ch]; D[r] = coef[2 * C + ch];
+    }
+    const float2 cs = *reinterpret_cast<const float2*>(csum + j0 + tj);
+#pragma unroll
+    for (int p = 0; p < NW; ++p) {
+        const int q = t + 256 * p, row = q / CPR, col = q % CPR;
+        *reinterpret_cast<u32x4*>(wsm + row * WP + col * 8) = wv[p];
+    }
+#pragma unroll
+    for (int p = 0; p < NG; ++p) {
+        const int q = t + 256 * p;
+        *reinterpret_cast<u32x4*>(gsm + (q >> 3) * 32 + (q & 7) * 4) = gv[p];
+    }
+    __syncthreads();
+    float acc[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc[r][0] = 0.f; acc[r][1] = 0.f; }
+#pragma unroll 4
+    for (int i = 0; i < c; i += 4) {
+        float2 g2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g2[q] = *reinterpret_cast<const float2*>(gsm + (i + q) * 32 + tj);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint2 w4 = *reinterpret_cast<const uint2*>(wsm + (tch + r) * WP + i);
+            const float wf[4] = {bf16_bits_to_f32(w4.x & 0xffffu), __uint_as_float(w4.x & 0xffff0000u),
+                                 bf16_bits_to_f32(w4.y & 0xffffu), __uint_as_float(w4.y & 0xffff0000u)};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc[r][0] += wf[q] * g2[q].x; acc[r][1] += wf[q] * g2[q].y; }
         }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ch = ch0 + tch + r;
+        if (ch < C)
+            *reinterpret_cast<float2*>(dW + (int64_t)ch * lddw + j0 + tj) =
+                float2{A[r] * pv[r].x + B[r] * acc[r][0] + D[r] * cs.x, A[r] * pv[r].y + B[r] * acc[r][1] + D[r] * cs.y};
     }
 }
 
@@ -385,9 +393,16 @@ int iif_bn3_algebra_prep(const float* P, int ldp, const void* w_bf16, int ldw, c
 int iif_bn3_algebra_dw(const float* P, int ldp, const void* w_bf16, int ldw, const float* gram, int ldg, const float* csum,
                        const float* coef, int C, int c, float* dW, int lddw, void* stream) {
     if (!P || !w_bf16 || !gram || !csum || !coef || !dW || C <= 0 || c <= 0) return IIF_EINVAL;
-    if (c > 256 || ldp < c || ldw < c || ldg < c || lddw < c) return IIF_EUNSUPPORTED;
-    hipLaunchKernelGGL(bn3_dw_kernel, dim3((C + 63) / 64, (c + 63) / 64), dim3(256), 0, as_stream(stream), P, ldp, (const unsigned short*)w_bf16,
-                       ldw, gram, ldg, csum, coef, C, c, dW, lddw);
+    if ((c != 64 && c != 128 && c != 256) || ldp < c || ldw < c || ldg < c || lddw < c) return IIF_EUNSUPPORTED;
+    // 16-byte pieces of W and Gram, 8-byte pairs of P / dW / csum
+    if ((ldw % 8) || (ldg % 4) || (ldp % 2) || (lddw % 2) || (reinterpret_cast<uintptr_t>(w_bf16) & 15) || (reinterpret_cast<uintptr_t>(gram) & 15) ||
+        (reinterpret_cast<uintptr_t>(P) & 7) || (reinterpret_cast<uintptr_t>(dW) & 7) || (reinterpret_cast<uintptr_t>(csum) & 7))
+        return IIF_EUNSUPPORTED;
+    const dim3 grid((C + 63) / 64, c / 32), blk(256);
+    hipStream_t st = as_stream(stream);
+#define IIF_DW(CC) hipLaunchKernelGGL(bn3_dw_kernel<CC>, grid, blk, 0, st, P, ldp, (const unsigned short*)w_bf16, ldw, gram, ldg, csum, coef, C, dW, lddw)
+    if (c == 64) IIF_DW(64); else if (c == 128) IIF_DW(128); else IIF_DW(256);
+#undef IIF_DW
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }

@@ -65,6 +65,17 @@ template <int N> __device__ __forceinline__ void tr_fence() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+// The two 64-bit halves of one MFMA fragment, as the transposing reads return them.  The compiler does not know that the
+// registers are still being written, so NOTHING may touch them (not even the copy that assembles the 128-bit fragment)
+// before the covering tr_fence: the halves stay separate values until tr_join(), which is called AFTER the fence and routes
+// them through an empty asm - the fragment is then assembled from values that are defined behind the `s_waitcnt`, and any
+// register copy the allocator needs for it reads completed data.  tests/test_cabi.py::test_tr_read_results_are_waited_for
+// checks the emitted ISA for exactly this (no instruction names a tr-read destination before the wait that covers it).
+struct TrPair { s16x4 lo, hi; };
+__device__ __forceinline__ s16x8 tr_join(TrPair& p) {
+    asm volatile("" : "+v"(p.lo), "+v"(p.hi));
+    return s16x8{p.lo.x, p.lo.y, p.lo.z, p.lo.w, p.hi.x, p.hi.y, p.hi.z, p.hi.w};
+}
 
 template <typename T, int BC>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgArgs a) {
@@ -172,20 +183,23 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgArgs a) {
         if constexpr (sizeof(T) == 2) {
             // fragment element j<4 <-> LDS row 4g+j, j>=4 <-> row 16+4g+(j-4) (same map for both operands)
             const int q = li >> 2, p = li & 3;
+            TrPair xp[4], yp[KJ];
             s16x8 xf[4], yf[KJ];
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const unsigned char* base = X + (4 * g + q) * PX + (wn * 64 + ni * 16 + 4 * p) * 2;
-                const s16x4 lo = tr_read(base), hi = tr_read(base + 16 * PX);
-                xf[ni] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                xp[ni].lo = tr_read(base); xp[ni].hi = tr_read(base + 16 * PX);
             }
 #pragma unroll
             for (int kj = 0; kj < KJ; ++kj) {
                 const unsigned char* base = Y + (4 * g + q) * PY + (wk * (BC / 2) + kj * 16 + 4 * p) * 2;
-                const s16x4 lo = tr_read(base), hi = tr_read(base + 16 * PY);
-                yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                yp[kj].lo = tr_read(base); yp[kj].hi = tr_read(base + 16 * PY);
             }
             tr_fence<0>();
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) xf[ni] = tr_join(xp[ni]);
+#pragma unroll
+            for (int kj = 0; kj < KJ; ++kj) yf[kj] = tr_join(yp[kj]);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -418,26 +432,30 @@ __global__ void __launch_bounds__(128 * WK) conv_wgrad_dma_kernel(WgArgs a, unsi
             const int q = li >> 2, p = li & 3;
             // LDS returns in order: the dy fragments first, then the x fragments one 16-column block at a time; the MFMAs of
             // block ni start as soon as its two reads are back (6 / 4 / 2 / 0 younger reads still outstanding)
-            s16x8 xf[4], yf[KJ];
+            TrPair xp[4], yp[KJ];
+            s16x8 yf[KJ];
 #pragma unroll
             for (int kj = 0; kj < KJ; ++kj) {
                 const int colb = (wk * CW + kj * 16 + 4 * p) * 2;
-                const s16x4 lo = tr_read(Y + SY::addr(4 * g + q, colb)), hi = tr_read(Y + SY::addr(16 + 4 * g + q, colb));
-                yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                yp[kj].lo = tr_read(Y + SY::addr(4 * g + q, colb)); yp[kj].hi = tr_read(Y + SY::addr(16 + 4 * g + q, colb));
             }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const int colb = (wn * 64 + ni * 16 + 4 * p) * 2;
-                const s16x4 lo = tr_read(X + SX::addr(4 * g + q, colb)), hi = tr_read(X + SX::addr(16 + 4 * g + q, colb));
-                xf[ni] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                xp[ni].lo = tr_read(X + SX::addr(4 * g + q, colb)); xp[ni].hi = tr_read(X + SX::addr(16 + 4 * g + q, colb));
             }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 if (ni == 0) tr_fence<6>(); else if (ni == 1) tr_fence<4>(); else if (ni == 2) tr_fence<2>(); else tr_fence<0>();
+                if (ni == 0) {
+#pragma unroll
+                    for (int kj = 0; kj < KJ; ++kj) yf[kj] = tr_join(yp[kj]);
+                }
+                const s16x8 xf = tr_join(xp[ni]);
 #pragma unroll
                 for (int kj = 0; kj < KJ; ++kj)
                     acc[ni][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, xf[ni]), __builtin_bit_cast(bf16x8, yf[kj]), acc[ni][kj], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8, xf), __builtin_bit_cast(bf16x8, yf[kj]), acc[ni][kj], 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -591,23 +609,27 @@ __device__ __forceinline__ void wgrad1x1_body(const W1Args& a, unsigned x_bytes,
         if (t + 1 < nst) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (t + 2 < nst) issue(refill_c);
-        s16x8 xf[4], yf[KJ];
+        TrPair xp[4], yp[KJ];
+        s16x8 yf[KJ];
 #pragma unroll
         for (int kj = 0; kj < KJ; ++kj) {
-            const s16x4 lo = tr_read_at<S * STAGE>(yo[kj]), hi = tr_read_at<S * STAGE + 16 * RBY>(yo[kj]);
-            yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            yp[kj].lo = tr_read_at<S * STAGE>(yo[kj]); yp[kj].hi = tr_read_at<S * STAGE + 16 * RBY>(yo[kj]);
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const s16x4 lo = tr_read_at<S * STAGE>(xo[ni]), hi = tr_read_at<S * STAGE + 16 * RBX>(xo[ni]);
-            xf[ni] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            xp[ni].lo = tr_read_at<S * STAGE>(xo[ni]); xp[ni].hi = tr_read_at<S * STAGE + 16 * RBX>(xo[ni]);
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             if (ni == 0) tr_fence<6>(); else if (ni == 1) tr_fence<4>(); else if (ni == 2) tr_fence<2>(); else tr_fence<0>();
+            if (ni == 0) {
+#pragma unroll
+                for (int kj = 0; kj < KJ; ++kj) yf[kj] = tr_join(yp[kj]);
+            }
+            const s16x8 xf = tr_join(xp[ni]);
 #pragma unroll
             for (int kj = 0; kj < KJ; ++kj)
-                acc[ni][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf[ni]), __builtin_bit_cast(bf16x8, yf[kj]),
+                acc[ni][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf), __builtin_bit_cast(bf16x8, yf[kj]),
                                                                       acc[ni][kj], 0, 0, 0);
         }
     };
@@ -762,16 +784,15 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, u
         IIF_WSTAMP(w2); w_wait += w1 - w0; w_issue += w2 - w1; w3 = w2;
 #endif
         const int xs = t * (32 * RB), ys = t * (32 * RB);
-        s16x8 yf[4], xf[9];
+        TrPair yp[4], xp[9];
+        s16x8 yf[4];
 #pragma unroll
         for (int kj = 0; kj < 4; ++kj) {
-            const s16x4 lo = tr_read(YS + ((yo[kj] + ys) & (YR * RB - 1))), hi = tr_read(YS + ((yo[kj] + ys + 16 * RB) & (YR * RB - 1)));
-            yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            yp[kj].lo = tr_read(YS + ((yo[kj] + ys) & (YR * RB - 1))); yp[kj].hi = tr_read(YS + ((yo[kj] + ys + 16 * RB) & (YR * RB - 1)));
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const s16x4 lo = tr_read(XS + ((xo[tap] + xs) & (XR * RB - 1))), hi = tr_read(XS + ((xo[tap] + xs + 16 * RB) & (XR * RB - 1)));
-            xf[tap] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            xp[tap].lo = tr_read(XS + ((xo[tap] + xs) & (XR * RB - 1))); xp[tap].hi = tr_read(XS + ((xo[tap] + xs + 16 * RB) & (XR * RB - 1)));
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -779,9 +800,14 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgHaloArgs a, u
             if (tap == 0) tr_fence<15>(); else if (tap == 1) tr_fence<14>(); else if (tap == 2) tr_fence<12>();
             else if (tap == 3) tr_fence<10>(); else if (tap == 4) tr_fence<8>(); else if (tap == 5) tr_fence<6>();
             else if (tap == 6) tr_fence<4>(); else if (tap == 7) tr_fence<2>(); else tr_fence<0>();
+            if (tap == 0) {
+#pragma unroll
+                for (int kj = 0; kj < 4; ++kj) yf[kj] = tr_join(yp[kj]);
+            }
+            const s16x8 xf = tr_join(xp[tap]);
 #pragma unroll
             for (int kj = 0; kj < 4; ++kj)
-                acc[tap][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf[tap]), __builtin_bit_cast(bf16x8, yf[kj]),
+                acc[tap][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf), __builtin_bit_cast(bf16x8, yf[kj]),
                                                                         acc[tap][kj], 0, 0, 0);
         }
     }
@@ -898,23 +924,27 @@ __global__ void __launch_bounds__(256) conv4x4_s2d_wgrad_kernel(WgStemArgs a, un
         if (wave == 0) issue_x();
         issue_y();
         const int xs = t * (32 * XRB), ys = t * (32 * YRB);
-        s16x8 yf[4], xf[4];
+        TrPair yp[4], xp[4];
+        s16x8 yf[4];
 #pragma unroll
         for (int kj = 0; kj < 4; ++kj) {
-            const s16x4 lo = tr_read(YS + ((yo[kj] + ys) & (YR * YRB - 1))), hi = tr_read(YS + ((yo[kj] + ys + 16 * YRB) & (YR * YRB - 1)));
-            yf[kj] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            yp[kj].lo = tr_read(YS + ((yo[kj] + ys) & (YR * YRB - 1))); yp[kj].hi = tr_read(YS + ((yo[kj] + ys + 16 * YRB) & (YR * YRB - 1)));
         }
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_) {
-            const s16x4 lo = tr_read(XS + ((xo[s_] + xs) & (XR * XRB - 1))), hi = tr_read(XS + ((xo[s_] + xs + 16 * XRB) & (XR * XRB - 1)));
-            xf[s_] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            xp[s_].lo = tr_read(XS + ((xo[s_] + xs) & (XR * XRB - 1))); xp[s_].hi = tr_read(XS + ((xo[s_] + xs + 16 * XRB) & (XR * XRB - 1)));
         }
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_) {
             if (s_ == 0) tr_fence<6>(); else if (s_ == 1) tr_fence<4>(); else if (s_ == 2) tr_fence<2>(); else tr_fence<0>();
+            if (s_ == 0) {
+#pragma unroll
+                for (int kj = 0; kj < 4; ++kj) yf[kj] = tr_join(yp[kj]);
+            }
+            const s16x8 xf = tr_join(xp[s_]);
 #pragma unroll
             for (int kj = 0; kj < 4; ++kj)
-                acc[s_][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf[s_]), __builtin_bit_cast(bf16x8, yf[kj]),
+                acc[s_][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf), __builtin_bit_cast(bf16x8, yf[kj]),
                                                                        acc[s_][kj], 0, 0, 0);
         }
     }
@@ -950,16 +980,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int 
         const int64_t e = i * 4;
         const int n = (int)(e % ldw);
         if (n >= K) continue;
-        f32x4 s = IIF_SLAB_LD(ws + (int64_t)s0 * slab + e);
-        int j = s0 + 1;
-        for (; j + 3 < s1; j += 4) {                      // 4 slabs in flight, added in slab order
-            const f32x4 t0 = IIF_SLAB_LD(ws + (int64_t)j * slab + e);
-            const f32x4 t1 = IIF_SLAB_LD(ws + (int64_t)(j + 1) * slab + e);
-            const f32x4 t2 = IIF_SLAB_LD(ws + (int64_t)(j + 2) * slab + e);
-            const f32x4 t3 = IIF_SLAB_LD(ws + (int64_t)(j + 3) * slab + e);
-            s += t0; s += t1; s += t2; s += t3;
+        // 16 slabs in flight, requested unconditionally (a slab past the chunk reads the chunk's first one again and is not
+        // added), summed in slab order.  Round 4 kept 4 in flight under a run-time trip count: a 32-slab sum was 8 dependent
+        // memory round trips of 2-5 us each on the weight-gradient stream; it is 2 now, with the same additions in the same order.
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = s0; j < s1; j += 16) {
+            f32x4 t[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t[q] = IIF_SLAB_LD(ws + (int64_t)(j + q < s1 ? j + q : s0) * slab + e);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 u = s + t[q];
+                if (j + q < s1) s = (j + q == s0) ? t[q] : u;
+            }
         }
-        for (; j < s1; ++j) s += IIF_SLAB_LD(ws + (int64_t)j * slab + e);
         *reinterpret_cast<f32x4*>(dst + e) = s;
     }
 }

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* x, int N, int
 // argmax are exactly those of bn_apply followed by maxpool_fwd_kernel.
 template <typename T>
 __global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const T* x, const float* stats, int N, int H, int W, int C, int k,
-                                                             int s, int p, int Ho, int Wo, T* y, unsigned char* idx) {
+                                                             int s, int p, int Ho, int Wo, T* y, unsigned char* idx, T* px) {
     constexpr int V = PT<T>::V;
     const int cv = C / V;
     const int64_t total = (int64_t)N * Ho * Wo * cv;
@@ -90,9 +90,9 @@ __global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const T* x, const f
         const int wo = (int)(pix % Wo); pix /= Wo;
         const int ho = (int)(pix % Ho);
         const int n = (int)(pix / Ho);
-        float best[V], ca[V], cb[V]; unsigned char bi[V];
+        float best[V], bx[V], ca[V], cb[V]; unsigned char bi[V];
 #pragma unroll
-        for (int q = 0; q < V; ++q) { best[q] = -INFINITY; bi[q] = 0; ca[q] = stats[2 * C + c + q]; cb[q] = stats[3 * C + c + q]; }
+        for (int q = 0; q < V; ++q) { best[q] = -INFINITY; bx[q] = 0.f; bi[q] = 0; ca[q] = stats[2 * C + c + q]; cb[q] = stats[3 * C + c + q]; }
         bool first = true;
         for (int kh = 0; kh < k; ++kh) {
             const int h = ho * s - p + kh;
@@ -106,13 +106,14 @@ __global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const T* x, const f
                 for (int q = 0; q < V; ++q) {
                     float t = fmaxf(fmaf(ca[q], v[q], cb[q]), 0.f);
                     if constexpr (sizeof(T) == 2) t = bf16_bits_to_f32(f32_to_bf16_bits(t));
-                    if (first || t > best[q] || t != t) { best[q] = t; bi[q] = (unsigned char)(kh * k + kw); }
+                    if (first || t > best[q] || t != t) { best[q] = t; bx[q] = v[q]; bi[q] = (unsigned char)(kh * k + kw); }
                 }
                 first = false;
             }
         }
         const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + c;
         PT<T>::store(y + o, best);
+        if (px) PT<T>::store(px + o, bx);
 #pragma unroll
         for (int q = 0; q < V; ++q) idx[o + q] = bi[q];
     }
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const T* x, const f
 // in the (kh, kw) order of the general kernel with its first-valid / strictly-greater / NaN rule: identical results.
 template <typename T>
 __global__ void __launch_bounds__(256) maxpool321_bn_fwd_kernel(const T* x, const float* stats, int N, int H, int W, int C, int Ho,
-                                                                int Wo, T* y, unsigned char* idx) {
+                                                                int Wo, T* y, unsigned char* idx, T* px) {
     constexpr int V = PT<T>::V;
     const unsigned cv = C / V, rowv = (unsigned)Wo * cv;
     const int c = (int)(threadIdx.x % cv) * V;
@@ -148,10 +149,10 @@ __global__ void __launch_bounds__(256) maxpool321_bn_fwd_kernel(const T* x, cons
                     const int hc = h < 0 ? 0 : (h >= H ? H - 1 : h), wc = w < 0 ? 0 : (w >= W ? W - 1 : w);
                     PT<T>::load(x + (((int64_t)n * H + hc) * W + wc) * C + c, v[kh * 3 + kw]);
                 }
-            float best[V];
+            float best[V], bx[V];
             unsigned bi[V];
 #pragma unroll
-            for (int q = 0; q < V; ++q) { best[q] = -INFINITY; bi[q] = 0; }
+            for (int q = 0; q < V; ++q) { best[q] = -INFINITY; bx[q] = 0.f; bi[q] = 0; }
             bool first = true;
 #pragma unroll
             for (int t9 = 0; t9 < 9; ++t9) {
@@ -160,12 +161,13 @@ __global__ void __launch_bounds__(256) maxpool321_bn_fwd_kernel(const T* x, cons
                 for (int q = 0; q < V; ++q) {
                     float t = fmaxf(fmaf(ca[q], v[t9][q], cb[q]), 0.f);
                     if constexpr (sizeof(T) == 2) t = bf16_bits_to_f32(f32_to_bf16_bits(t));
-                    if (first || t > best[q] || t != t) { best[q] = t; bi[q] = (unsigned)t9; }
+                    if (first || t > best[q] || t != t) { best[q] = t; bx[q] = v[t9][q]; bi[q] = (unsigned)t9; }
                 }
                 first = false;
             }
             const int64_t o = ((int64_t)row * Wo + wo) * C + c;
             PT<T>::store(y + o, best);
+            if (px) PT<T>::store(px + o, bx);          // the RAW value at the arg max: what the backward's column sums start from
             if constexpr (V == 8) {
                 const unsigned lo = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24), hi = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
                 *reinterpret_cast<uint2*>(idx + o) = make_uint2(lo, hi);
@@ -490,12 +492,12 @@ int iif_maxpool_forward(const void* x, int dtype, int n, int h, int w, int c, in
 }
 
 int iif_maxpool_bn_forward(const void* x, int dtype, const float* stats, int n, int h, int w, int c, int k, int stride, int pad,
-                           void* y, uint8_t* argmax, void* stream) {
+                           void* y, uint8_t* argmax, void* pool_x, void* stream) {
     if (!x || !stats || !y || !argmax || n <= 0 || h <= 0 || w <= 0 || c <= 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0)
         return IIF_EINVAL;
     const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
     if (ho <= 0 || wo <= 0) return IIF_EINVAL;
-    if (mis(x) || mis(y) || c % (dtype == IIF_F32 ? 4 : 8)) return IIF_EUNSUPPORTED;
+    if (mis(x) || mis(y) || (pool_x && mis(pool_x)) || c % (dtype == IIF_F32 ? 4 : 8)) return IIF_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
     const int64_t tot = (int64_t)n * ho * wo * (c / (dtype == IIF_F32 ? 4 : 8));
     const int cvs = c / (dtype == IIF_F32 ? 4 : 8);
@@ -503,14 +505,14 @@ int iif_maxpool_bn_forward(const void* x, int dtype, const float* stats, int n, 
         (int64_t)n * h * w * c < 0x7fffffffLL) {
         const int rowblocks = (int)((int64_t)n * ho < 16384 ? (int64_t)n * ho : 16384);
         IIF_BY_DTYPE(dtype,
-            hipLaunchKernelGGL(maxpool321_bn_fwd_kernel<float>, dim3(rowblocks), dim3(256), 0, st, (const float*)x, stats, n, h, w, c, ho, wo, (float*)y, argmax),
-            hipLaunchKernelGGL(maxpool321_bn_fwd_kernel<unsigned short>, dim3(rowblocks), dim3(256), 0, st, (const unsigned short*)x, stats, n, h, w, c, ho, wo, (unsigned short*)y, argmax))
+            hipLaunchKernelGGL(maxpool321_bn_fwd_kernel<float>, dim3(rowblocks), dim3(256), 0, st, (const float*)x, stats, n, h, w, c, ho, wo, (float*)y, argmax, (float*)pool_x),
+            hipLaunchKernelGGL(maxpool321_bn_fwd_kernel<unsigned short>, dim3(rowblocks), dim3(256), 0, st, (const unsigned short*)x, stats, n, h, w, c, ho, wo, (unsigned short*)y, argmax, (unsigned short*)pool_x))
         IIF_LAUNCH_CHECK();
         return IIF_OK;
     }
     IIF_BY_DTYPE(dtype,
-        hipLaunchKernelGGL(maxpool_bn_fwd_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, (const float*)x, stats, n, h, w, c, k, stride, pad, ho, wo, (float*)y, argmax),
-        hipLaunchKernelGGL(maxpool_bn_fwd_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, (const unsigned short*)x, stats, n, h, w, c, k, stride, pad, ho, wo, (unsigned short*)y, argmax))
+        hipLaunchKernelGGL(maxpool_bn_fwd_kernel<float>, dim3(sblocks(tot)), dim3(256), 0, st, (const float*)x, stats, n, h, w, c, k, stride, pad, ho, wo, (float*)y, argmax, (float*)pool_x),
+        hipLaunchKernelGGL(maxpool_bn_fwd_kernel<unsigned short>, dim3(sblocks(tot)), dim3(256), 0, st, (const unsigned short*)x, stats, n, h, w, c, k, stride, pad, ho, wo, (unsigned short*)y, argmax, (unsigned short*)pool_x))
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }

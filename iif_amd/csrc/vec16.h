@@ -18,6 +18,17 @@ template <> struct VT<float> {
     static __device__ __forceinline__ void load_nt(const float* p, float (&v)[4]) {
         const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
+    // the 16 raw bytes first, the conversion later: a batch of loads can be requested before the first value is touched
+    static __device__ __forceinline__ u32x4 raw_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+    static __device__ __forceinline__ u32x4 raw(const float* p) { return *reinterpret_cast<const u32x4*>(p); }
+    static __device__ __forceinline__ void unpack(const u32x4& t, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(t[i]);
+    }
+    template <bool NT> static __device__ __forceinline__ void store_as(float* p, const float (&v)[4]) {
+        const f32x4 t{v[0], v[1], v[2], v[3]};
+        if (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p)); else *reinterpret_cast<f32x4*>(p) = t;
+    }
 };
 template <> struct VT<unsigned short> {
     static constexpr int V = 8;
@@ -40,6 +51,18 @@ template <> struct VT<unsigned short> {
 #else
         *reinterpret_cast<u32x4*>(p) = t;
 #endif
+    }
+    static __device__ __forceinline__ u32x4 raw_nt(const unsigned short* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+    static __device__ __forceinline__ u32x4 raw(const unsigned short* p) { return *reinterpret_cast<const u32x4*>(p); }
+    static __device__ __forceinline__ void unpack(const u32x4& t, float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_bits_to_f32(t[i] & 0xffffu); v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u); }
+    }
+    template <bool NT> static __device__ __forceinline__ void store_as(unsigned short* p, const float (&v)[8]) {
+        u32x4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        if (NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p)); else *reinterpret_cast<u32x4*>(p) = t;
     }
 };
 }  // namespace

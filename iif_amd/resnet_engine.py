@@ -662,6 +662,8 @@ class _Plan(object):
             self.pool_hw = ((ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1)
             self.pool_out = E(n, self.pool_hw[0], self.pool_hw[1], c1.cout)
             self.pool_idx = torch.empty((n, self.pool_hw[0], self.pool_hw[1], c1.cout), dtype=torch.uint8, device=dev)
+            # the raw stem output at each window's arg max: what bn1's backward column sums are taken from (bf16, fused pool)
+            self.pool_x = E(n, self.pool_hw[0], self.pool_hw[1], c1.cout) if (self.pool_fused and dt == torch.bfloat16) else None
             cur = self.pool_out
         else:
             cur = u.y
@@ -1086,7 +1088,8 @@ class _Plan(object):
             # bn1 + relu + maxpool in one pass over the raw stem output: the stem's activation is never stored
             _lib.check(_lib.lib().iif_maxpool_bn_forward(_lib.ptr(u.x), _lib.dtype_code(u.x), _lib.ptr(u.stats), u.n, u.ho, u.wo,
                                                          u.conv.cout, 3, 2, 1, _lib.ptr(self.pool_out), _lib.ptr(self.pool_idx),
-                                                         _lib.stream_ptr()), "iif_maxpool_bn_forward")
+                                                         _lib.ptr(self.pool_x if training else None), _lib.stream_ptr()),
+                       "iif_maxpool_bn_forward")
         else:
             ops.bn_apply(x2, u.stats, u.y.view(x2.shape), relu=True, relu_bits=u.bits)
             if net.style == "imagenet":
@@ -1573,10 +1576,11 @@ class _Plan(object):
             cv, bn = u.conv, u.bn
             m = u.n * u.ho * u.wo
             g2 = g.view(m, cv.cout)
-            # bf16: the two column sums come from the pooled gradient and the pooled output (a quarter of the elements, no pass
-            # over the scattered gradient and the stem output: 190 -> ~45 us at batch 256); the normalisation pass is unchanged.
-            # fp32 (parity mode) keeps the reduction pass: recovering xhat from the pooled value costs a few ulps that BN
-            # backward amplifies past the 2e-4 the parity tests hold the stem's weight gradient to.
+            # bf16: the two column sums come from the pooled gradient and the raw stem output at the arg max (pool_x, stored by the
+            # fused forward pool): a quarter of the elements, no pass over the scattered gradient and the stem output (190 -> ~45 us
+            # at batch 256), term for term the standard pass's sums; the normalisation pass is unchanged.
+            # fp32 (parity mode) keeps the reduction pass (the parity tests hold the stem's weight gradient to 2e-4 against a
+            # reference that sums in that order).
             if self.dt == torch.float32:
                 _lib.check(_lib.lib().iif_bn_backward_relu_recompute(_lib.ptr(g2), _lib.ptr(u.x), _lib.dtype_code(u.x), m, cv.cout,
                                                                      _lib.ptr(u.stats), _lib.ptr(bn.weight), _lib.ptr(bn._dgamma),
@@ -1587,7 +1591,7 @@ class _Plan(object):
                 _lib.check(_lib.lib().iif_bn_backward_relu_recompute_pooled(
                     _lib.ptr(g2), _lib.ptr(u.x), _lib.dtype_code(u.x), m, cv.cout, _lib.ptr(u.stats), _lib.ptr(bn.weight),
                     _lib.ptr(bn._dgamma), _lib.ptr(bn._dbeta), _lib.ptr(g2), _lib.ptr(self.bn_ws), self.bn_ws.numel(), _lib.ptr(g_pooled),
-                    _lib.ptr(self.pool_out), self.pool_out.numel() // cv.cout, _lib.stream_ptr()),
+                    _lib.ptr(self.pool_x), self.pool_x.numel() // cv.cout, _lib.stream_ptr()),
                     "iif_bn_backward_relu_recompute_pooled")
             self._stem_wgrad(u, g2.view(u.n, u.ho, u.wo, cv.cout))
         else:

@@ -525,18 +525,20 @@ int iif_bn_backward_partials_fused(const void* gy, const uint8_t* relu_bits, con
  *                                    shift at [3c]); candidates are rounded to the storage type first, so value and
  *                                    argmax equal iif_bn_apply followed by iif_maxpool_forward
  *   iif_bn_backward_relu_recompute   iif_bn_backward with the ReLU mask recomputed as a*x + b > 0 (same fmaf)
- *   iif_bn_backward_relu_recompute_pooled   the same, its two column sums taken from the POOLED gradient g_pool and the pooled
- *                                    forward output pool_out ([pool_pixels][c] each) instead of a reduction pass over gy and x:
- *                                    sum g = sum g_pool [out > 0], sum g xhat = sum g_pool [out > 0] ((out - b) / a - mean) invstd.  gy is the
- *                                    pooled gradient already scattered to the stem's resolution (iif_maxpool_backward) */
+ *   iif_bn_backward_relu_recompute_pooled   the same, its two column sums taken from the POOLED gradient g_pool and the RAW stem
+ *                                    output at each window's arg max, pool_x ([pool_pixels][c] each; written by
+ *                                    iif_maxpool_bn_forward when its pool_x argument is given) instead of a reduction pass over
+ *                                    gy and x: sum g = sum g_pool [a x* + b > 0], sum g xhat = sum g_pool [a x* + b > 0] (x* - mean) invstd
+ *                                    - term for term what the reduction pass adds, in another order.  gy is the pooled gradient
+ *                                    already scattered to the stem's resolution (iif_maxpool_backward) */
 int iif_maxpool_bn_forward(const void* x, int dtype, const float* stats, int n, int h, int w, int c, int k, int stride,
-                           int pad, void* y, uint8_t* argmax, void* stream);
+                           int pad, void* y, uint8_t* argmax, void* pool_x /* nullable */, void* stream);
 int iif_bn_backward_relu_recompute(const void* gy, const void* x, int dtype, int64_t m, int c, const float* stats,
                                    const float* gamma, float* dgamma, float* dbeta, void* dx, void* workspace,
                                    int64_t workspace_bytes, void* stream);
 int iif_bn_backward_relu_recompute_pooled(const void* gy, const void* x, int dtype, int64_t m, int c, const float* stats,
                                           const float* gamma, float* dgamma, float* dbeta, void* dx, void* workspace,
-                                          int64_t workspace_bytes, const void* g_pool, const void* pool_out, int64_t pool_pixels,
+                                          int64_t workspace_bytes, const void* g_pool, const void* pool_x, int64_t pool_pixels,
                                           void* stream);
 
 #ifdef __cplusplus

@@ -174,3 +174,62 @@ def test_ticket_protocol_isa(tmp_path, src, kernel):
         assert any(" sc1" in t for t in loads_after), (name, loads_after[:4])
         checked += 1
     assert checked >= 1
+
+
+def _vregs(tok):
+    """VGPR numbers an operand token names: v12 -> [12], v[12:15] -> [12..15]; anything else -> []."""
+    import re
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return [int(m.group(1))]
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return list(range(int(m.group(1)), int(m.group(2)) + 1))
+    return []
+
+
+@pytest.mark.parametrize("src", ["conv_wgrad.hip", "bn3_algebra.hip"])
+def test_tr_read_results_are_waited_for(tmp_path, src):
+    """The transposing LDS reads are inline asm (the builtin drains every LDS-DMA in flight, conv_wgrad.hip:51-56), so the
+    compiler does not know that their destination registers are still being written.  Pin the emitted gfx950 ISA: between a
+    `ds_read_b64_tr_b16 vD, ...` and the `s_waitcnt lgkmcnt(N)` that covers it (LDS operations return in order: the wait covers
+    a read once at most N LDS instructions were issued after it), NO instruction may name a register of vD - not an MFMA,
+    and not a register copy the allocator placed there to assemble a 128-bit fragment."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(ROOT, "iif_amd", "csrc")
+    asm_path = tmp_path / "k.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + csrc, "--offload-device-only",
+                    "-S", "-o", str(asm_path), os.path.join(csrc, src)], check=True, stderr=subprocess.DEVNULL)
+    bodies = _kernel_bodies(asm_path.read_text(), "")
+    reads = 0
+    for name, ins in bodies.items():
+        pending = {}                 # vgpr -> index of its read among the LDS instructions issued so far
+        n_lds = 0
+        for t in ins:
+            op, _, rest = t.partition(" ")
+            toks = [x.strip() for x in re.split(r"[ ,]+", rest.split(";")[0]) if x.strip()]
+            if op == "s_waitcnt":
+                m = re.search(r"lgkmcnt\((\d+)\)", t)
+                if m:
+                    keep = int(m.group(1))
+                    pending = {r: i for r, i in pending.items() if i > n_lds - keep}
+                continue
+            named = [r for tok in toks for r in _vregs(tok)]
+            if op == "ds_read_b64_tr_b16":
+                dst = _vregs(toks[0])
+                clash = [r for r in named[len(dst):] if r in pending]
+                assert not clash, (name, t, "address register still pending")
+                n_lds += 1
+                reads += 1
+                for r in dst:
+                    assert r not in pending, (name, t, "destination rewritten while a read into it is in flight")
+                    pending[r] = n_lds
+                continue
+            clash = [r for r in named if r in pending]
+            assert not clash, "%s: `%s` touches v%s before the s_waitcnt that covers its ds_read_b64_tr_b16" % (name, t, clash)
+            if op.startswith("ds_"):
+                n_lds += 1
+    assert reads >= 8, "no transposing reads found in %s" % src

@@ -654,8 +654,12 @@ def test_bf16_loss_curve_of_the_default_routes_against_the_standard_backward(mon
     """The DEFAULT bf16 configuration at the benchmark's image size (224 x 224, batch 64: the 56 x 56 stage takes the algebraic
     BN3 backward with sum g~ y from P = g~^T a2 — sums of the UNROUNDED conv3 output, csrc/bn3_algebra.hip — the other stages
     the producer's sums, the stem its pooled sums) against the same network with every BN backward on the standard
-    reduction passes: six SGD steps on the damped initialisation.  The two differ by bf16 roundings only; the bound catches a
-    drift of either route (measured: <= 1.3e-3 over the six steps; bound 5e-3)."""
+    reduction passes: six SGD steps on the damped initialisation.  The two differ by bf16 roundings only, and the recipe
+    amplifies such differences from step to step: measured in round 5 (scripts/dbg_route_curve.py), the standard backward with
+    and without the fused BN-backward sums - two orderings of the same sums - are 3.9e-4, 1.7e-3, 3.9e-4, 3.8e-3 and 1.0e-2 apart
+    at steps 2 ... 6, the default routes 2.7e-4, 6.8e-4, 2.2e-3, 2.7e-3, 7.5e-3 from the standard backward.  The bound grows with
+    the step accordingly (a fixed 5e-3 over all six steps held in round 4 by the luck of one trajectory and broke when the
+    stem's sums became MORE exact); a drift of a route shows at steps 2-4, where the bound is still tight."""
     from iif_amd.custom import IIFLoss
     arch, C, B, hw = "resnet50", 1000, 64, 224
     counts = [max(int(1280 * (5 / 1280) ** (i / (C - 1.0))), 1) for i in range(C)]
@@ -684,8 +688,8 @@ def test_bf16_loss_curve_of_the_default_routes_against_the_standard_backward(mon
                 and not all(plan._a3_is_pure(u) for u in plan.alg3_units)               # the mixed configuration
         curves[mode] = losses
         del net
-    for a, b in zip(curves["default"], curves["standard"]):
-        assert abs(a - b) <= 5e-3 * abs(b), (curves["default"], curves["standard"])
+    for a, b, tol in zip(curves["default"], curves["standard"], (1e-6, 1e-3, 2e-3, 5e-3, 1e-2, 2e-2)):
+        assert abs(a - b) <= tol * abs(b), (curves["default"], curves["standard"])
     assert curves["default"][-1] < curves["default"][0]              # (lr 0.002: the raw IIF recipe descends smoothly)
 
 
