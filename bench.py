@@ -355,6 +355,9 @@ def main():
     ap.add_argument("--event-every", type=int, default=20, help="bracket the conv launches of every n-th timed step")
     ap.add_argument("--trace-loss", action="store_true", help="record the loss of every step (one tiny copy per step)")
     ap.add_argument("--force-reducer", action="store_true", help="drive the bucketed all-reduce path even with one rank")
+    ap.add_argument("--reducer-cus", type=int, default=None,
+                    help="compute units the persistent kernels may take while the reducer is active (iif_set_cu_budget; default: "
+                         "240 with more than one rank, no reservation with one)")
     ap.add_argument("--reduce-mode", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="gradient buckets: one all_reduce each, or reduce_scatter + all_gather (iif_amd.ddp)")
     ap.add_argument("--bf16-buckets", action="store_true",
@@ -365,9 +368,10 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` as the driver types it: this process has not touched the GPU yet (counting devices does
-        # not initialise HIP), so it may start the N ranks as a CHILD torch.distributed.run and relay rank 0's JSON line.
-        # Never an exec: a process that has initialised the GPU must not be replaced on this pool.
+        # `python bench.py --gpus N` as the driver types it: start the N ranks as a CHILD torch.distributed.run and relay rank
+        # 0's JSON line.  Always a child process (subprocess), never an exec: counting the devices may already have initialised
+        # the HIP runtime in this process (torch.cuda.device_count() falls back to hipGetDeviceCount on builds without amdsmi),
+        # and a process that has touched the GPU must not be replaced on this pool.
         sys.exit(_self_launch(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -414,7 +418,7 @@ def main():
     net.train()
     broadcast_parameters(net)
     crit = IIFLoss(_Counts(counts), variant="raw", reduction="mean", device=dev)
-    reducer = net.make_reducer(mode=args.reduce_mode) if (world > 1 or args.force_reducer) else None
+    reducer = net.make_reducer(mode=args.reduce_mode, cu_budget=args.reducer_cus) if (world > 1 or args.force_reducer) else None
     if reducer is not None and args.force_reducer:
         reducer.force = True
     tail_events = []

@@ -24,6 +24,8 @@ _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
 # name -> argtypes; must list every symbol of include/iif_amd.h (tests check this)
 SIGNATURES = {
     "iif_build_table": [_P, _I, _I, _I, _P],
+    "iif_set_cu_budget": [_I],
+    "iif_get_cu_budget": [],
     "iif_ce_fwd_bwd": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _L, _F, _I, _I, _P, _P, _P, _L, _P, _P, _P],
     "iif_scale_logits": [_P, _I, _L, _P, _I, _I, _P, _L, _P],
     "iif_softmax": [_P, _I, _L, _P, _I, _I, _P, _L, _P],

@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partial, 
 // tensor one vector per trip ran at 5.4 TB/s - the stores of blocks that have drifted apart land in DRAM pages 16 MB apart
 // (a write-only sweep of the same form: 4.2 TB/s at 4 096 blocks, 6.1 at 16 384); ONE trip per thread over U vectors 256 apart
 // (the same channel vector, so the coefficients are still loaded once), every load requested before the first use,
-// non-temporal loads and stores: 6.6 TB/s.  The grid is as large as the tensor; IIF_BN_GRID_CAP brings the loop back.
+// non-temporal loads: 6.2 TB/s (6.6 with non-temporal stores too).  The grid is as large as the tensor (stream_grid below).
 template <typename T, bool RELU, int RES, int U, bool NTS>   // RES 0: none, 1: + r, 2: + a2*r + b2
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* x, const float* stats, const T* r, const float* stats2,
                                                        T* y, int64_t total_vec, int cv, int C, unsigned char* relu_bits) {
@@ -511,12 +511,16 @@ inline int launch_bn_finalize(const float* partial, int nblk, int C, double coun
     return IIF_OK;
 }
 
-// grid of the two normalisation passes: one trip per thread over U vectors (U = 4 where that still leaves >= 2 048 blocks);
-// IIF_BN_GRID_CAP=<blocks> caps the grid (the kernels then loop), IIF_BN_PLAIN_STORES=1 turns the non-temporal stores off
+// grid of the two normalisation passes: one trip per thread over U vectors (U = 4 where that still leaves >= 2 048 blocks).
+// In the ResNet-50 step (same-call A/B, ms per step): round 4's form (4 096 blocks looping, U = 1) 18.59 / 18.62; one trip,
+// U <= 4 18.32 / 18.33; the same with non-temporal stores 18.34 / 18.41 (alone they are the faster form, 6.6 against 6.2 TB/s;
+// in the step the consumer reads the tensor next); U = 1 one trip 19.09 / 19.04 (100 k blocks of one vector per thread: alone
+// 6.1 TB/s, in the step the other streams' blocks wait behind them); a grid capped at 4 096 / 2 048 / 1 024 blocks with U <= 4
+// 18.42 / 18.47 / 18.51.  IIF_BN_GRID_CAP=<blocks>, IIF_BN_UNROLL=<1|2|4>, IIF_BN_NT_STORES=1 select the other forms.
 struct StreamGrid { int blocks, u; bool nts; };
 inline StreamGrid stream_grid(int64_t total_vec) {
     static const int64_t cap = [] { const char* e = getenv("IIF_BN_GRID_CAP"); return e ? atoll(e) : (1LL << 30); }();
-    static const bool nts = getenv("IIF_BN_PLAIN_STORES") == nullptr;
+    static const bool nts = getenv("IIF_BN_NT_STORES") != nullptr;
     static const int umax = [] { const char* e = getenv("IIF_BN_UNROLL"); return e ? atoi(e) : 4; }();
     int u = total_vec >= (int64_t)4 * 256 * 2048 ? 4 : (total_vec >= (int64_t)2 * 256 * 2048 ? 2 : 1);
     if (u > umax) u = umax;

@@ -70,3 +70,8 @@ bool iif_regw3x3_ok(int N, int H, int W, int C);
 int iif_regw3x3_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
                        int N, int H, int W, int C, int ldw, const signed char* tap_dy, const signed char* tap_dx, const unsigned char* tap_w,
                        const void* bw_x, const unsigned char* bw_bits, const float* bw_stats, hipStream_t st);
+
+// Compute units a persistent grid (one or two resident blocks per CU: conv_regw.hip, conv_stem.hip, the streaming 1x1 kernel)
+// sizes itself to: the device's count, or the budget set by iif_set_cu_budget() when that is smaller (a rank that overlaps
+// RCCL's reduction kernels with backward leaves them a few CUs instead of making their blocks queue behind a persistent grid).
+int iif_persistent_cus();

@@ -1830,11 +1830,7 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
     }
     StreamPlan sp{0, 0, 0};
     if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_stream1x1(a, utap, (int)sizeof(T), OUTF32, &sp)) {
-        static const int cus = [] {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-            return n > 0 ? n : 256;
-        }();
+        const int cus = iif_persistent_cus();
         a.mtiles = (a.M + 127) / 128;
         a.ntiles = sp.slices;
         // one block per CU, in whole groups of 8 S (the S slices of a tile sequence on one XCD); a short layer takes fewer

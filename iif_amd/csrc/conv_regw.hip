@@ -252,11 +252,7 @@ int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_pa
     const bool epi = e != nullptr;
     if (epi && no_store) return IIF_EUNSUPPORTED;
     if (!src || !wgt || !dst || !iif_regw1x1_ok(M, K, N, epi)) return IIF_EUNSUPPORTED;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        return n > 0 ? n : 256;
-    }();
+    const int cus = iif_persistent_cus();
     int cw = 0, mt = 0;
     regw_plan(K, N, epi, &cw, &mt);
     const int S = N / (8 * cw);
@@ -550,11 +546,7 @@ int iif_regw3x3_launch(const void* src, const void* wgt, void* dst, float* bn_pa
                        int N, int H, int W, int C, int ldw, const signed char* tap_dy, const signed char* tap_dx, const unsigned char* tap_w,
                        const void* bw_x, const unsigned char* bw_bits, const float* bw_stats, hipStream_t st) {
     if (!src || !wgt || !dst || !iif_regw3x3_ok(N, H, W, C)) return IIF_EUNSUPPORTED;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        return n > 0 ? n : 256;
-    }();
+    const int cus = iif_persistent_cus();
     Regw3Args a{};
     a.src = (const unsigned char*)src; a.wgt = (const unsigned char*)wgt; a.dst = (unsigned char*)dst; a.bn_partial = bn_partial;
     a.bw_x = (const unsigned char*)bw_x; a.bw_bits = bw_bits; a.bw_stats = bw_stats;

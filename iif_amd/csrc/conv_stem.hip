@@ -177,11 +177,7 @@ bool iif_stem4x4_ok(int N, int H, int W) {
 int iif_stem4x4_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
                        int N, int H, int W, hipStream_t st) {
     if (!src || !wgt || !dst || !iif_stem4x4_ok(N, H, W)) return IIF_EUNSUPPORTED;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        return n > 0 ? n : 256;
-    }();
+    const int cus = iif_persistent_cus();
     StemArgs a{(const unsigned char*)src, (const unsigned char*)wgt, (unsigned char*)dst, bn_partial, N, H, W, N * H * W,
                N * H * W / SBM, 64, bn_row0};
     int grid = 2 * cus / 8 * 8;                          // two blocks per CU, whole groups of 8 (one per XCD)

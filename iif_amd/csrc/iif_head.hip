@@ -68,9 +68,13 @@ template <> struct RowIo<float> {
 template <> struct RowIo<unsigned short> {
     static constexpr int V = 8, DEPTH = 2;
     using Raw = u32x4;
+    // 8-byte aligned 16-byte vectors: the rows of a CONTIGUOUS [B, C] matrix with C % 8 == 4 (LVIS: 1204) start on alternate
+    // 8-byte boundaries; gfx950 runs with unaligned access enabled, so the access stays one dwordx4 (round 3 / 4 advice: such a
+    // matrix used to fall back to the streaming kernel)
+    typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
     static __device__ __forceinline__ Raw load_raw(const unsigned short* p, int nv) {
         u32x4 w = u32x4{0u, 0u, 0u, 0u};
-        if (nv == 8) w = *reinterpret_cast<const u32x4*>(p);
+        if (nv == 8) w = *reinterpret_cast<const u32x4_a8*>(p);
         else { const u32x2 h = *reinterpret_cast<const u32x2*>(p); w.x = h.x; w.y = h.y; }
         return w;
     }
@@ -82,7 +86,7 @@ template <> struct RowIo<unsigned short> {
         u32x4 w;
 #pragma unroll
         for (int q = 0; q < 4; ++q) w[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
-        if (nv == 8) *reinterpret_cast<u32x4*>(p) = w;
+        if (nv == 8) *reinterpret_cast<u32x4_a8*>(p) = w;
         else *reinterpret_cast<u32x2*>(p) = u32x2{w.x, w.y};
     }
 };
@@ -472,8 +476,11 @@ int launch_rows(CeArgs a, float* sm_out, int64_t ld_sm, hipStream_t st, bool* in
     const dim3 pgrid(grid.x < maxb ? grid.x : maxb);
     // rows in 16-byte lane vectors: 4 fp32 / 8 bf16 columns; a bf16 row may end on a half vector (C % 8 == 4: 1204)
     constexpr int V = RowIo<T>::V;
-    bool vec = (a.C % 4 == 0) && (a.C <= 2048) && (a.ldx % V == 0) && aligned(a.x, 16) && aligned(a.tab, 16);
-    if (MODE != 1 && a.dx) vec = vec && (a.lddx % V == 0) && aligned(a.dx, 16);
+    // (bf16 rows need 8-byte alignment only - RowIo<unsigned short>: a contiguous [B, 1204] matrix qualifies)
+    constexpr int RA = sizeof(T) == 2 ? 4 : V;            // row pitch granule in elements, = 8 / 16 bytes
+    constexpr int PA = sizeof(T) == 2 ? 8 : 16;
+    bool vec = (a.C % 4 == 0) && (a.C <= 2048) && (a.ldx % RA == 0) && aligned(a.x, PA) && aligned(a.tab, 16);
+    if (MODE != 1 && a.dx) vec = vec && (a.lddx % RA == 0) && aligned(a.dx, PA);
     if (MODE == 1) vec = vec && (ld_sm % 4 == 0) && aligned(sm_out, 16);
     if constexpr (MODE == 0) {       // plain CE on whole 16-byte vectors: the loop without mixup / weights / half tails
         if (vec && !a.tb && !a.roww && !a.clsw && a.C % V == 0) return launch_rows<T, 2>(a, sm_out, ld_sm, st, inline_reduce);

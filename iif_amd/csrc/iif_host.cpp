@@ -3,9 +3,41 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
+#include <hip/hip_runtime.h>
+
 #include "../../include/iif_amd.h"
 
 extern "C" const char* iif_version(void) { return "iif_amd 0.1.0 gfx950"; }
+
+// ---- compute-unit budget of the persistent grids (see common.h: iif_persistent_cus) -------------------------------------
+namespace {
+std::atomic<int> g_cu_budget{0};          // 0: the whole device
+int device_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        return v > 0 ? v : 256;
+    }();
+    return n;
+}
+}  // namespace
+
+int iif_persistent_cus() {
+    const int n = device_cus(), b = g_cu_budget.load(std::memory_order_relaxed);
+    return (b > 0 && b < n) ? b : n;
+}
+
+extern "C" int iif_set_cu_budget(int cus) {
+    if (cus < 0) return IIF_EINVAL;
+    // whole groups of 8 (one block per XCD and group), at least 64: below that the persistent kernels refuse small layers
+    if (cus != 0) { cus = cus / 8 * 8; if (cus < 64) cus = 64; }
+    g_cu_budget.store(cus, std::memory_order_relaxed);
+    return IIF_OK;
+}
+
+extern "C" int iif_get_cu_budget(void) { return iif_persistent_cus(); }
 
 namespace {
 

@@ -37,7 +37,7 @@ class ArenaReducer(object):
     gradient stays within a stated tolerance of the fp32 reduction)."""
 
     def __init__(self, grad_arena, boundaries, bucket_bytes=32 << 20, process_group=None, tail_bytes=2 << 20,
-                 mode="allreduce", bucket_dtype=torch.float32):
+                 mode="allreduce", bucket_dtype=torch.float32, cu_budget=None):
         """grad_arena: flat fp32 tensor; boundaries: sorted arena offsets where a bucket
         may start (tensor starts, in elements).  The LAST bucket (the arena's head: stem and
         first blocks) can only start when backward has finished, so its reduction is exposed:
@@ -81,6 +81,16 @@ class ArenaReducer(object):
         self.extra_streams = []    # other producer streams of gradients (the engine's wgrad stream)
         self.launched = 0          # collectives enqueued since construction (bench / tests read it)
         self.steps = 0
+        # Compute units the engine's persistent kernels (one resident block per CU) may take while this reducer's collectives
+        # are in flight (iif_set_cu_budget, include/iif_amd.h): RCCL's reduction kernels are ordinary workgroups that need a
+        # free CU each, and a grid that holds all 256 makes them queue until a block exits.  Default with world > 1: 240 (two CUs
+        # per XCD left over; RCCL runs up to 32 channels of one workgroup); 0 = no reservation.  IIF_REDUCER_CUS / cu_budget=
+        # override.  The price of the reservation on one GPU is in profiles/r5_reducer_cu_budget.txt; what it buys needs >= 2 GPUs.
+        import os
+        if cu_budget is None:
+            env = os.environ.get("IIF_REDUCER_CUS")
+            cu_budget = int(env) if env is not None else (240 if self.world > 1 else 0)
+        self.cu_budget = int(cu_budget)
         if bucket_dtype != torch.float32:
             self.set_bucket_dtype(bucket_dtype)
 
@@ -120,7 +130,7 @@ class ArenaReducer(object):
         return {"world": self.world, "mode": self.mode, "bucket_dtype": "bf16" if esz == 2 else "f32",
                 "buckets": len(self.buckets), "bucket_bytes": [int((hi - lo) * esz) for lo, hi in self.buckets],
                 "payload_bytes_per_step": int(self.arena.numel() * esz), "tail_bucket_bytes": int((self.buckets[-1][1] - self.buckets[-1][0]) * esz),
-                "collectives_launched": self.launched, "steps_reduced": self.steps}
+                "collectives_launched": self.launched, "steps_reduced": self.steps, "cu_budget": self.cu_budget}
 
     # ---- called by the engine -------------------------------------------------
     def begin(self):

@@ -533,11 +533,11 @@ class NativeResNet(nn.Module):
         self._saved = None
         return self
 
-    def make_reducer(self, bucket_bytes=32 << 20, process_group=None, mode="allreduce"):
+    def make_reducer(self, bucket_bytes=32 << 20, process_group=None, mode="allreduce", cu_budget=None):
         """Bucketed, backward-overlapped all-reduce of the gradient arena (see iif_amd.ddp)."""
         from .ddp import ArenaReducer
         bounds = [o for (o, _, _) in self._offsets.values()]
-        return ArenaReducer(self._grad_arena, bounds, bucket_bytes, process_group, mode=mode)
+        return ArenaReducer(self._grad_arena, bounds, bucket_bytes, process_group, mode=mode, cu_budget=cu_budget)
 
     def block_offsets(self):
         """Arena offset of the first parameter of the stem, of every block (forward order) and of the head."""
@@ -1417,14 +1417,27 @@ class _Plan(object):
         return dgrad_out
 
     def backward(self, reducer=None):
-        net = self.net
-        head = net._head
-        n = self.n
-        offs = net.block_offsets() if reducer is not None else None
+        offs = self.net.block_offsets() if reducer is not None else None
         self._bw_ready = None
+        budget = 0
         if reducer is not None:
             reducer.begin()
             reducer.extra_streams = [self.wg_stream] if self.wg_stream is not None else []
+            if reducer.world > 1 or reducer.force:
+                budget = int(getattr(reducer, "cu_budget", 0))
+        if budget:
+            # grids are sized when a launch is enqueued: every persistent kernel of this backward leaves the reduction its CUs
+            _lib.check(_lib.lib().iif_set_cu_budget(budget), "iif_set_cu_budget")
+        try:
+            self._backward(reducer, offs)
+        finally:
+            if budget:
+                _lib.lib().iif_set_cu_budget(0)
+
+    def _backward(self, reducer, offs):
+        net = self.net
+        head = net._head
+        n = self.n
         if self.wg_stream is not None:
             # fork the side streams off the compute stream before anything is recorded on them: under hipGraph capture
             # every event of the step then belongs to the capture (the first fence used to be recorded on a stream that

@@ -541,6 +541,14 @@ int iif_bn_backward_relu_recompute_pooled(const void* gy, const void* x, int dty
                                           int64_t workspace_bytes, const void* g_pool, const void* pool_x, int64_t pool_pixels,
                                           void* stream);
 
+/* Compute-unit budget of the persistent grids (the weights-in-registers kernels, the stem, the streaming 1x1 kernel size their
+ * grids to one or two resident blocks per CU).  Process-wide, default 0 = every CU of the device; a rank whose gradient
+ * all-reduce (RCCL kernels, classification/train.py:230-234 DDP) overlaps backward sets e.g. 240 so that the reduction's
+ * channels find free CUs instead of queueing behind a resident grid.  Rounded down to a multiple of 8, at least 64.
+ * iif_get_cu_budget: the count the next persistent launch will use. */
+int iif_set_cu_budget(int cus);
+int iif_get_cu_budget(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,6 +251,32 @@ def test_single_launch_loss_reduce_matches_two_launch(B, C, dt):
     assert rel_err(loss1, ref) <= REL
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 7, 1024, 5000])
+def test_contiguous_bf16_rows_with_half_vector_tail(B):
+    """A CONTIGUOUS bf16 [B, 1204] logits matrix (mmdet's LVIS head through custom._launch_ce): rows start on alternate 8-byte
+    boundaries.  It takes the vector kernel since round 5 (8-byte aligned 16-byte lanes, csrc/iif_head.hip RowIo): per-row
+    losses, gradient and scalar loss bit-identical to the same rows at a 16-byte pitch, and the loss against the oracle
+    (instance_segmentation/mmdet/models/losses/iif_loss.py:184-202)."""
+    dev = _dev()
+    C = 1204
+    counts = lt_counts(C, 2000)
+    pred, tgt = sample(B, C, counts, 3 * B + 1)
+    table = O.iif_tables(counts)["raw"].reshape(-1).to(dev)
+    p = pred.to(dev).to(torch.bfloat16).contiguous()
+    assert p.stride(0) == C and (p.data_ptr() % 16) == 0
+    pitched = torch.zeros(B, 1208, dtype=torch.bfloat16, device=dev)
+    pitched[:, :C] = p
+    ws = torch.zeros(1 + 2048, dtype=torch.int32, device=dev)
+    rc, loss, rows, d, st = _ce_raw(p, table, tgt.to(dev), scale=1.0 / B, ticket=ws)
+    assert rc == 0 and int(st.item()) == 0 and ws[0].item() == 0
+    rc2, loss2, rows2, d2, _ = _ce_raw(pitched[:, :C], table, tgt.to(dev), scale=1.0 / B, ticket=ws, ld=1208)
+    assert rc2 == 0
+    assert torch.equal(rows[:B], rows2[:B]) and torch.equal(d, d2) and loss.item() == loss2.item()
+    ref = O.iif_ce(p.float().cpu(), tgt, table.cpu().reshape(1, -1), None, "mean")
+    assert rel_err(loss, ref) <= REL
+
+
 def test_autograd_backward_twice_and_scaled():
     """The saved gradient is not modified by backward (retain_graph / two losses sharing the node / a loss scale)."""
     from iif_amd.custom import IIFLoss
