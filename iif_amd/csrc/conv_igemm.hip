@@ -1735,6 +1735,8 @@ inline bool use_stream1x1(const ConvArgs& a, bool utap, int esz, bool outf32, St
 // the chip (2 blocks per CU resident).
 inline bool use_bm256(const ConvArgs& a, bool utap, int esz) {
     if (!utap || esz != 2 || a.Cd <= 64 || a.groups > 1) return false;
+    static const bool no2 = getenv("IIF_CONV_NO_BM256_2SRC") != nullptr;      // (round-5 experiment knob)
+    if (no2 && a.src2) return false;
     // measured (scripts/bm_ab.sh): +13..39 % on K >= 1024 (3x3 at 128/256 channels, 1x1 from 1024 channels) when the
     // 256-row grid still offers >= 1.5 blocks per CU; short K loops and small grids are better off with 128 rows
     const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.Cd + 127) / 128);
