@@ -1735,7 +1735,9 @@ inline bool use_stream1x1(const ConvArgs& a, bool utap, int esz, bool outf32, St
 // the chip (2 blocks per CU resident).
 inline bool use_bm256(const ConvArgs& a, bool utap, int esz) {
     if (!utap || esz != 2 || a.Cd <= 64 || a.groups > 1) return false;
-    static const bool no2 = getenv("IIF_CONV_NO_BM256_2SRC") != nullptr;      // (round-5 experiment knob)
+    // IIF_CONV_NO_BM256_2SRC=1: the two-source data gradient of the BN3 algebra route on the 34 KB / 4-blocks-per-CU tile instead
+    // (it starts beside the weight-gradient blocks, profiles/r5_contention.txt; level in the step: 18.33 against 18.34 ms)
+    static const bool no2 = getenv("IIF_CONV_NO_BM256_2SRC") != nullptr;
     if (no2 && a.src2) return false;
     // measured (scripts/bm_ab.sh): +13..39 % on K >= 1024 (3x3 at 128/256 channels, 1x1 from 1024 channels) when the
     // 256-row grid still offers >= 1.5 blocks per CU; short K loops and small grids are better off with 128 rows
@@ -1881,6 +1883,9 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
         const unsigned sb = (unsigned)src_bytes, wb = (unsigned)wgt_bytes;
         if (utap) {
             // two-stage / 4-blocks-per-CU variant up to K = 2304
+            // (round 5, same-call A/B: the long-K launches of small grids - the 7 x 7 stage's 392-block data gradients with 64 K steps -
+            // on the three-stage kernel instead, one barrier per step and two steps of prefetch: 18.40 / 18.43 / 18.41 ms per step
+            // against 18.39 / 18.42 / 18.40; for every grid of <= 1 600 blocks 18.42 / 18.42 / 18.43.  Level: knob removed.)
             const bool shortk = sizeof(T) == 2 && !OUTF32 && a.ntaps * a.Cs <= kTwoStageK && (a.Cd & 7) == 0 && !a.bias;
             if constexpr (sizeof(T) == 2 && !OUTF32) {
                 if (shortk) {

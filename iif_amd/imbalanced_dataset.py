@@ -174,10 +174,9 @@ class LT_Dataset_Eval(Dataset):
 # ---------------------------------------------------------------------------------------------------
 # Host-side tensor transforms for the list datasets (torchvision is not in this image).  Same geometry and
 # statistics as the reference's pipelines (imbalanced_dataset.py:189-233: RandomResizedCrop(224) + horizontal
-# flip for training, Resize(256) + CenterCrop(224) for evaluation, per-dataset mean / std).  NOT rebuilt (CPU
-# augmentation outside the measured path, SURVEY 2a presets.py): the ColorJitter(0.4, 0.4, 0.4, 0) of the reference's
-# default training transform (imbalanced_dataset.py:196-212) and the auto-augment policies — an accuracy-parity gap on
-# real data, not a throughput one; iif_amd.train warns when --auto-augment is given.
+# flip for training, Resize(256) + CenterCrop(224) for evaluation, per-dataset mean / std), its ColorJitter(0.4, 0.4, 0.4,
+# hue 0.25 for iNaturalist / 0 otherwise) and, with ``auto_augment`` = "imagenet" / "randaugment" / "cifar", the policy that
+# REPLACES the jitter there (imbalanced_dataset.py:210-225) - restated on tensors in iif_amd/augment.py (parity unpinned: no PIL here).
 LT_LISTS = {   # initialisers.py:83-100: (classes, train list, eval list) relative to the reference's working directory
     "imagenet_lt": (1000, "../../../datasets/ImageNet-LT/ImageNet_LT_train.txt", "../../../datasets/ImageNet-LT/ImageNet_LT_test.txt"),
     "inat18": (8142, "../../../datasets/train_val2018/iNaturalist18_train.txt", "../../../datasets/train_val2018/iNaturalist18_val.txt"),
@@ -186,8 +185,21 @@ LT_LISTS = {   # initialisers.py:83-100: (classes, train list, eval list) relati
 
 
 class TensorTransform(object):
-    def __init__(self, dset_name, train, size=224, seed=0):
+    def __init__(self, dset_name, train, size=224, seed=0, auto_augment=None, color_jitter=True):
+        from . import augment
         inat = dset_name == "inat18"
+        self.colour = None
+        if train:
+            if auto_augment == "imagenet":
+                self.colour = augment.AutoAugmentPolicy("imagenet")
+            elif auto_augment == "randaugment":
+                self.colour = augment.RandAugment()
+            elif auto_augment in ("cifar", "cifar10"):
+                self.colour = augment.AutoAugmentPolicy("cifar10")
+            elif auto_augment not in (None, "", "None"):
+                raise ValueError("--auto-augment %r: the reference knows imagenet, randaugment and cifar" % (auto_augment,))
+            elif color_jitter:
+                self.colour = augment.ColorJitter(0.4, 0.4, 0.4, 0.25 if inat else 0.0)
         self.mean = torch.tensor([0.466, 0.471, 0.380] if inat else [0.485, 0.456, 0.406]).view(3, 1, 1)
         self.std = torch.tensor([0.195, 0.194, 0.192] if inat else [0.229, 0.224, 0.225]).view(3, 1, 1)
         self.train, self.size = train, size
@@ -237,6 +249,8 @@ class TensorTransform(object):
             t = self._resize(t[:, top:top + ch, left:left + cw], s, s)
             if r() < 0.5:
                 t = t.flip(-1)
+            if self.colour is not None:                  # on the [0, 1] image, before normalisation, as the reference composes it
+                t = self.colour(t.clamp(0.0, 1.0), gen)
         else:                                            # Resize(256 * s / 224) on the short side + CenterCrop(s)
             short = int(round(s * 256 / 224))
             nh, nw = (short, max(int(round(w * short / h)), short)) if h <= w else (max(int(round(h * short / w)), short), short)
@@ -250,7 +264,8 @@ def get_dataset_lt(args, num_classes, train_txt, eval_txt, loader=None):
     """imbalanced_dataset.py:177-259 without its samplers (built by the caller): the two list datasets, the
     evaluation one remapped with the training class map."""
     size = getattr(args, "image_size", 224)
-    train = LT_Dataset(args.data_path, train_txt, num_classes, transform=TensorTransform(args.dset_name, True, size, args.rand_number),
+    train = LT_Dataset(args.data_path, train_txt, num_classes,
+                       transform=TensorTransform(args.dset_name, True, size, args.rand_number, auto_augment=getattr(args, "auto_augment", None)),
                        loader=loader)
     ev = LT_Dataset_Eval(args.data_path, eval_txt, train.class_map, num_classes, transform=TensorTransform(args.dset_name, False, size),
                          loader=loader)

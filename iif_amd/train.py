@@ -144,10 +144,10 @@ def main(args):
         raise SystemExit("iif_amd.train needs an MI355X: the native engine has no CPU path")
     device = torch.device(args.device)
     print(args)
-    if getattr(args, "auto_augment", None):
+    if getattr(args, "auto_augment", None) and not getattr(args, "data_path", None):
         import warnings
-        warnings.warn("--auto-augment %r is accepted for command-line compatibility but NOT applied: the host-side tensor "
-                      "transforms rebuild crop / flip / resize only (iif_amd/imbalanced_dataset.py)" % (args.auto_augment,))
+        warnings.warn("--auto-augment %r applies to the list datasets (--data-path); the synthetic long-tailed data of this run "
+                      "is not augmented" % (args.auto_augment,))
     dataset, num_classes, data_loader, data_loader_test, train_sampler = initialisers.get_data(args)
     print("Creating model")
     model = build_model(args, num_classes)

@@ -1,0 +1,9 @@
+#!/bin/bash
+mkdir -p gpurun_out/r5
+B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-fp32-step --no-kernel-events"
+run() { label=$1; shift; env "$@" $B 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/$label: /"; }
+for i in 1 2 3; do
+  run "default" X=1
+  run "3-stage for <= 512 blocks" IIF_CONV_SMALLGRID_3STAGE=512
+  run "3-stage for <= 1600 blocks" IIF_CONV_SMALLGRID_3STAGE=1600
+done 2>&1 | tee gpurun_out/r5/ab_d.txt
