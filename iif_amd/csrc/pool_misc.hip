@@ -527,7 +527,9 @@ int iif_maxpool_backward(const void* gy, const uint8_t* argmax, int dtype, int n
     hipStream_t st = as_stream(stream);
     const int64_t tot = (int64_t)n * h * w * (c / (dtype == IIF_F32 ? 4 : 8));
     if (k == 3 && stride == 2 && pad == 1 && (int64_t)n * h < 0x7fffffffLL) {
-        const int rowblocks = (int)((int64_t)n * h < 16384 ? (int64_t)n * h : 16384);
+        // one image row per block, every row its own block (round 5: a grid capped at 16 384 blocks walked 28 672 rows in two
+        // uneven passes, and stores of a looping grid spread over DRAM pages - bn.hip, stream_grid)
+        const int rowblocks = (int)((int64_t)n * h);
         IIF_BY_DTYPE(dtype,
             hipLaunchKernelGGL(maxpool321_bwd_kernel<float>, dim3(rowblocks), dim3(256), 0, st, (const float*)gy, argmax, n, h, w, c, ho, wo, (float*)dx),
             hipLaunchKernelGGL(maxpool321_bwd_kernel<unsigned short>, dim3(rowblocks), dim3(256), 0, st, (const unsigned short*)gy, argmax, n, h, w, c, ho, wo, (unsigned short*)dx))
