@@ -77,7 +77,7 @@ SIGNATURES = {
     "iif_conv_igemm_bn_relu": [_P, _P, _P, _P, _P, _P, _P, _P],
     "iif_conv_igemm_dgrad_masksum": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "iif_conv_igemm_dgrad2_bnbwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
-    "iif_bn3_algebra_prep": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P],
+    "iif_bn3_algebra_prep": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _P],
     "iif_bn3_algebra_prep_scratch_floats": [_I, _I],
     "iif_bn3_algebra_dw": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P],
     "iif_conv_pack_fragments": [_P, _P, _I, _I, _P, _P],

@@ -65,10 +65,10 @@ template <int c>
 __global__ void __launch_bounds__(256) bn3_prep_kernel(const float* P, int ldp, const unsigned short* W, int ldw, const float* partial,
                                                        int nrows, int rows_per_slice, const float* stats, const float* gamma, int C,
                                                        double count, float* slices, int* tickets, float* coef, float* dgamma, float* dbeta,
-                                                       unsigned short* wt, int ldwt, float* slab, float* bias_slab) {
+                                                       unsigned short* wt, int ldwt, float* slab, float* bias_slab, float* corr_slab) {
     __shared__ __attribute__((aligned(1024))) unsigned char tiles[2 * kGC * 512];      // W and B o W, [64][c] bf16 each
     __shared__ double shd[256];
-    __shared__ float cA[kGC], cB[kGC], cD[kGC], ssum[2 * kGC];
+    __shared__ float cA[kGC], cB[kGC], cD[kGC], cE[kGC], cM[kGC], ssum[2 * kGC];
     __shared__ int last;
     const int g = blockIdx.x, sl = blockIdx.y, S = gridDim.y;
     const int ch0 = g * kGC, C2 = 2 * C;
@@ -173,18 +173,20 @@ __global__ void __launch_bounds__(256) bn3_prep_kernel(const float* P, int ldp, 
     __syncthreads();
     if (sub4 == 0) {
         const int lc = lc4, ch = ch0 + lc;
-        float A = 0.f, B = 0.f, D = 0.f;
+        float A = 0.f, B = 0.f, D = 0.f, E = 0.f, Mu = 0.f;
         if (ch < C) {
             const float mu = mu_, invstd = invstd_;
             const float s1 = ssum[lc];
             const float s2 = P ? invstd * (pw - mu * s1) : ssum[kGC + lc];        // sum g~ xhat
             A = gamma_ * invstd;
             B = -A * (float)((double)s2 / count) * invstd;
-            D = -A * (float)((double)s1 / count) - B * mu;
+            E = -A * (float)((double)s1 / count);
+            D = E - B * mu;
+            Mu = mu;
             dbeta[ch] = s1; dgamma[ch] = s2;
             coef[ch] = A; coef[C + ch] = B; coef[2 * C + ch] = D;
         }
-        cA[lc] = A; cB[lc] = B; cD[lc] = D;
+        cA[lc] = A; cB[lc] = B; cD[lc] = D; cE[lc] = E; cM[lc] = Mu;
     }
     __syncthreads();
     // B o W beside it
@@ -203,18 +205,31 @@ __global__ void __launch_bounds__(256) bn3_prep_kernel(const float* P, int ldp, 
     // the g~ half of the stacked weights: wt[j][ch0 + lane] = bf16(A W[ch][j]); a wave writes 128 contiguous bytes per j
     {
         const int lane = t & 63, wv = t >> 6;
-        if (ch0 + lane < C) {
-            const float A = cA[lane];
+        {
+            // corr_slab[g][j] = sum_ch sum(g~)[ch] * (bf16(A W[ch][j]) - A W[ch][j]): what the rounding of this half of the stacked
+            // weights adds to the COLUMN SUM of the data gradient (see bn3_gm_finish_kernel)
+            const bool chv2 = ch0 + lane < C;
+            const float A = cA[lane], s1 = chv2 ? ssum[lane] : 0.f;
             for (int j = wv; j < c; j += 4) {
                 const unsigned short wb = *reinterpret_cast<const unsigned short*>(WT + swz_addr(lane, j * 2, rb));
-                wt[(int64_t)j * ldwt + ch0 + lane] = f32_to_bf16_bits(A * bf16_bits_to_f32(wb));
+                const float v = A * bf16_bits_to_f32(wb);
+                const unsigned short r = f32_to_bf16_bits(v);
+                if (chv2) wt[(int64_t)j * ldwt + ch0 + lane] = r;
+                const float e = wsum(chv2 ? s1 * (bf16_bits_to_f32(r) - v) : 0.f);
+                if (lane == 0) corr_slab[(int64_t)g * c + j] = e;
             }
         }
-        // bias_slab[g][jo] = sum_ch D[ch] W[ch][jo]
+        // bias_slab[g][jo] = sum_ch D[ch] W[ch][jo], D = E - B mu, with the B W product taken AS THE MATRIX PIPE SEES IT
+        // (bf16(B W), the BT tile): the a2 half of the stacked weights is sum_ch bf16(B W[ch][jo]) W[ch][i], and only with the
+        // same rounded factor does  sum_i colsum(a2)[i] G[jo][i] + M bias[jo]  cancel (mu[ch] = W[ch] . colsum(a2) / M); the
+        // rounding of B W times mu - the same sign on every pixel - otherwise lands in the data gradient's column sums
         if (t < c) {
             float bsum = 0.f;
-            for (int ch = 0; ch < kGC; ++ch)
-                bsum += cD[ch] * bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(WT + swz_addr(ch, t * 2, rb)));
+            for (int ch = 0; ch < kGC; ++ch) {
+                const float w = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(WT + swz_addr(ch, t * 2, rb)));
+                const float bw = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(BT + swz_addr(ch, t * 2, rb)));
+                bsum += cE[ch] * w - cM[ch] * bw;
+            }
             bias_slab[(int64_t)g * c + t] = bsum;
         }
     }
@@ -254,24 +269,47 @@ __global__ void __launch_bounds__(256) bn3_prep_kernel(const float* P, int ldp, 
 // sum of the channel-group slabs of bn3_prep_kernel in a fixed order (deterministic), bf16 conversion into the stacked weights
 // (G = the slab count as a template parameter: with a run-time trip count every slab was one dependent round trip - load, wait, add -
 // i.e. 16 of them at C = 1024 on the compute stream's critical path, 12 us on average and 45 at worst inside the step; now one.)
+//
+// Column-sum compensation (round 5).  In exact arithmetic the data gradient da = [g~ | a2] [A o W ; W^T diag(B) W]^T + D W sums
+// to ZERO over the pixels in every column (BN backward has sum_m dy = 0 per channel).  The stacked weights are bf16: each
+// rounding error delta is multiplied by the SAME-signed column sums of its operand (a2 is a ReLU output: all >= 0; g~ is gated),
+// so sum_m da[m][j] picks up  sum_i colsum(a2)[i] delta2[j][i] + sum_ch colsum(g~)[ch] delta1[j][ch]  - coherent over all
+// pixels, and what is left of the upstream column sums (d beta of the BN below, the stem's above all) after cancellation is
+// small: 32 % on bn1's bias gradient through the shortcut of layer1.0.  Both column sums are known here, so the fp32 bias
+// absorbs the error:  bias[j] = D W[j] - (those two sums) / M.  colsum2 == nullptr: no compensation (the round-3 / 4 behaviour).
+// Grid c * c / 256 blocks; a block owns whole rows j (256 / c of them).
 template <int G>
-__global__ void __launch_bounds__(256) bn3_gm_finish_kernel(const float* slab, const float* bias_slab, int slices, int C, int c,
-                                                            unsigned short* wt, int ldwt, float* bias) {
+__global__ void __launch_bounds__(256) bn3_gm_finish_kernel(const float* slab, const float* bias_slab, const float* corr_slab, int slices,
+                                                            int C, int c, const float* colsum2, float inv_count, unsigned short* wt,
+                                                            int ldwt, float* bias) {
+    __shared__ float red[4];
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int cc = c * c;
-    const int qq = q < cc ? q : 0, qb = q < c ? q : 0;
-    float v[G], vb[G];
+    const int j = q / c, i = q - j * c;                    // (c * c is a multiple of 256: every thread has an element)
+    float v[G], vb[G], vc[G];
 #pragma unroll
     for (int k = 0; k < G; ++k) {                                   // unconditional, clamped: all in flight together
         const int kk = k < slices ? k : 0;
-        v[k] = slab[(int64_t)kk * cc + qq];
-        vb[k] = bias_slab[(int64_t)kk * c + qb];
+        v[k] = slab[(int64_t)kk * cc + q];
+        vb[k] = bias_slab[(int64_t)kk * c + j];
+        vc[k] = corr_slab[(int64_t)kk * c + j];
     }
-    float s = 0.f, sb = 0.f;
+    const float cs = colsum2 ? colsum2[i] : 0.f;
+    float s = 0.f, sb = 0.f, sc = 0.f;
 #pragma unroll
-    for (int k = 0; k < G; ++k) { s += k < slices ? v[k] : 0.f; sb += k < slices ? vb[k] : 0.f; }
-    if (q < cc) wt[(int64_t)(q / c) * ldwt + C + q % c] = f32_to_bf16_bits(s);
-    if (q < c) bias[q] = sb;
+    for (int k = 0; k < G; ++k) { s += k < slices ? v[k] : 0.f; sb += k < slices ? vb[k] : 0.f; sc += k < slices ? vc[k] : 0.f; }
+    const unsigned short r = f32_to_bf16_bits(s);
+    wt[(int64_t)j * ldwt + C + i] = r;
+    // row sum of colsum2[i] * (rounded - exact): lanes of a wave, then the c / 64 waves of the row (fixed order)
+    const float e = wsum(cs * (bf16_bits_to_f32(r) - s));
+    const int wave = threadIdx.x >> 6, wpr = c >> 6;       // waves per row: 1 / 2 / 4
+    if ((threadIdx.x & 63) == 0) red[wave] = e;
+    __syncthreads();
+    if (i == 0) {
+        float es = 0.f;
+        for (int w = 0; w < wpr; ++w) es += red[wave + w];
+        bias[j] = colsum2 ? sb - (es + sc) * inv_count : sb;
+    }
 }
 
 // dW[ch][j] = A P[ch][j] + B sum_i W[ch][i] Gram[i][j] + D csum[j].  Grid (C / 64, c / 32); c in {64, 128, 256}.
@@ -357,12 +395,13 @@ extern "C" {
 
 int64_t iif_bn3_algebra_prep_scratch_floats(int C, int c) {
     const int64_t G = (C + kGC - 1) / kGC;
-    return (int64_t)64 * 2 * C + G * ((int64_t)c * c + c);
+    return (int64_t)64 * 2 * C + G * ((int64_t)c * c + 2 * c);
 }
 
 int iif_bn3_algebra_prep(const float* P, int ldp, const void* w_bf16, int ldw, const float* partial, int n_partials,
                          const float* stats, const float* gamma, int C, int c, int64_t m, float* coef, float* dgamma, float* dbeta,
-                         void* wt, int ldwt, float* bias, float* scratch, int64_t scratch_floats, int32_t* tickets, void* stream) {
+                         void* wt, int ldwt, float* bias, float* scratch, int64_t scratch_floats, int32_t* tickets, const float* colsum2,
+                         void* stream) {
     if (!w_bf16 || !partial || !stats || !gamma || !coef || !dgamma || !dbeta || !wt || !bias || !scratch || !tickets || C <= 0 ||
         c <= 0 || m <= 0 || n_partials <= 0)
         return IIF_EINVAL;
@@ -376,14 +415,15 @@ int iif_bn3_algebra_prep(const float* P, int ldp, const void* w_bf16, int ldw, c
     const int S = (n_partials + rps - 1) / rps;
     float* slab = scratch + (int64_t)64 * 2 * C;
     float* bias_slab = slab + (int64_t)G * c * c;
+    float* corr_slab = bias_slab + (int64_t)G * c;
     hipStream_t st = as_stream(stream);
 #define IIF_PREP(CC) hipLaunchKernelGGL(bn3_prep_kernel<CC>, dim3(G, S), dim3(256), 0, st, P, ldp, (const unsigned short*)w_bf16, ldw, partial, \
-                                        n_partials, rps, stats, gamma, C, (double)m, scratch, tickets, coef, dgamma, dbeta, (unsigned short*)wt, ldwt, slab, bias_slab)
+                                        n_partials, rps, stats, gamma, C, (double)m, scratch, tickets, coef, dgamma, dbeta, (unsigned short*)wt, ldwt, slab, bias_slab, corr_slab)
     if (c == 64) IIF_PREP(64); else if (c == 128) IIF_PREP(128); else IIF_PREP(256);
 #undef IIF_PREP
     IIF_LAUNCH_CHECK();
-#define IIF_GMF(GG) hipLaunchKernelGGL(bn3_gm_finish_kernel<GG>, dim3((c * c + 255) / 256), dim3(256), 0, st, slab, bias_slab, G, C, c, \
-                                       (unsigned short*)wt, ldwt, bias)
+#define IIF_GMF(GG) hipLaunchKernelGGL(bn3_gm_finish_kernel<GG>, dim3(c * c / 256), dim3(256), 0, st, slab, bias_slab, corr_slab, G, C, c, \
+                                       colsum2, (float)(1.0 / (double)m), (unsigned short*)wt, ldwt, bias)
     if (G <= 4) IIF_GMF(4); else if (G <= 8) IIF_GMF(8); else if (G <= 16) IIF_GMF(16); else if (G <= 32) IIF_GMF(32); else IIF_GMF(64);
 #undef IIF_GMF
     IIF_LAUNCH_CHECK();

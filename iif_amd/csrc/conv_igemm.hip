@@ -326,15 +326,26 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x4 (&
     constexpr int CI = BN / 32;
     constexpr int NT = BM * 2;                  // threads of the block (4 or 8 waves)
     constexpr int PITCH = BN * 2 + 16;
+    // The fp32 per-channel bias (the D W term of the BN3 algebra's data gradient) joins the ACCUMULATOR, before the one rounding
+    // to bf16.  Round 3/4 added it to the staged bf16 tile and rounded again: a constant added to values on the bf16 grid loses
+    // the SAME fraction of an ulp on every pixel of equal exponent - 1.3 instead of 0.35 on a column sum of 392 elements that is
+    // zero in exact arithmetic (scripts/dbg_colsum.py), and d beta of the BN below is exactly that column sum.
+    f32x4 sb4[CI];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+        const int n = n0 + wn * (BN / 2) + ci * 16 + fc * 4;
+        sb4[ci] = (a.sbias && n < a.Cd) ? *reinterpret_cast<const f32x4*>(a.sbias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     __syncthreads();                            // every wave is done reading the last stage
 #pragma unroll
     for (int pj = 0; pj < 4; ++pj)
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) {
             const int row = wm * 64 + pj * 16 + fr, ch = wn * (BN / 2) + ci * 16 + fc * 4;
+            const f32x4 v = acc[ci][pj] + sb4[ci];
             u32x2 w;
-            w.x = pack_bf16x2(acc[ci][pj].x, acc[ci][pj].y);
-            w.y = pack_bf16x2(acc[ci][pj].z, acc[ci][pj].w);
+            w.x = pack_bf16x2(v.x, v.y);
+            w.y = pack_bf16x2(v.z, v.w);
             *reinterpret_cast<u32x2*>(smem + row * PITCH + ch * 2) = w;
         }
     __syncthreads();
@@ -363,13 +374,6 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
     if (a.aff && n < a.Cd) {                        // never together with bw_x: the same registers carry (a, b)
 #pragma unroll
         for (int q = 0; q < 8; ++q) { bmean[q] = a.aff[2 * a.Cd + n + q]; bistd[q] = a.aff[3 * a.Cd + n + q]; }
-    }
-    float sb[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) sb[q] = 0.f;
-    if (a.sbias && n < a.Cd) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) sb[q] = a.sbias[n + q];
     }
     if (n < a.Cd) {
         // Everything a batch of RBATCH rows needs from memory (residual, its ReLU bits, the upstream bits, the upstream x) is
@@ -425,11 +429,6 @@ __device__ __forceinline__ void staged_drain(const ConvArgs& a, unsigned char* s
                 const int row = r0 + (b0 + i) * RPP;
                 const int64_t o = ob[i];
                 u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PITCH + chunk * 16);
-                if (a.sbias) {                          // block-uniform
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        v[q] = pack_bf16x2(bf16_bits_to_f32(v[q] & 0xffffu) + sb[2 * q], __uint_as_float(v[q] & 0xffff0000u) + sb[2 * q + 1]);
-                }
                 if (a.aff) {                            // block-uniform: BN affine + identity + ReLU of the block output
                     const u32x4 rr = rrv[i];
                     unsigned bits = 0;

@@ -492,14 +492,15 @@ def bn3_algebra_prep_scratch(C, c, device):
     return torch.empty(lib().iif_bn3_algebra_prep_scratch_floats(C, c), dtype=torch.float32, device=device)
 
 
-def bn3_algebra_prep(P, w_bf16, c, partial, n_partials, stats, gamma, m, coef, dgamma, dbeta, wt, bias, scratch, tickets):
+def bn3_algebra_prep(P, w_bf16, c, partial, n_partials, stats, gamma, m, coef, dgamma, dbeta, wt, bias, scratch, tickets, colsum2=None):
     """P [C, ldp] fp32 (or None: sum g~ xhat comes from the second half of the partial rows), w_bf16 [C, ldw] (c valid
     columns), the producer's partial rows -> coef [3, C], dgamma, dbeta, the stacked bf16 weights wt [c, ldwt >= C + c]
-    (g~ half and a2 half) and bias [c].  tickets: int32[64], zero before the first call (self-resetting)."""
+    (g~ half and a2 half) and bias [c].  tickets: int32[64], zero before the first call (self-resetting).  colsum2 [c]:
+    column sums of the data gradient's second source (a2): the bias then keeps the data gradient's column sums at zero."""
     C = w_bf16.shape[0]
     check(lib().iif_bn3_algebra_prep(ptr(P), 0 if P is None else P.stride(0), ptr(w_bf16), w_bf16.stride(0), ptr(partial), n_partials, ptr(stats),
                                      ptr(gamma), C, c, int(m), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(wt), wt.stride(0), ptr(bias),
-                                     ptr(scratch), scratch.numel(), ptr(tickets), stream_ptr()), "iif_bn3_algebra_prep", tickets)
+                                     ptr(scratch), scratch.numel(), ptr(tickets), ptr(colsum2), stream_ptr()), "iif_bn3_algebra_prep", tickets)
 
 
 def bn3_algebra_dw(P, w_bf16, c, gram, csum, coef, dW):

@@ -844,6 +844,30 @@ class _Plan(object):
         if self.wg_stream is not None and ds_units and dt == torch.bfloat16 and not os.environ.get("IIF_NO_BWD_SIDE"):
             self.ds_stream = torch.cuda.Stream(device=dev)
             self.bn_ws_ds = ops.bn_workspace(max(u.n * u.ho * u.wo for u in ds_units), max(u.conv.cout for u in ds_units), dev)
+        # BN backward of a stride-1 convolutional shortcut by the same algebra as bn3 (round 5): the shortcut's BN sees the SAME
+        # gated block-output gradient g~ as bn3, and its input x_in is the narrow block input, so
+        #     d x_in (shortcut part) = [g~ | x_in] [A o Wd ; Wd^T diag(B) Wd]^T + D Wd,   sum g~ y_d = rowdot(g~^T x_in, Wd)
+        # replaces the reduction pass, the normalisation pass and the data gradient over the C-wide shortcut output
+        # (3.1 -> 1.3 GB at 56 x 56, all of it on the shortcut stream, which the compute stream used to wait ~120 us for at the
+        # end of layer1.0).  Units: 1 x 1 / stride 1 shortcuts of a block whose last unit takes the bn3 algebra (ResNet-50: layer1.0).
+        self.ds_alg = {}
+        if self.ds_stream is not None and self.alg3_units and not os.environ.get("IIF_NO_DS_ALGEBRA"):
+            for b in self.blocks:
+                du = b.get("ds")
+                if du is None or "se" in b or b["units"][-1] not in self.alg3_units:
+                    continue
+                cv = du.conv
+                if (cv.k == 1 and cv.stride == 1 and cv.groups == 1 and cv.cin in (64, 128, 256) and cv.cout % 64 == 0 and cv.cout <= 4096
+                        and _dma_ok(du.x) and _dma_ok(b["inp"]) and du.n * du.ho * du.wo < (1 << 30)):
+                    F = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)   # noqa: E731
+                    C, c = cv.cout, cv.cin
+                    self.ds_alg[id(du)] = {
+                        "P": F(C, cv.ldw), "coef": F(3, C), "bias": F(c), "wt": torch.zeros((c, C + c), dtype=dt, device=dev),
+                        "scr": torch.empty(ops.lib().iif_bn3_algebra_prep_scratch_floats(C, c), dtype=torch.float32, device=dev),
+                        "tickets": torch.zeros(64, dtype=torch.int32, device=dev), "gram": F(c, cv.ldw), "csum": F(2, c),
+                        "rows": torch.empty(self.bw_partial.numel(), dtype=torch.float32, device=dev),
+                        "ws": torch.empty(64 << 20, dtype=torch.uint8, device=dev),
+                        "ws_sum": ops.bn_workspace(du.n * du.ho * du.wo, c, dev)}
 
     def _finish_weight_plan(self):
         """One arena for every dense transposed weight copy ([cin][k*k*cout], the data-gradient operand) and
@@ -1392,10 +1416,13 @@ class _Plan(object):
             ops.conv_wgrad(u.src, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=self.a3_ws)
         wt = A["wt"][:c * (C + c)].view(c, C + c)
         coef = A["coef"].view(-1)[:3 * C].view(3, C)
-        ops.bn3_algebra_prep(P if pure else None, wb, c, self.bw_partial, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt,
-                             A["bias"][:c], A["scr"], A["tickets"])
-        # the weight gradient needs Gram / colsum (issued a block ahead) and nothing on the critical path needs it
+        # colsum(a2) (issued a block ahead with the Gram matrix) keeps the data gradient's column sums at zero through the bf16
+        # rounding of the stacked weights (bn3_gm_finish_kernel); the weight gradient needs Gram / colsum too, off the critical path
         gram_ev = Ag["ev"]
+        if gram_ev is not None:
+            torch.cuda.current_stream().wait_event(gram_ev)
+        ops.bn3_algebra_prep(P if pure else None, wb, c, self.bw_partial, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt,
+                             A["bias"][:c], A["scr"], A["tickets"], colsum2=Ag["csum"].view(-1)[:c])
 
         def finish_dw():
             if not pure:
@@ -1416,13 +1443,37 @@ class _Plan(object):
         self._bw_ready = (up, nt2)
         return dgrad_out
 
+    def _ds_algebra(self, du, D, gt, x_in, nt, gin_ds):
+        """Backward of a stride-1 convolutional shortcut (1x1 conv + BN, no ReLU of its own) from the gated block-output gradient
+        ``gt`` without reading the shortcut's output (see ``ds_alg`` in __init__).  Runs on the shortcut stream; ``gin_ds`` receives
+        the gradient w.r.t. the block input through the shortcut, the first unit's data gradient adds it as its residual."""
+        cv, bn = du.conv, du.bn
+        C, c = cv.cout, cv.cin
+        m = du.n * du.ho * du.wo
+        g4 = gt.view(du.n, du.ho, du.wo, C)
+        P = D["P"].view(-1)[:C * cv.ldw].view(C, cv.ldw)
+        ops.bn_stats_sums(x_in.view(-1, c), D["csum"], D["ws_sum"])
+        ops.conv_wgrad(x_in, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=D["ws"])
+        coef = D["coef"]
+        ops.bn3_algebra_prep(P, du.w, c, D["rows"], nt, du.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, D["wt"], D["bias"],
+                             D["scr"], D["tickets"], colsum2=D["csum"].view(-1)[:c])
+        ops.conv_dgrad2_bnbwd(g4, x_in, D["wt"], D["bias"], gin_ds)
+        done = torch.cuda.Event()
+        done.record()                       # what the compute stream waits for: the data gradient
+        # the weight gradient: dWd = A P + B Wd Gram(x_in) + D (x) colsum(x_in); nothing waits for it but the gradient
+        # reduction (the reducer waits for this stream too) and the end of backward
+        gram = D["gram"].view(-1)[:c * cv.ldw].view(c, cv.ldw)
+        ops.conv_wgrad(x_in, x_in, 1, 1, 1, 0, ldw=cv.ldw, out=gram, workspace=D["ws"])
+        ops.bn3_algebra_dw(P, du.w, c, gram, D["csum"].view(-1)[:c], coef, cv._g2d)
+        return done
+
     def backward(self, reducer=None):
         offs = self.net.block_offsets() if reducer is not None else None
         self._bw_ready = None
         budget = 0
         if reducer is not None:
             reducer.begin()
-            reducer.extra_streams = [self.wg_stream] if self.wg_stream is not None else []
+            reducer.extra_streams = [st for st in (self.wg_stream, self.ds_stream if self.ds_alg else None) if st is not None]
             if reducer.world > 1 or reducer.force:
                 budget = int(getattr(reducer, "cu_budget", 0))
         if budget:
@@ -1505,8 +1556,6 @@ class _Plan(object):
             par = bi % self.wg_lag
             self._wgrad_fence(bi)
             self._cur_block = bi
-            if bi > 0 and self.blocks[bi - 1]["units"][-1] in self.alg3_units:
-                self._bn3_gram_async(self.blocks[bi - 1]["units"][-1], bi - 1)
             gin = self._gbuf(("gin", tuple(inp.shape), bi % (self.wg_lag + 1)), inp.shape)
             dkey = ("d", tuple(last.src.shape), len(units) - 1, par)
             # The block's ReLU gates g on both paths.  With a convolutional shortcut or a plain identity no masked
@@ -1524,14 +1573,31 @@ class _Plan(object):
             if "ds" in b and lazy_mask and self.ds_stream is not None:
                 du = b["ds"]
                 gin_ds = self._gbuf(("ginds", tuple(inp.shape), par), inp.shape)
+                rdy = self._bw_ready
+                D = self.ds_alg.get(id(du))
+                by_algebra = D is not None and rdy is not None and rdy[0] is last and len(rdy) == 3
+                if by_algebra:
+                    # the producer's partial rows (sum g~ per tile) are overwritten by the next fused data gradient of the compute
+                    # stream: the shortcut stream works from a copy
+                    nrow = rdy[1] * 2 * last.conv.cout
+                    D["rows"][:nrow].copy_(self.bw_partial[:nrow])
                 ev = torch.cuda.Event()
                 ev.record()
                 with torch.cuda.stream(self.ds_stream):
                     self.ds_stream.wait_event(ev)
-                    self._unit_backward(du, g, last.y, mask_bits=last.bits, keep_gy=True, dgrad_out=gin_ds, par=par,
-                                        ws=self.bn_ws_ds, dxkey="dxds")
-                    ds_done = torch.cuda.Event()
-                    ds_done.record()
+                    if by_algebra:
+                        ds_done = self._ds_algebra(du, D, g, inp, rdy[1], gin_ds)
+                    else:
+                        self._unit_backward(du, g, last.y, mask_bits=last.bits, keep_gy=True, dgrad_out=gin_ds, par=par,
+                                            ws=self.bn_ws_ds, dxkey="dxds")
+                        ds_done = torch.cuda.Event()
+                        ds_done.record()
+            # Gram / column sums of the PREVIOUS block's a2 (forward data, needed by that block's weight gradient only): queued on the
+            # shortcut stream BEHIND this block's shortcut branch, which the compute stream waits for at the end of the block (round 5:
+            # in front of it, it delayed the branch by its ~100-150 us: the compute stream idled 120-230 us at every downsample block,
+            # profiles/r5_b_step_timeline.txt)
+            if bi > 0 and self.blocks[bi - 1]["units"][-1] in self.alg3_units:
+                self._bn3_gram_async(self.blocks[bi - 1]["units"][-1], bi - 1)
             if "se" in b:
                 G = self._se_backward(b, last, g, par)
                 d = self._unit_backward(last, G, None, par=par, dgrad_out=self._gbuf(dkey, last.src.shape),

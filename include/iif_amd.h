@@ -402,7 +402,10 @@ int iif_conv3x3_frag_ok(const iif_conv_desc* d);
  *                                 wt [c][ldwt >= C + c]: wt[j][ch] = A[ch] W[ch][j], wt[j][C + i] = sum_ch bf16(B[ch] W[ch][j]) W[ch][i],
  *                                 and bias[j] = sum_ch D[ch] W[ch][j].  Two launches (one ticketed kernel over channel groups x row
  *                                 slices, one slab sum); scratch: iif_bn3_algebra_prep_scratch_floats(C, c) floats; tickets:
- *                                 int32[64], zero on entry, zero again on exit.  c in {64, 128, 256}, C <= 4096;
+ *                                 int32[64], zero on entry, zero again on exit.  c in {64, 128, 256}, C <= 4096.  With colsum2
+ *                                 (sum over the pixels of the second K source of the data gradient, i.e. of a2) the bias also absorbs
+ *                                 what the bf16 rounding of wt adds to the COLUMN SUMS of the data gradient (exactly zero in exact
+ *                                 arithmetic): bias[j] -= (sum_i colsum2[i] d2[j][i] + sum_ch sum(g~)[ch] d1[j][ch]) / m;
  *   iif_conv_igemm_dgrad2_bnbwd   dst = [src | src2] wgt^T + bias (1x1, stride 1, bf16; K runs over src's cs then src2's cs2
  *                                 channels), optionally with the upstream BN-backward sums of iif_conv_igemm_dgrad_bnbwd;
  *   iif_bn3_algebra_dw            dW [C][lddw] from P, W, Gram, csum, coef.
@@ -429,7 +432,8 @@ int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* src, const v
 int64_t iif_bn3_algebra_prep_scratch_floats(int C, int c);
 int iif_bn3_algebra_prep(const float* P, int ldp, const void* w_bf16, int ldw, const float* partial, int n_partials,
                          const float* stats, const float* gamma, int C, int c, int64_t m, float* coef, float* dgamma, float* dbeta,
-                         void* wt, int ldwt, float* bias, float* scratch, int64_t scratch_floats, int32_t* tickets, void* stream);
+                         void* wt, int ldwt, float* bias, float* scratch, int64_t scratch_floats, int32_t* tickets,
+                         const float* colsum2 /* nullable: colsum of the data gradient's second source, [c] */, void* stream);
 int iif_bn3_algebra_dw(const float* P, int ldp, const void* w_bf16, int ldw, const float* gram, int ldg, const float* csum,
                        const float* coef, int C, int c, float* dW, int lddw, void* stream);
 

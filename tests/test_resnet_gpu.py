@@ -395,6 +395,42 @@ def test_bn3_backward_by_algebra_inside_the_step(monkeypatch, pure, streams):
         assert e <= (1e-1 if m_ is net.bn1 else 6e-2), (type(m_).__name__, attr, e)
 
 
+def test_stride1_shortcut_bn_backward_by_algebra(monkeypatch):
+    """The convolutional shortcut of layer1.0 (1x1 / stride 1 + BN, resnet_pytorch.py:152-167 `identity = self.downsample(x)`)
+    takes the same algebra as bn3 on the shortcut stream (resnet_engine.py::_ds_algebra): every gradient of the step against the
+    step with the shortcut on the standard passes (reduction, normalisation, data gradient, weight gradient) - bf16 roundings
+    apart, amplified as in the test above - and bit-identical when repeated."""
+    from iif_amd.custom import IIFLoss
+    arch, C, B, hw = "resnet50", 1000, 32, 64
+    counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
+    net, sd = _build(arch, C, torch.bfloat16)
+    net.load_state_dict(damp_residual_branches(sd, arch))
+    x, y = _data(B, hw, counts, seed=22)
+    crit = IIFLoss(DS(counts), variant="raw")
+    net.train()
+    xd, yd = x.to(DEV), y.to(DEV)
+    net.loss_and_backward(xd, yd, crit)
+    plan = net._saved
+    assert len(plan.ds_alg) == 1                            # layer1.0: the only stride-1 shortcut convolution of a ResNet-50
+    alg = net._grad_arena.clone()
+    net.loss_and_backward(xd, yd, crit)
+    assert torch.equal(net._grad_arena, alg)
+    keep, plan.ds_alg = plan.ds_alg, {}
+    net.loss_and_backward(xd, yd, crit)
+    std = net._grad_arena.clone()
+    plan.ds_alg = keep
+    assert (alg - std).norm().item() / std.norm().item() <= 2e-2
+    ds = net.layer1[0].downsample
+    for (m_, attr, rows, pitch) in net._param_specs():
+        off = net._offsets[(id(m_), attr)][0]
+        a_, b_ = alg[off:off + rows * pitch], std[off:off + rows * pitch]
+        e = (a_ - b_).norm().item() / max(b_.norm().item(), 1e-12)
+        if m_ is ds[0] or m_ is ds[1]:
+            assert e <= 2e-2, (type(m_).__name__, attr, e)  # the shortcut's own weight / BN gradients: nothing amplifies them
+        else:
+            assert e <= (1e-1 if m_ is net.bn1 else 6e-2), (type(m_).__name__, attr, e)
+
+
 @pytest.mark.parametrize("arch,C,B,hw,alg3", [("resnet50", 1000, 16, 64, False), ("resnet50", 1000, 16, 64, True),
                                               ("resnet50", 1000, 16, 64, "no_shortcut_stream"), ("resnet50", 1000, 16, 64, "one_stream"),
                                               ("resnext50_32x4d", 365, 8, 64, False)])
