@@ -205,32 +205,31 @@ __global__ void __launch_bounds__(256) bn3_prep_kernel(const float* P, int ldp, 
     // the g~ half of the stacked weights: wt[j][ch0 + lane] = bf16(A W[ch][j]); a wave writes 128 contiguous bytes per j
     {
         const int lane = t & 63, wv = t >> 6;
-        {
-            // corr_slab[g][j] = sum_ch sum(g~)[ch] * (bf16(A W[ch][j]) - A W[ch][j]): what the rounding of this half of the stacked
-            // weights adds to the COLUMN SUM of the data gradient (see bn3_gm_finish_kernel)
-            const bool chv2 = ch0 + lane < C;
-            const float A = cA[lane], s1 = chv2 ? ssum[lane] : 0.f;
+        if (ch0 + lane < C) {
+            const float A = cA[lane];
             for (int j = wv; j < c; j += 4) {
                 const unsigned short wb = *reinterpret_cast<const unsigned short*>(WT + swz_addr(lane, j * 2, rb));
-                const float v = A * bf16_bits_to_f32(wb);
-                const unsigned short r = f32_to_bf16_bits(v);
-                if (chv2) wt[(int64_t)j * ldwt + ch0 + lane] = r;
-                const float e = wsum(chv2 ? s1 * (bf16_bits_to_f32(r) - v) : 0.f);
-                if (lane == 0) corr_slab[(int64_t)g * c + j] = e;
+                wt[(int64_t)j * ldwt + ch0 + lane] = f32_to_bf16_bits(A * bf16_bits_to_f32(wb));
             }
         }
         // bias_slab[g][jo] = sum_ch D[ch] W[ch][jo], D = E - B mu, with the B W product taken AS THE MATRIX PIPE SEES IT
         // (bf16(B W), the BT tile): the a2 half of the stacked weights is sum_ch bf16(B W[ch][jo]) W[ch][i], and only with the
         // same rounded factor does  sum_i colsum(a2)[i] G[jo][i] + M bias[jo]  cancel (mu[ch] = W[ch] . colsum(a2) / M); the
         // rounding of B W times mu - the same sign on every pixel - otherwise lands in the data gradient's column sums
+        // corr_slab[g][jo] = sum_ch sum(g~)[ch] * (bf16(A W[ch][jo]) - A W[ch][jo]): what the rounding of the g~ half of the
+        // stacked weights (the loop above stores exactly these bf16 values) adds to the COLUMN SUM of the data gradient
+        // (bn3_gm_finish_kernel); a thread owns a column and walks the group's channels, as for the bias
         if (t < c) {
-            float bsum = 0.f;
+            float bsum = 0.f, esum = 0.f;
             for (int ch = 0; ch < kGC; ++ch) {
                 const float w = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(WT + swz_addr(ch, t * 2, rb)));
                 const float bw = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(BT + swz_addr(ch, t * 2, rb)));
                 bsum += cE[ch] * w - cM[ch] * bw;
+                const float v = cA[ch] * w;
+                esum += ssum[ch] * (bf16_bits_to_f32(f32_to_bf16_bits(v)) - v);
             }
             bias_slab[(int64_t)g * c + t] = bsum;
+            corr_slab[(int64_t)g * c + t] = esum;
         }
     }
     // slab[g][jo][i] on the matrix pipe: A operand = W (rows i), B operand = B o W (columns jo), K = the group's 64 channels
