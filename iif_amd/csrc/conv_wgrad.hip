@@ -1114,13 +1114,23 @@ inline int launch_wgrad_1x1(const WgArgs& g, float* dw, float* ws, int64_t ws_by
     // 128 x 128: three (48 KB); 64 x {128, 64}: four
     const int per_cu = bc == 256 ? 1 : (bc == 128 ? 3 : 4);
     int splits = splits_req;
+    const int64_t slab = (int64_t)g.Cd * g.ldw;
     if (splits <= 0) {
         splits = 256 * per_cu / tiles;
         if (splits < 1) splits = 1;
         const int max_by_work = a.nsteps / 8 > 0 ? a.nsteps / 8 : 1;
         if (splits > max_by_work) splits = max_by_work;
+        // Small outputs write splits x their own size in slabs: a Gram matrix a2^T a2 (16-256 KB) 16-48 MB, P = g~^T a2 of the
+        // 56 x 56 stage (64 KB) 16 MB - more than the operands at 14 x 14.  Round 5, same-call A/B of the step (ms): default splits
+        // 18.02; Gram 1/4 + other outputs <= 256 KB 1/2: 17.78; Gram 1/8: 17.77; 1/2 for EVERY 1x1 weight gradient 17.86 and for
+        // the nine-tap kernel 17.90 (their streams become the critical path).  Gram (x == dy) is forward data a block ahead on the
+        // shortcut stream: nothing waits for it.  IIF_WGRAD_GRAM_DIV / IIF_WGRAD_SMALL_DIV = 1 restore the full round of splits.
+        static const int small_div = [] { const char* e = getenv("IIF_WGRAD_SMALL_DIV"); return e ? atoi(e) : 2; }();
+        static const int gram_div = [] { const char* e = getenv("IIF_WGRAD_GRAM_DIV"); return e ? atoi(e) : 8; }();
+        const bool gram = g.x == g.dy;
+        const int div = gram ? gram_div : (slab * 4 <= (256 << 10) ? small_div : 1);
+        if (div > 1 && splits > 8) { splits /= div; if (splits < 8) splits = 8; }       // (never more splits than before)
     }
-    const int64_t slab = (int64_t)g.Cd * g.ldw;
     const int64_t fit = ws ? ws_bytes / (slab * 4) : 0;
     if (splits > fit) splits = (int)fit;
     if (splits < 1) splits = 1;
