@@ -999,6 +999,13 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int 
 }
 
 // sum the split-K slabs into dw (fixed order)
+// splits_req < 0: an automatic round sized for 1/|splits_req| of the device - the caller runs that many weight gradients
+// side by side on streams of their own.  Every block writes its accumulator tile once whatever the tiling, so the split-K
+// slab traffic of a launch is (blocks in the round) x (tile bytes): 75 MB written + read again by the nine-tap kernel, 32 MB
+// by the 256 x 128 1x1 kernel, ~4 GB of the step's 73 (profiles/r5_d_pmc_hbm_traffic.csv).  Two half rounds side by side
+// keep the device as full with half of that.
+inline int share_of(int splits_req) { return splits_req < 0 ? -splits_req : 1; }
+
 inline int reduce_slabs(float* ws, int64_t ws_bytes, int splits, int64_t slab, int rows, int ldw, int K, float* dw, hipStream_t st) {
     const int64_t total4 = slab / 4;
     const int blocks = (int)(cdiv64(total4, 256) < 2048 ? cdiv64(total4, 256) : 2048);
@@ -1036,7 +1043,7 @@ inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_b
     int splits = splits_req;
     if (splits <= 0) {
         const int per_cu = 2;
-        splits = 256 * per_cu / tiles;
+        splits = 256 * per_cu / share_of(splits_req) / tiles;
         if (splits < 1) splits = 1;
         const int max_by_work = h.nsteps / 8 > 0 ? h.nsteps / 8 : 1;
         if (splits > max_by_work) splits = max_by_work;
@@ -1077,7 +1084,7 @@ inline int launch_wgrad_stem(const WgArgs& a, float* dw, float* ws, int64_t ws_b
     int splits = splits_req;
     if (splits <= 0) {
         const int per_cu = 2;
-        splits = 256 * per_cu;
+        splits = 256 * per_cu / share_of(splits_req);
         const int max_by_work = h.nsteps / 8 > 0 ? h.nsteps / 8 : 1;
         if (splits > max_by_work) splits = max_by_work;
     }
@@ -1116,7 +1123,7 @@ inline int launch_wgrad_1x1(const WgArgs& g, float* dw, float* ws, int64_t ws_by
     int splits = splits_req;
     const int64_t slab = (int64_t)g.Cd * g.ldw;
     if (splits <= 0) {
-        splits = 256 * per_cu / tiles;
+        splits = 256 * per_cu / share_of(splits_req) / tiles;
         if (splits < 1) splits = 1;
         const int max_by_work = a.nsteps / 8 > 0 ? a.nsteps / 8 : 1;
         if (splits > max_by_work) splits = max_by_work;
@@ -1196,7 +1203,7 @@ int launch_wgrad(WgArgs a, float* dw, float* ws, int64_t ws_bytes, int splits_re
         // blocks per CU: 4 (64-channel tile), 3 (128), and ONE 8-wave block for the 256-channel tile: two per CU write twice
         // the split-K slabs for nothing (step 20.67 -> 20.62 ms at one; 0.75 / 1.25 per CU leave a tail round: 21.2 / 20.8;
         // round 3, scripts removed).
-        const int slots = 256 * (bc == 256 ? 1 : (bc == 128 ? 3 : 4));
+        const int slots = 256 * (bc == 256 ? 1 : (bc == 128 ? 3 : 4)) / share_of(splits_req);
         splits = slots / (tiles * a.groups);
         if (splits < 1) splits = 1;
         const int max_by_work = a.nsteps / 8 > 0 ? a.nsteps / 8 : 1;

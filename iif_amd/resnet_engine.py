@@ -832,6 +832,18 @@ class _Plan(object):
         if dev.type == "cuda" and side != "0":
             self.wg_stream = torch.cuda.Stream(device=dev)
         self._wg_events = {}
+        # IIF_WG_STREAMS=n: n weight-gradient streams taken round robin, each launch sized for 1/n of the device.  Every block of
+        # a split-K weight gradient writes its accumulator tile once, so a round over 256 CUs writes (and the reduction reads
+        # back) 32-75 MB of slabs per launch, ~4 GB of the step's 73; n part rounds side by side write 1/n of that.  Measured
+        # (round 5, same call, ms per step): 1 stream 17.65, 2 streams 18.74 (the part rounds take 1.3x their share of time:
+        # the two streams together are busy 13.2 ms against 10.0, profiles/r5_two_wgrad_streams.txt), 3 streams 29.7 (five
+        # streams on four hardware queues).  Default 1.
+        self.wg_streams = []
+        if self.wg_stream is not None:
+            nws = int(os.environ.get("IIF_WG_STREAMS", "1"))
+            self.wg_streams = [self.wg_stream] + [torch.cuda.Stream(device=dev) for _ in range(max(nws, 1) - 1)]
+        self.wg_wss = [self.wg_ws] + [torch.empty_like(self.wg_ws) for _ in self.wg_streams[1:]]
+        self._wg_rr = 0
         self.stem_wgrad_main = self.wg_stream is not None
         # own split-K workspace of the stem's weight gradient (it runs on the compute stream next to the side stream's):
         # allocated here, never inside backward (a lazy allocation there would land inside a hipGraph capture)
@@ -851,6 +863,7 @@ class _Plan(object):
         # (3.1 -> 1.3 GB at 56 x 56, all of it on the shortcut stream, which the compute stream used to wait ~120 us for at the
         # end of layer1.0).  Units: 1 x 1 / stride 1 shortcuts of a block whose last unit takes the bn3 algebra (ResNet-50: layer1.0).
         self.ds_alg = {}
+        self._alg_rows = {}
         if self.ds_stream is not None and self.alg3_units and not os.environ.get("IIF_NO_DS_ALGEBRA"):
             for b in self.blocks:
                 du = b.get("ds")
@@ -868,6 +881,10 @@ class _Plan(object):
                         "rows": torch.empty(self.bw_partial.numel(), dtype=torch.float32, device=dev),
                         "ws": torch.empty(64 << 20, dtype=torch.uint8, device=dev),
                         "ws_sum": ops.bn_workspace(du.n * du.ho * du.wo, c, dev)}
+                    # the data gradient that feeds this block's last unit writes its per-tile sums of g~ straight into "rows":
+                    # both branches read them, and the compute stream's next fused data gradient does not overwrite them
+                    # (round 5: the copy out of bw_partial was a 65 us blit on the compute stream)
+                    self._alg_rows[id(b["units"][-1])] = self.ds_alg[id(du)]["rows"]
 
     def _finish_weight_plan(self):
         """One arena for every dense transposed weight copy ([cin][k*k*cout], the data-gradient operand) and
@@ -1095,10 +1112,13 @@ class _Plan(object):
             with torch.cuda.stream(self.wg_stream):
                 self.wg_stream.wait_event(ev)
                 self.prepare_weights(training, "rest")
+                net._nbt += 1                  # (a 10 us launch nothing in the step reads: not on the compute stream)
                 prep_done = torch.cuda.Event()
                 prep_done.record()
         else:
             self.prepare_weights(training)
+            if training:
+                net._nbt += 1
         c1 = net.conv1
         if self.stem_s2d:
             ops.space_to_depth_nchw(img, S2D_CPAD, self.patches)
@@ -1182,8 +1202,6 @@ class _Plan(object):
             feat = self.head_ex
         ops.conv_forward(feat.view(self.n, 1, 1, head.in_features), self.head_w, 1, 1, 1, 0,
                          out=self.logits.view(self.n, 1, 1, head.out_padded), bias=bias)
-        if training:
-            net._nbt += 1
 
     def _se_forward(self, b, last, training):
         """y = relu(bn(x) * e + identity), e = sigmoid(W2 relu(W1 mean_hw(bn(x)))) — SEBottleneck.forward
@@ -1242,26 +1260,37 @@ class _Plan(object):
     # reads that block's dx buffers and its g (= the block-input gradient G[b+2]); so dx buffers rotate over
     # 2 slots, block-input gradients over 3, and before block b starts the main stream waits for every wgrad
     # of the blocks >= b+2 (the fence recorded when block b+1 started).
-    def _wgrad_async(self, fn):
+    def _wgrad_async(self, fn, after=None):
+        """``fn(workspace, splits)`` on the next weight-gradient stream (round robin); ``splits`` is the value for
+        ops.conv_wgrad: 0 with one stream, -n with n (each launch sized for 1/n of the device, include/iif_amd.h)."""
         if self.wg_stream is None:
-            fn()
+            fn(self.wg_ws, 0)
             return
         ev = torch.cuda.Event()
         ev.record()
-        with torch.cuda.stream(self.wg_stream):
-            self.wg_stream.wait_event(ev)
-            fn()
+        k = self._wg_rr
+        self._wg_rr = (k + 1) % len(self.wg_streams)
+        st = self.wg_streams[k]
+        with torch.cuda.stream(st):
+            st.wait_event(ev)
+            if after is not None:
+                st.wait_event(after)
+            fn(self.wg_wss[k], -len(self.wg_streams) if len(self.wg_streams) > 1 else 0)
 
     def _wgrad_fence(self, tag):
-        """Record where the side stream is after block ``tag``; wait for the fence of block tag+2."""
+        """Record where the side streams are after block ``tag``; wait for the fence of block tag+2."""
         if self.wg_stream is None:
             return
-        ev = torch.cuda.Event()
-        ev.record(self.wg_stream)
-        self._wg_events[tag] = ev
+        evs = []
+        for st in self.wg_streams:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
+        self._wg_events[tag] = evs
         old = self._wg_events.pop(tag + self.wg_lag - 1, None)
         if old is not None:
-            torch.cuda.current_stream().wait_event(old)
+            for ev in old:
+                torch.cuda.current_stream().wait_event(ev)
 
     def _stem_wgrad(self, u, dx4):
         cv = u.conv
@@ -1273,12 +1302,12 @@ class _Plan(object):
                 ops.stem_s2d_unpack_grad(u.dwp, cv.cout, cv.cin, cv.k, S2D_CPAD, cv._g2d)
                 return
 
-            def stem():
-                ops.conv_wgrad(u.src, dx4, 4, 4, 1, 2, ldw=u.dwp.shape[1], out=u.dwp, workspace=self.wg_ws)
+            def stem(ws, sp):
+                ops.conv_wgrad(u.src, dx4, 4, 4, 1, 2, ldw=u.dwp.shape[1], out=u.dwp, workspace=ws, splits=sp)
                 ops.stem_s2d_unpack_grad(u.dwp, cv.cout, cv.cin, cv.k, S2D_CPAD, cv._g2d)
             self._wgrad_async(stem)
         else:
-            self._wgrad_async(lambda: ops.conv_wgrad(u.src, dx4, 1, 1, 1, 0, ldw=cv.ldw, out=cv._g2d, workspace=self.wg_ws))
+            self._wgrad_async(lambda ws, sp: ops.conv_wgrad(u.src, dx4, 1, 1, 1, 0, ldw=cv.ldw, out=cv._g2d, workspace=ws, splits=sp))
 
     def stem_activation(self):
         """The stem's activated output (tests replay its ReLU decisions): stored, or — when bn1/relu/maxpool run
@@ -1322,7 +1351,7 @@ class _Plan(object):
                                        u.stats, bn.weight, local, total, float(m) * world, bn._dgamma, bn._dbeta, dx, coef,
                                        gmasked=None if gmasked is None else gmasked.view(m, cv.cout), relu_bits=bits)
         elif ready is not None and ready[0] is u and len(ready) == 3:
-            return self._bn3_algebra(u, gy, ready[1], par, self._cur_block, dgrad_out, fuse_up)
+            return self._bn3_algebra(u, gy, ready[1], par, self._cur_block, dgrad_out, fuse_up, ready[2])
         elif u in self.twopass_units:
             raise RuntimeError("two-pass unit reached the standard BN backward: its convolution output was never stored")
         elif ready is not None and ready[0] is u and gmasked is None:
@@ -1345,14 +1374,14 @@ class _Plan(object):
             self._stem_wgrad(u, dx4)
             return None
         if u.groups > 1:
-            def grouped():
+            def grouped(ws, sp):
                 ops.conv_wgrad(u.src, dx4, cv.k, cv.k, cv.stride, cv.pad, ldw=u.dwp.shape[1], out=u.dwp,
-                               workspace=self.wg_ws, groups=u.groups)
+                               workspace=ws, groups=u.groups, splits=sp)
                 ops.group_unpack_grad(u.dwp, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, cv._g2d)
             self._wgrad_async(grouped)
         else:
-            self._wgrad_async(lambda: ops.conv_wgrad(u.src, dx4, cv.k, cv.k, cv.stride, cv.pad, ldw=cv.ldw, out=cv._g2d,
-                                                     workspace=self.wg_ws))
+            self._wgrad_async(lambda ws, sp: ops.conv_wgrad(u.src, dx4, cv.k, cv.k, cv.stride, cv.pad, ldw=cv.ldw, out=cv._g2d,
+                                                            workspace=ws, splits=sp))
         if not need_dgrad:
             return None
         if (fuse_up is not None and self.fuse_bwd and (u.groups == 1 or cv.stride == 1) and dgrad_out is not None
@@ -1361,10 +1390,11 @@ class _Plan(object):
             if up in self.alg3_units and cv.k == 1 and cv.stride == 1 and up_bits is not None:
                 # the upstream unit's BN backward runs by algebra: store the gradient gated by its block's ReLU, emit its
                 # column sums only (conv3's output is not read)
-                nt = ops.conv_dgrad_masksum(dx4, u.wt, (u.hi, u.wi), dgrad_out, up_bits, self.bw_partial, res=dgrad_res,
+                rows = self._alg_rows.get(id(up), self.bw_partial)
+                nt = ops.conv_dgrad_masksum(dx4, u.wt, (u.hi, u.wi), dgrad_out, up_bits, rows, res=dgrad_res,
                                             res_bits=dgrad_res_bits, up_x=None if self._a3_is_pure(up) else up.x,
                                             up_stats=None if self._a3_is_pure(up) else up.stats)
-                self._bw_ready = (up, nt, True)
+                self._bw_ready = (up, nt, rows)
                 return dgrad_out
             nt = ops.conv_dgrad_bnbwd(dx4, u.wt, cv.k, cv.k, cv.stride, cv.pad, (u.hi, u.wi), dgrad_out, up.x, up_bits, up.stats,
                                       self.bw_partial, res=dgrad_res, res_bits=dgrad_res_bits, w_frag=u.wtf, groups=u.groups)
@@ -1401,7 +1431,7 @@ class _Plan(object):
             done.record()
         A["ev"] = done
 
-    def _bn3_algebra(self, u, gt, nt, par, bi, dgrad_out, fuse_up):
+    def _bn3_algebra(self, u, gt, nt, par, bi, dgrad_out, fuse_up, rows):
         """Backward of conv3 + bn3 from the gated block-output gradient ``gt`` without reading conv3's output
         (csrc/bn3_algebra.hip).  Returns the gradient w.r.t. the unit's source (a2)."""
         cv, bn = u.conv, u.bn
@@ -1421,23 +1451,17 @@ class _Plan(object):
         gram_ev = Ag["ev"]
         if gram_ev is not None:
             torch.cuda.current_stream().wait_event(gram_ev)
-        ops.bn3_algebra_prep(P if pure else None, wb, c, self.bw_partial, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt,
+        ops.bn3_algebra_prep(P if pure else None, wb, c, rows, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt,
                              A["bias"][:c], A["scr"], A["tickets"], colsum2=Ag["csum"].view(-1)[:c])
 
-        def finish_dw():
+        def finish_dw(ws, sp):
             if not pure:
-                ops.conv_wgrad(u.src, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=self.wg_ws if self.wg_stream is not None else self.a3_ws)
+                ops.conv_wgrad(u.src, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=ws, splits=sp)
             ops.bn3_algebra_dw(P, wb, c, Ag["gram"].view(-1)[:c * cv.ldw].view(c, cv.ldw), Ag["csum"].view(-1)[:c], coef, cv._g2d)
         if self.wg_stream is None:
-            finish_dw()
+            finish_dw(self.a3_ws, 0)
         else:
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(self.wg_stream):
-                self.wg_stream.wait_event(ev)
-                if gram_ev is not None:
-                    self.wg_stream.wait_event(gram_ev)
-                finish_dw()
+            self._wgrad_async(finish_dw, after=gram_ev)
         up, up_bits = fuse_up
         nt2 = ops.conv_dgrad2_bnbwd(g4, u.src, wt, A["bias"][:c], dgrad_out, up.x, up_bits, up.stats, self.bw_partial)
         self._bw_ready = (up, nt2)
@@ -1473,7 +1497,7 @@ class _Plan(object):
         budget = 0
         if reducer is not None:
             reducer.begin()
-            reducer.extra_streams = [st for st in (self.wg_stream, self.ds_stream if self.ds_alg else None) if st is not None]
+            reducer.extra_streams = self.wg_streams + ([self.ds_stream] if self.ds_alg and self.ds_stream is not None else [])
             if reducer.world > 1 or reducer.force:
                 budget = int(getattr(reducer, "cu_budget", 0))
         if budget:
@@ -1495,7 +1519,8 @@ class _Plan(object):
             # had not joined it yet), and all of them are joined again at the end of backward
             ev = torch.cuda.Event()
             ev.record()
-            self.wg_stream.wait_event(ev)
+            for st in self.wg_streams:
+                st.wait_event(ev)
             if self.ds_stream is not None:
                 self.ds_stream.wait_event(ev)
         # ---- head: dlogits (fp32, pad columns are zero) -> head grads -> pooled grad -> final activation grad
@@ -1506,9 +1531,11 @@ class _Plan(object):
             dl = ops.cast(self.dlogits, self.dlogits_t)
         dpooled = self._gbuf(("dpooled",), (n, 1, 1, D))
         if self.head_kind == "linear":
-            ops.colsum_f32(self.dlogits, n, op, op, head._gb1d)
-            ops.conv_wgrad(self.pooled.view(n, 1, 1, D), dl.view(n, 1, 1, op), 1, 1, 1, 0, ldw=D, out=head._g2d,
-                           workspace=self.wg_ws)
+            def head_grads(ws, sp):          # only the data gradient is on the chain
+                ops.colsum_f32(self.dlogits, n, op, op, head._gb1d)
+                ops.conv_wgrad(self.pooled.view(n, 1, 1, D), dl.view(n, 1, 1, op), 1, 1, 1, 0, ldw=D, out=head._g2d,
+                               workspace=ws, splits=sp)
+            self._wgrad_async(head_grads)
             ops.conv_dgrad(dl.view(n, 1, 1, op), self.head_wt, 1, 1, 1, 0, (1, 1), out=dpooled)
         else:
             # d(normalised weights) = dlogits^T @ ex, then back through the row normalisation
@@ -1535,7 +1562,8 @@ class _Plan(object):
         fh, fw, fc = self.final.shape[1], self.final.shape[2], self.final.shape[3]
         if net._head_only:              # frozen backbone: the classifier's gradients are all that is needed
             if self.wg_stream is not None:
-                torch.cuda.current_stream().wait_stream(self.wg_stream)
+                for st in self.wg_streams:
+                    torch.cuda.current_stream().wait_stream(st)
                 if self.ds_stream is not None:
                     torch.cuda.current_stream().wait_stream(self.ds_stream)
             if reducer is not None:
@@ -1576,11 +1604,7 @@ class _Plan(object):
                 rdy = self._bw_ready
                 D = self.ds_alg.get(id(du))
                 by_algebra = D is not None and rdy is not None and rdy[0] is last and len(rdy) == 3
-                if by_algebra:
-                    # the producer's partial rows (sum g~ per tile) are overwritten by the next fused data gradient of the compute
-                    # stream: the shortcut stream works from a copy
-                    nrow = rdy[1] * 2 * last.conv.cout
-                    D["rows"][:nrow].copy_(self.bw_partial[:nrow])
+                by_algebra = by_algebra and rdy[2] is D["rows"]        # (the rows live where nothing on the compute stream overwrites them)
                 ev = torch.cuda.Event()
                 ev.record()
                 with torch.cuda.stream(self.ds_stream):
@@ -1676,7 +1700,8 @@ class _Plan(object):
         else:
             self._unit_backward(u, g, u.y, need_dgrad=False)
         if self.wg_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.wg_stream)
+            for st in self.wg_streams:
+                torch.cuda.current_stream().wait_stream(st)
             if self.ds_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.ds_stream)
             self._wg_events.clear()

@@ -169,7 +169,11 @@ int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, const void* 
  * d describes the FORWARD convolution (source = x, destination = dy grid,
  * transposed must be 0).  dw: float [cd][ldw] (columns >= r*s*cs are not
  * written).  The pixel reduction is split over `splits` workgroup rows
- * (0 = choose) into fp32 slabs in `workspace` (>= splits*cd*ldw*4 bytes; fewer
+ * (0 = choose: one co-resident round of workgroups on the whole device; -n =
+ * choose for 1/n of the device, for a caller that runs n weight gradients side
+ * by side on n streams - every workgroup writes its accumulator tile once, so
+ * n half-size rounds write 1/n of the slab bytes each) into fp32 slabs in
+ * `workspace` (>= splits*cd*ldw*4 bytes; fewer
  * splits are used if it is smaller, NULL = no split) that are then summed in
  * fixed order: deterministic, no float atomics.  bf16 fragments are formed by
  * ds_read_b64_tr_b16.  Replaces the wgrad half of autograd's conv backward for

@@ -9,6 +9,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/p_kt /tmp/p_f /tmp/p_w /tmp/p_m      # a leased box keeps /tmp between calls: never read a stale database
 BENCH="$root/bench.py --no-cpu-baseline --no-kernel-events --no-fp32-step"
 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/p_kt -- python3 $BENCH --steps 10 --warmup 3 > $out/kt.log 2>&1
 db=$(find /tmp/p_kt -name "*.db" | head -1)
