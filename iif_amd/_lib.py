@@ -58,6 +58,7 @@ SIGNATURES = {
     "iif_colsum_f32": [_P, _I, _I, _L, _P, _P],
     "iif_sgd_step": [_P, _P, _P, _L, _F, _P, _F, _F, _I, _F, _P],
     "iif_group_pack": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "iif_group_pack_batched": [_P, _I, _I, _I, _P],
     "iif_group_unpack_grad": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "iif_space_to_depth_nchw": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "iif_stem_s2d_pack": [_P, _I, _I, _I, _I, _I, _I, _P, _P],

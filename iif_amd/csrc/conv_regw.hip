@@ -236,6 +236,13 @@ static bool regw_plan(int K, int N, bool epi, int* cw, int* mt) {
     if (K == 256 && N == 1024) { *cw = 32; *mt = 64; return true; }
     if (K == 512 && N == 2048 && !epi) { *cw = 16; *mt = 64; return true; }       // (with epilogue operands: 77 against 69 us)
     // (the wide -> narrow shapes are level with the tile kernels alone, 59.3 / 60.1 and 43.1 / 42.8 us, and level to +0.05 ms in the step)
+    // ResNeXt's conv3 (width -> 2 x width; resnet_pytorch.py:141-143 with groups 32, base width 4): the same kernels, fewer slices
+    if (!getenv("IIF_REGW_NO_X2")) {
+        if (K == 128 && N == 256) { *cw = 32; *mt = 64; return true; }
+        if (K == 256 && N == 512) { *cw = 32; *mt = 64; return true; }
+        if (K == 512 && N == 1024 && !epi) { *cw = 16; *mt = 64; return true; }
+        if (K == 1024 && N == 2048 && !epi) { *cw = 16; *mt = 32; return true; }
+    }
     if (K == 512 && N == 128 && !epi) { *cw = 16; *mt = 64; return true; }
     if (K == 1024 && N == 256 && !epi) { *cw = 16; *mt = 32; return true; }
     return false;
@@ -283,7 +290,8 @@ int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_pa
         else if (K == 128) IIF_REGW(128, 32, 64, true);
         else IIF_REGW(256, 32, 64, true);
     } else {
-        if (K == 128) IIF_REGW(128, 64, 64, false);
+        if (K == 128 && cw == 64) IIF_REGW(128, 64, 64, false);
+        else if (K == 128) IIF_REGW(128, 32, 64, false);
         else if (K == 256) IIF_REGW(256, 32, 64, false);
         else if (K == 512) IIF_REGW(512, 16, 64, false);
         else IIF_REGW(1024, 16, 32, false);

@@ -280,6 +280,22 @@ def group_pack(master, channels, cg, chunk, rs, out, transposed=False):
     return out
 
 
+def group_pack_table(entries, device):
+    """Device table for group_pack_batched.  entries: (master fp32 [C, ldm], C, cg, chunk, rs, out [C, ldp], transposed);
+    every ``out`` of one dtype.  The tensors must stay alive and in place as long as the table is used."""
+    import struct
+    raw = b"".join(struct.pack("<QQ8i", ptr(m) or 0, ptr(o) or 0, c, cg, ch, rs, m.shape[1], o.shape[1], 1 if tr else 0, 0)
+                   for (m, c, cg, ch, rs, o, tr) in entries)
+    tab = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    biggest = max(c * o.shape[1] for (m, c, cg, ch, rs, o, tr) in entries)
+    return tab, len(entries), max(1, min(64, (biggest + 2047) // 2048)), entries[0][5]
+
+
+def group_pack_batched(table):
+    tab, n, blocks, like = table
+    check(lib().iif_group_pack_batched(ptr(tab), n, blocks, dtype_code(like), stream_ptr()), "iif_group_pack_batched")
+
+
 def group_unpack_grad(packed, channels, cg, chunk, rs, master_grad):
     check(lib().iif_group_unpack_grad(ptr(packed), channels, cg, chunk, rs, packed.shape[1], master_grad.shape[1],
                                       ptr(master_grad), stream_ptr()), "iif_group_unpack_grad")

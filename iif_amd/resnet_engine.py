@@ -1002,6 +1002,20 @@ class _Plan(object):
         return u
 
     # ---------------------------------------------------------------- weights
+    def _group_pack_table(self, transposed):
+        key = bool(transposed)
+        tabs = self.__dict__.setdefault("_gp_tables", {})
+        if key not in tabs:
+            ent = []
+            for u in self.units:
+                cv = u.conv
+                if not u.s2d and cv.groups > 1:
+                    ent.append((cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.w, False))
+                    if transposed:
+                        ent.append((cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.wt, True))
+            tabs[key] = ops.group_pack_table(ent, self.dev) if ent else None
+        return tabs[key]
+
     def prepare_weights(self, need_transposed, part="all"):
         """Low-precision / transposed / fragment-packed copies of the fp32 master weights.  part = "stem": only the stem's
         packed matrix; "rest": everything else (forward() runs that on the idle weight-gradient stream under the stem)."""
@@ -1020,17 +1034,12 @@ class _Plan(object):
             ops.pack_fragments(self.lp_arena, self.frag_fwd[0], self.frag_fwd[2], self.frag_fwd[1], self.frag_arena)
         if need_transposed and self.frag_bwd is not None:
             ops.pack_fragments(self.wt_arena, self.frag_bwd[0], self.frag_bwd[2], self.frag_bwd[1], self.frag_arena)
-        for u in self.units:
-            cv = u.conv
-            if not u.s2d and cv.groups > 1:
-                ops.group_pack(cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.w)
-                if need_transposed:
-                    ops.group_pack(cv._w2d, cv.cout, cv.cg, cv.chunk, cv.k * cv.k, u.wt, transposed=True)
+        # grouped layers: block-diagonal chunk weights, both orientations, ONE launch (the fragment table packs both, so the
+        # transposed chunks are filled in evaluation too)
+        tab = self._group_pack_table(need_transposed or self.gfrag is not None)
+        if tab is not None:
+            ops.group_pack_batched(tab)
         if self.gfrag is not None:
-            if not need_transposed:       # the table packs both orientations: keep the transposed chunks defined
-                for u in self.units:
-                    if u.groups > 1 and u.wtf is not None:
-                        ops.group_pack(u.conv._w2d, u.conv.cout, u.conv.cg, u.conv.chunk, u.conv.k * u.conv.k, u.wt, transposed=True)
             ops.pack_fragments(self.gw_arena, self.gfrag[0], self.gfrag[2], self.gfrag[1], self.gfrag_arena)
         head = net._head
         if self.head_kind == "linear":

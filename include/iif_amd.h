@@ -310,6 +310,16 @@ int iif_group_pack(const float* master, int channels, int cg, int chunk, int rs,
                    int transposed, int out_dtype, void* out, void* stream);
 int iif_group_unpack_grad(const float* packed, int channels, int cg, int chunk, int rs, int ldp,
                           int ldm, float* master, void* stream);
+/* iif_group_pack for every grouped layer in ONE launch: `table` = `entries` device-resident
+ * iif_group_pack_entry records (all outputs of dtype out_dtype), `blocks_per_entry` 256-thread
+ * blocks walk each entry.  Same arithmetic as iif_group_pack, entry by entry. */
+typedef struct iif_group_pack_entry {
+    const float* master;   /* fp32 [channels][ldm] */
+    void* out;             /* [channels][ldp] */
+    int32_t channels, cg, chunk, rs, ldm, ldp, transposed, reserved;
+} iif_group_pack_entry;
+int iif_group_pack_batched(const void* table, int entries, int blocks_per_entry, int out_dtype,
+                           void* stream);
 
 /* Stem as a space-to-depth convolution: the RxR / stride-2 / pad-(R-1)/2 convolution on a c-channel
  * NCHW fp32 image (resnet_pytorch.py:203: 7x7/2 on 3 channels) equals an AxA / stride-1 / pad-A/2

@@ -6,9 +6,10 @@ from iif_amd import resnet_pytorch
 from iif_amd.custom import IIFLoss
 import bench as B
 dev = torch.device('cuda', 0)
-C, bs = 1000, 256
+model = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
+C, bs = (int(sys.argv[3]) if len(sys.argv) > 3 else 1000), (int(sys.argv[2]) if len(sys.argv) > 2 else 256)
 counts = B.lt_counts(C, 1280)
-net = resnet_pytorch.resnet50(num_classes=C, use_norm="None", pretrained="None", device=dev, compute_dtype=torch.bfloat16)
+net = getattr(resnet_pytorch, model)(num_classes=C, use_norm="None", pretrained="None", device=dev, compute_dtype=torch.bfloat16)
 net.train()
 crit = IIFLoss(B._Counts(counts), variant="raw", reduction="mean", device=dev)
 x = torch.randn(bs, 3, 224, 224).to(dev); y = torch.randint(0, C, (bs,)).to(dev)

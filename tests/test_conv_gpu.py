@@ -560,7 +560,8 @@ def test_stem_s2d_forward_window_kernel(n, h, w):
 
 
 @pytest.mark.parametrize("case", [(16, 16, 128, 512), (16, 16, 256, 1024), (64, 8, 512, 2048), (16, 16, 512, 128), (16, 16, 1024, 256),
-                                  (37, 28, 128, 512), (3, 16, 128, 512)],
+                                  (37, 28, 128, 512), (3, 16, 128, 512),
+                                  (16, 16, 128, 256), (16, 16, 256, 512), (32, 8, 512, 1024), (64, 8, 1024, 2048)],   # ResNeXt conv3
                          ids=lambda c: "%dx%dx%d_%d_%d" % (c[0], c[1], c[1], c[2], c[3]))
 def test_forward_1x1_weights_in_registers_equals_the_tile_kernel(case, conv_env):
     """conv_regw.hip (persistent blocks, weight fragments in registers, one partial row per tile sequence) against the tile
@@ -1027,3 +1028,31 @@ def test_register_staged_fallback_kernels(case, conv_env):
         assert (dx - ref_dx).abs().max().item() <= 2.0 ** -7 * ref_dx.abs().max().item(), mode
         assert (dw - ref_dw).norm().item() <= 1e-4 * ref_dw.norm().item(), mode             # fp32 sums of exact bf16 products
     assert (got["regstage"][0] - got["default"][0]).abs().max().item() <= 2.0 ** -7 * ref_y.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_group_pack_batched_equals_the_per_layer_launches(dt):
+    """One launch over a device table (ResNeXt: every grouped layer, both orientations) writes the bytes of the
+    per-layer iif_group_pack calls (resnet_pytorch.py:137,141 grouped 3x3 weights)."""
+    from iif_amd import ops
+    g = torch.Generator().manual_seed(11)
+    layers = [(128, 4), (256, 8), (512, 16), (1024, 32), (64, 2)]
+    ent, want = [], []
+    for width, cg in layers:
+        ch = max(64, cg)
+        ldm = (9 * cg + 15) // 16 * 16
+        master = torch.zeros(width, ldm)
+        master[:, :9 * cg] = torch.randn(width, 9 * cg, generator=g)
+        master = master.to(DEV)
+        for tr in (False, True):
+            ref = torch.empty(width, 9 * ch, dtype=dt, device=DEV)
+            ops.group_pack(master, width, cg, ch, 9, ref, transposed=tr)
+            out = torch.full((width, 9 * ch), 7.0, dtype=dt, device=DEV)
+            ent.append((master, width, cg, ch, 9, out, tr))
+            want.append(ref)
+    tab = ops.group_pack_table(ent, DEV)
+    ops.group_pack_batched(tab)
+    torch.cuda.synchronize()
+    for e, ref in zip(ent, want):
+        assert torch.equal(e[5], ref)
