@@ -59,6 +59,7 @@ SIGNATURES = {
     "iif_sgd_step": [_P, _P, _P, _L, _F, _P, _F, _F, _I, _F, _P],
     "iif_group_pack": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "iif_group_pack_batched": [_P, _I, _I, _I, _P],
+    "iif_wgrad1x1_stacked": [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _L, _I, _P],
     "iif_group_unpack_grad": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "iif_space_to_depth_nchw": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "iif_stem_s2d_pack": [_P, _I, _I, _I, _I, _I, _I, _P, _P],

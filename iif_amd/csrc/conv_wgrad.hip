@@ -513,6 +513,8 @@ struct W1Args {
     const unsigned char* x; const unsigned char* dy; float* out;
     int M, Cs, Cd, ldw, ktiles, ntiles, steps_per_split, nsteps, nsplits;
     int64_t slab;
+    // stacked dy (iif_wgrad1x1_stacked): output rows >= Cd1 contract the second tensor dy2 [M][Cd2]; Cd = Cd1 + Cd2, Cd1 % BC == 0
+    const unsigned char* dy2; int Cd1, Cd2;
 };
 
 template <int OFF> __device__ __forceinline__ s16x4 tr_read_at(unsigned a) {
@@ -529,12 +531,15 @@ __device__ __forceinline__ void wgrad1x1_body(const W1Args& a, unsigned x_bytes,
     constexpr int RBX = SX::RB, RBY = SY::RB;                     // row bytes
     constexpr int XB = 32 * RBX, YB = 32 * RBY, STAGE = XB + YB;
     constexpr int NPX = XB / 1024, NPY = YB / 1024;               // 1-KB DMA pieces per step
-    constexpr int NIX = NPX / NWV, NIY = NPY / NWV, LPS = NIX + NIY;
+    // YPAD: fewer dy pieces than waves (64 channels x 32 pixels = 4 KB under 8 waves): the waves without one issue an
+    // out-of-range piece into a dump kilobyte, so that every wave's load count per step - what the counted waits rely on - is the same
+    constexpr bool YPAD = NPY < NWV;
+    constexpr int NIX = NPX / NWV, NIY = YPAD ? 1 : NPY / NWV, LPS = NIX + NIY;
     constexpr int LPRX = RBX / 16, RPIX = 64 / LPRX, LPRY = RBY / 16, RPIY = 64 / LPRY;
     constexpr unsigned OOB = 0xfffffff0u;
-    static_assert(NIX >= 1 && NIY >= 1 && NIX * NWV == NPX && NIY * NWV == NPY && KJ >= 1, "tile geometry");
+    static_assert(NIX >= 1 && NIY >= 1 && NIX * NWV == NPX && (YPAD || NIY * NWV == NPY) && KJ >= 1, "tile geometry");
     static_assert(2 * STAGE + 16 * RBY < 65536 && 2 * STAGE + 16 * RBX < 65536, "fragment reads use 16-bit immediates");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE + (YPAD ? 1024 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -550,7 +555,12 @@ __device__ __forceinline__ void wgrad1x1_body(const W1Args& a, unsigned x_bytes,
     const int nst = step1 - step0;
 
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x), 0, x_bytes, 0x00020000);
-    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.dy), 0, dy_bytes, 0x00020000);
+    // (block-uniform) which dy tensor this block's channel tile lives in, its row pitch in channels and the tile's first channel in it
+    const bool second = a.dy2 != nullptr && k0 >= a.Cd1;
+    const int ycols = a.dy2 == nullptr ? a.Cd : (second ? a.Cd2 : a.Cd1);
+    const int yk0 = second ? k0 - a.Cd1 : k0;
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(second ? a.dy2 : a.dy), 0,
+                                                        second ? (unsigned)a.M * (unsigned)a.Cd2 * 2u : dy_bytes, 0x00020000);
 
     // ---- DMA: piece p of a step covers tile rows RPI * p ...; this wave issues pieces NI * wave + i
     unsigned offx[NIX], incx[NIX], offy[NIY], incy[NIY];
@@ -565,10 +575,10 @@ __device__ __forceinline__ void wgrad1x1_body(const W1Args& a, unsigned x_bytes,
 #pragma unroll
     for (int i = 0; i < NIY; ++i) {
         const int r = RPIY * (NIY * wave + i) + lane / LPRY;
-        const int col = k0 + SY::logical(lane % LPRY, r) * 8;
-        const bool ok = col < a.Cd;
-        offy[i] = ok ? ((unsigned)(step0 * 32 + r) * (unsigned)a.Cd + (unsigned)col) * 2u : OOB;
-        incy[i] = ok ? 64u * (unsigned)a.Cd : 0u;
+        const int col = yk0 + SY::logical(lane % LPRY, r) * 8;
+        const bool ok = col < ycols && (!YPAD || wave < NPY);
+        offy[i] = ok ? ((unsigned)(step0 * 32 + r) * (unsigned)ycols + (unsigned)col) * 2u : OOB;
+        incy[i] = ok ? 64u * (unsigned)ycols : 0u;
     }
     auto issue = [&](auto stage_c) {                       // the next step's tiles into stage S; offsets move on by 32 rows
         constexpr int S = decltype(stage_c)::value;
@@ -579,7 +589,9 @@ __device__ __forceinline__ void wgrad1x1_body(const W1Args& a, unsigned x_bytes,
         }
 #pragma unroll
         for (int i = 0; i < NIY; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)(smem + S * STAGE + XB + (NIY * wave + i) * 1024), 16, offy[i], 0, 0, IIF_WG_AUX_Y);
+            unsigned char* dst = smem + S * STAGE + XB + (NIY * wave + i) * 1024;
+            if (YPAD && wave >= NPY) dst = smem + 3 * STAGE;                         // (wave-uniform)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_w*)dst, 16, offy[i], 0, 0, IIF_WG_AUX_Y);
             offy[i] += incy[i];
         }
     };
@@ -661,6 +673,9 @@ __global__ void __launch_bounds__(512) wgrad1x1_256x128_kernel(W1Args a, unsigne
 __global__ void __launch_bounds__(256) wgrad1x1_128x128_kernel(W1Args a, unsigned xb, unsigned yb) { wgrad1x1_body<128, 128, 4>(a, xb, yb); }
 __global__ void __launch_bounds__(256) wgrad1x1_64x128_kernel(W1Args a, unsigned xb, unsigned yb) { wgrad1x1_body<64, 128, 4>(a, xb, yb); }
 __global__ void __launch_bounds__(256) wgrad1x1_64x64_kernel(W1Args a, unsigned xb, unsigned yb) { wgrad1x1_body<64, 64, 4>(a, xb, yb); }
+// <= 64 dy channels x 256 x columns: conv1 of the 56 x 56 bottlenecks (256 -> 64).  As two 64 x 128 tiles every block streamed
+// the dy tensor again (617 MB for 514, 342 us in the step, 1.8 TB/s); one tile per block reads both operands once.
+__global__ void __launch_bounds__(512) wgrad1x1_64x256_kernel(W1Args a, unsigned xb, unsigned yb) { wgrad1x1_body<64, 256, 8>(a, xb, yb); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 weight gradient with ALL NINE TAPS per block ("halo window", bf16).
@@ -1108,18 +1123,21 @@ inline int launch_wgrad_stem(const WgArgs& a, float* dw, float* ws, int64_t ws_b
 
 // 1x1 / stride 1 (wgrad1x1_body): tile by the channel counts, one co-resident round of splits as below
 inline int launch_wgrad_1x1(const WgArgs& g, float* dw, float* ws, int64_t ws_bytes, int splits_req, int64_t x_bytes, int64_t dy_bytes,
-                            hipStream_t st) {
+                            hipStream_t st, const unsigned char* dy2 = nullptr, int cd2 = 0) {
     W1Args a{};
     a.x = g.x; a.dy = g.dy; a.M = g.M; a.Cs = g.Cs; a.Cd = g.Cd; a.ldw = g.ldw;
-    const int bc = (g.Cd >= 256 && g.Cd % 256 == 0) ? 256 : (g.Cd <= 64 ? 64 : 128);
-    const int bnw = (g.Cs <= 64 && bc == 64) ? 64 : 128;      // (256 x 64 as two 4-wave blocks per CU was slower than 256 x 128 with half of its columns empty: 0.115 against 0.106 ms at 56 x 56)
+    a.dy2 = dy2; a.Cd1 = dy2 ? g.Cd - cd2 : g.Cd; a.Cd2 = cd2;
+    // (stacked: the first tensor's channels fill whole tiles; the second's last tile may be partly empty)
+    const int bc = dy2 ? (a.Cd1 % 256 == 0 ? 256 : 128) : ((g.Cd >= 256 && g.Cd % 256 == 0) ? 256 : (g.Cd <= 64 ? 64 : 128));
+    static const bool no_wide = getenv("IIF_WGRAD_NO_64X256") != nullptr;
+    const int bnw = (g.Cs <= 64 && bc == 64) ? 64 : ((bc == 64 && g.Cs > 128 && g.Cs % 256 == 0 && !no_wide) ? 256 : 128);      // (256 x 64 as two 4-wave blocks per CU was slower than 256 x 128 with half of its columns empty: 0.115 against 0.106 ms at 56 x 56)
     a.ktiles = (g.Cd + bc - 1) / bc;
     a.ntiles = (g.Cs + bnw - 1) / bnw;
     a.nsteps = (g.M + 31) / 32;
     const int tiles = a.ktiles * a.ntiles;
     // blocks per CU by LDS (3 stages of 32 x (bnw + bc) x 2 bytes) and registers: 256 x 128: one 8-wave block (72 KB);
     // 128 x 128: three (48 KB); 64 x {128, 64}: four
-    const int per_cu = bc == 256 ? 1 : (bc == 128 ? 3 : 4);
+    const int per_cu = bc == 256 ? 1 : (bc == 128 ? 3 : (bnw == 256 ? 2 : 4));
     int splits = splits_req;
     const int64_t slab = (int64_t)g.Cd * g.ldw;
     if (splits <= 0) {
@@ -1134,7 +1152,7 @@ inline int launch_wgrad_1x1(const WgArgs& g, float* dw, float* ws, int64_t ws_by
         // shortcut stream: nothing waits for it.  IIF_WGRAD_GRAM_DIV / IIF_WGRAD_SMALL_DIV = 1 restore the full round of splits.
         static const int small_div = [] { const char* e = getenv("IIF_WGRAD_SMALL_DIV"); return e ? atoi(e) : 2; }();
         static const int gram_div = [] { const char* e = getenv("IIF_WGRAD_GRAM_DIV"); return e ? atoi(e) : 8; }();
-        const bool gram = g.x == g.dy;
+        const bool gram = g.x == g.dy && dy2 == nullptr;
         const int div = gram ? gram_div : (slab * 4 <= (256 << 10) ? small_div : 1);
         if (div > 1 && splits > 8) { splits /= div; if (splits < 8) splits = 8; }       // (never more splits than before)
     }
@@ -1153,6 +1171,7 @@ inline int launch_wgrad_1x1(const WgArgs& g, float* dw, float* ws, int64_t ws_by
     const unsigned xb = (unsigned)x_bytes, yb = (unsigned)dy_bytes;
     if (bc == 256) hipLaunchKernelGGL(wgrad1x1_256x128_kernel, grid, dim3(512), 0, st, a, xb, yb);
     else if (bc == 128) hipLaunchKernelGGL(wgrad1x1_128x128_kernel, grid, dim3(256), 0, st, a, xb, yb);
+    else if (bnw == 256) hipLaunchKernelGGL(wgrad1x1_64x256_kernel, grid, dim3(512), 0, st, a, xb, yb);
     else if (bnw == 128) hipLaunchKernelGGL(wgrad1x1_64x128_kernel, grid, dim3(256), 0, st, a, xb, yb);
     else hipLaunchKernelGGL(wgrad1x1_64x64_kernel, grid, dim3(256), 0, st, a, xb, yb);
     IIF_LAUNCH_CHECK();
@@ -1273,6 +1292,23 @@ extern "C" int iif_conv_wgrad(const iif_conv_desc* d, const void* x, const void*
     if (d->dtype == IIF_BF16)
         return launch_wgrad<unsigned short>(a, dw, (float*)workspace, workspace_bytes, splits, x_bytes, dy_bytes, st);
     return launch_wgrad<float>(a, dw, (float*)workspace, workspace_bytes, splits, x_bytes, dy_bytes, st);
+}
+
+extern "C" int iif_wgrad1x1_stacked(const void* x, const void* dy, const void* dy2, int64_t m, int cs, int cd1, int cd2, int ldw,
+                                    float* out, void* workspace, int64_t workspace_bytes, int splits, void* stream) {
+    if (!x || !dy || !dy2 || !out || m <= 0 || cs <= 0 || cd1 <= 0 || cd2 <= 0 || workspace_bytes < 0) return IIF_EINVAL;
+    if (cs % 8 || cd1 % 128 || cd2 % 8 || ldw % 4 || ldw < cs) return IIF_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dy2) |
+         reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(workspace)) & 15)
+        return IIF_EUNSUPPORTED;
+    if (m > 0x7fffff00LL || m * cs * 2 >= 0x7f000000LL || m * cd1 * 2 >= 0x7f000000LL || m * cd2 * 2 >= 0x7f000000LL) return IIF_EUNSUPPORTED;
+    WgArgs a{};
+    a.x = (const unsigned char*)x; a.dy = (const unsigned char*)dy;
+    a.N = 1; a.Hs = 1; a.Ws = (int)m; a.Cs = cs; a.Hd = 1; a.Wd = (int)m; a.Cd = cd1 + cd2;
+    a.R = 1; a.S = 1; a.sshift = 0; a.pad = 0; a.ldw = ldw; a.M = (int)m; a.K = cs; a.groups = 1;
+    a.xpitch = cs; a.ypitch = cd1;
+    return launch_wgrad_1x1(a, out, (float*)workspace, workspace_bytes, splits, m * cs * 2, m * cd1 * 2, as_stream(stream),
+                            (const unsigned char*)dy2, cd2);
 }
 
 #ifdef IIF_CONV_STAMPS

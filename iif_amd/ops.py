@@ -101,6 +101,19 @@ def conv_wgrad(x, dy, r, s, stride, pad, ldw=None, out=None, workspace=None, spl
     return out
 
 
+def wgrad1x1_stacked(x2d, dy2d, dy2_2d, out, workspace, splits=0):
+    """out[:cd1] = dy^T x, out[cd1:] = dy2^T x in one pass over x (bf16 [m, c] views; out float32 [cd1 + cd2, ldw])."""
+    require_gpu(x2d, dy2d, dy2_2d, out, workspace)
+    m, cs = x2d.shape
+    cd1, cd2 = dy2d.shape[1], dy2_2d.shape[1]
+    if not out.is_contiguous() or out.shape[0] < cd1 + cd2:
+        raise ValueError("wgrad1x1_stacked: out must be a contiguous float32 [cd1 + cd2, ldw] tensor")
+    wsb = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    check(lib().iif_wgrad1x1_stacked(ptr(x2d), ptr(dy2d), ptr(dy2_2d), m, cs, cd1, cd2, out.shape[1], ptr(out), ptr(workspace), wsb,
+                                     splits, stream_ptr()), "iif_wgrad1x1_stacked")
+    return out
+
+
 # ------------------------------------------------------------------ batch norm
 def bn_workspace(m, c, device):
     nbytes = lib().iif_bn_workspace_bytes(m, c)

@@ -802,7 +802,8 @@ class _Plan(object):
             F = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)   # noqa: E731
             # per-block scratch rotates over wg_lag slots (the weight-gradient stream finishes block b before block b - wg_lag
             # starts: _wgrad_fence); Gram / colsum are issued one block AHEAD on another stream, so they rotate over wg_lag + 1
-            self.a3 = [{"P": F(Cm, ldm), "coef": F(3, Cm), "bias": F(cm),
+            # "P" holds P = g~^T a2 [C, ldw] and, behind it, the Gram matrix a2^T a2 [c, ldw] where one stacked launch writes both
+            self.a3 = [{"P": F(Cm + cm, ldm), "coef": F(3, Cm), "bias": F(cm),
                         "wt": torch.zeros(cm * (Cm + cm), dtype=dt, device=dev),
                         "scr": torch.empty(max(ops.lib().iif_bn3_algebra_prep_scratch_floats(u.conv.cout, u.conv.cin)
                                                for u in self.alg3_units), dtype=torch.float32, device=dev),
@@ -1415,6 +1416,13 @@ class _Plan(object):
     def _a3_is_pure(self, u):
         return u.n * u.ho * u.wo * u.conv.cout >= self.a3_pure_min
 
+    def _a3_gram_stacked(self, u):
+        """The Gram matrix a2^T a2 rides in the launch that forms P on the weight-gradient stream ([g~ | a2]^T a2,
+        iif_wgrad1x1_stacked: the extra channel tile re-reads rows of a2 the launch streams anyway) instead of a launch and a
+        slab reduction of its own a block ahead.  Not where P is formed on the compute stream ("pure" units): there the extra
+        tile would lengthen the critical path."""
+        return (not self._a3_is_pure(u)) and u.conv.cout % 128 == 0 and self.wg_stream is not None and not os.environ.get("IIF_NO_GRAM_STACKED")
+
     def _bn3_gram_async(self, u, bi):
         """Gram = a2^T a2 and colsum(a2) of an algebra unit's input: forward data only, so it is issued a block ahead on the
         shortcut stream (idle outside the four downsample blocks) and never waited for in practice."""
@@ -1423,8 +1431,9 @@ class _Plan(object):
         a2 = u.src
 
         def work():
-            ops.conv_wgrad(a2, a2, 1, 1, 1, 0, ldw=cv.ldw, out=A["gram"].view(-1)[:cv.cin * cv.ldw].view(cv.cin, cv.ldw),
-                           workspace=A["ws_gram"])
+            if not self._a3_gram_stacked(u):
+                ops.conv_wgrad(a2, a2, 1, 1, 1, 0, ldw=cv.ldw, out=A["gram"].view(-1)[:cv.cin * cv.ldw].view(cv.cin, cv.ldw),
+                               workspace=A["ws_gram"])
             ops.bn_stats_sums(a2.view(-1, cv.cin), A["csum"].view(-1)[:2 * cv.cin].view(2, cv.cin), A["ws_sum"])
         st = self.ds_stream if self.ds_stream is not None else self.wg_stream
         if st is None:
@@ -1463,10 +1472,17 @@ class _Plan(object):
         ops.bn3_algebra_prep(P if pure else None, wb, c, rows, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt,
                              A["bias"][:c], A["scr"], A["tickets"], colsum2=Ag["csum"].view(-1)[:c])
 
+        stacked = self._a3_gram_stacked(u)
+
         def finish_dw(ws, sp):
-            if not pure:
+            gram = Ag["gram"].view(-1)[:c * cv.ldw].view(c, cv.ldw)
+            if stacked:
+                ext = A["P"].view(-1)[:(C + c) * cv.ldw].view(C + c, cv.ldw)
+                ops.wgrad1x1_stacked(u.src.view(m, c), gt.view(m, C), u.src.view(m, c), ext, ws, splits=sp)
+                gram = ext[C:]
+            elif not pure:
                 ops.conv_wgrad(u.src, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=ws, splits=sp)
-            ops.bn3_algebra_dw(P, wb, c, Ag["gram"].view(-1)[:c * cv.ldw].view(c, cv.ldw), Ag["csum"].view(-1)[:c], coef, cv._g2d)
+            ops.bn3_algebra_dw(P, wb, c, gram, Ag["csum"].view(-1)[:c], coef, cv._g2d)
         if self.wg_stream is None:
             finish_dw(self.a3_ws, 0)
         else:

@@ -181,6 +181,15 @@ int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, const void* 
 int iif_conv_wgrad(const iif_conv_desc* d, const void* x, const void* dy, float* dw,
                    void* workspace, int64_t workspace_bytes, int splits, void* stream);
 
+/* 1x1 weight gradient against TWO gradient tensors stacked along the channels, one pass over x (bf16):
+ *   out[k][:] = sum_m dy[m][k] x[m][:] for k < cd1,   out[cd1 + j][:] = sum_m dy2[m][j] x[m][:] for j < cd2;
+ * out float [cd1 + cd2][ldw], split-K slabs and `splits` as iif_conv_wgrad.  The BN-by-algebra backward
+ * (iif_bn3_algebra_*) takes P = g~^T a2 and the Gram matrix a2^T a2 from one launch this way (dy = g~, dy2 = x = a2).
+ * cd1 % 128 == 0, cs % 8 == 0, cd2 % 8 == 0; otherwise IIF_EUNSUPPORTED. */
+int iif_wgrad1x1_stacked(const void* x, const void* dy, const void* dy2, int64_t m, int cs, int cd1, int cd2,
+                         int ldw, float* out, void* workspace, int64_t workspace_bytes, int splits,
+                         void* stream);
+
 /* Training-mode batch norm, NHWC activation viewed as x[m, c] (m = N*H*W).
  * Replaces F.batch_norm(training=True) + ReLU + residual add and their autograd
  * backward under resnet_pytorch.py:152-167 / resnet_cifar.py:133-138.

@@ -107,9 +107,11 @@ HALO_WGRAD = [(2, 64, 14, 14, 64, 3, 1, 1), (3, 128, 7, 7, 64, 3, 1, 1), (2, 64,
               (4, 64, 2, 2, 64, 3, 1, 1), (3, 128, 1, 1, 64, 3, 1, 1), (2, 64, 4, 3, 128, 3, 1, 1), (40, 64, 1, 2, 64, 3, 1, 1)]
 # >= 256 output channels with long kernel rows (the 256-channel tile, 8 waves)
 SQUARE_WGRAD = [(2, 512, 14, 14, 256, 1, 1, 0), (2, 256, 15, 13, 256, 3, 2, 1), (3, 768, 7, 7, 512, 1, 1, 0)]
+# 1x1 with <= 64 output and 256 k input channels: the 64 x 256 tile (wgrad1x1_64x256_kernel: half of its waves issue a dump piece)
+WIDE_X_WGRAD = [(2, 256, 28, 28, 64, 1, 1, 0), (3, 512, 9, 11, 64, 1, 1, 0), (1, 256, 7, 5, 32, 1, 1, 0), (4, 256, 56, 56, 64, 1, 1, 0)]
 
 
-@pytest.mark.parametrize("case", CASES + [(4, 64, 28, 28, 64, 3, 1, 1), (2, 64, 33, 31, 256, 1, 1, 0)] + HALO_WGRAD + SQUARE_WGRAD)
+@pytest.mark.parametrize("case", CASES + [(4, 64, 28, 28, 64, 3, 1, 1), (2, 64, 33, 31, 256, 1, 1, 0)] + HALO_WGRAD + SQUARE_WGRAD + WIDE_X_WGRAD)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_conv_wgrad(case, dt):
     from iif_amd import ops
@@ -1056,3 +1058,32 @@ def test_group_pack_batched_equals_the_per_layer_launches(dt):
     torch.cuda.synchronize()
     for e, ref in zip(ent, want):
         assert torch.equal(e[5], ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2 * 28 * 28, 128, 512, 128), (3 * 14 * 14 + 5, 256, 1024, 256), (777, 64, 256, 64), (4 * 196, 128, 128, 128),
+                                  (1000, 256, 384, 40)])
+def test_wgrad1x1_stacked_equals_two_weight_gradients(case):
+    """iif_wgrad1x1_stacked: [dy | dy2]^T x in one pass (P = g~^T a2 and the Gram matrix a2^T a2 of the BN-by-algebra
+    backward) against the float64 products of the same bf16 operands; pad columns untouched; splits 0 / 1 / -2."""
+    from iif_amd import ops
+    m, cs, cd1, cd2 = case
+    g = torch.Generator().manual_seed(m + cs + cd1)
+    x = torch.randn(m, cs, generator=g).bfloat16()
+    dy = torch.randn(m, cd1, generator=g).bfloat16()
+    dy2 = x[:, :cd2].contiguous() if cd2 <= cs else torch.randn(m, cd2, generator=g).bfloat16()
+    ref = torch.cat([dy.double().t() @ x.double(), dy2.double().t() @ x.double()])
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    ldw = cs + 16
+    xd, dyd, dy2d = x.to(DEV), dy.to(DEV), dy2.to(DEV)
+    for splits in (0, 1, -2):
+        out = torch.full((cd1 + cd2, ldw), 7.0, device=DEV)
+        ops.wgrad1x1_stacked(xd, dyd, dy2d, out, ws, splits=splits)
+        assert (out[:, cs:] == 7.0).all()
+        assert (out[:, :cs].double().cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), (case, splits)
+    a = torch.zeros((cd1 + cd2, ldw), device=DEV)
+    ops.wgrad1x1_stacked(xd, dyd, dy2d, a, ws)
+    assert torch.equal(a, out.new_tensor(a))            # (contiguity)
+    b = torch.zeros_like(a)
+    ops.wgrad1x1_stacked(xd, dyd, dy2d, b, ws)
+    assert torch.equal(a, b)                            # deterministic
