@@ -14,7 +14,7 @@ BENCH="$root/bench.py --no-cpu-baseline --no-kernel-events --no-fp32-step"
 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/p_kt -- python3 $BENCH --steps 10 --warmup 3 > $out/kt.log 2>&1
 db=$(find /tmp/p_kt -name "*.db" | head -1)
 python3 $root/scripts/rocpd_stats.py $db $out/${tag}_kernel_stats.csv
-python3 $root/scripts/rocpd_timeline.py $db 2 $out/${tag}_step_listing.txt > $out/${tag}_step_timeline.txt
+python3 $root/scripts/rocpd_timeline.py $db 0 $out/${tag}_step_listing.txt > $out/${tag}_step_timeline.txt
 echo "trace done" > $out/progress.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d /tmp/p_f -- python3 $BENCH --steps 4 --warmup 2 > $out/f.log 2>&1
 echo "fetch done" >> $out/progress.txt

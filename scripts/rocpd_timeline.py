@@ -7,12 +7,21 @@ import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
-back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # 0: the step of median length (a profiler flush can stall one step by milliseconds)
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
 rows = db.execute("select name, start, end, %s from kernels order by start" % (qcol or "0")).fetchall()
 sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
-lo, hi = sgd[-back - 1] + 1, sgd[-back] + 1
+if back <= 0:
+    spans = []
+    for i in range(1, len(sgd)):
+        seg = rows[sgd[i - 1] + 1:sgd[i] + 1]
+        spans.append((max(r[2] for r in seg) - seg[0][1], i))
+    spans = sorted(spans[len(spans) // 3:])               # (the first third are warm-up steps)
+    mid = spans[len(spans) // 2][1]
+    lo, hi = sgd[mid - 1] + 1, sgd[mid] + 1
+else:
+    lo, hi = sgd[-back - 1] + 1, sgd[-back] + 1
 step = rows[lo:hi]
 t0, t1 = step[0][1], max(r[2] for r in step)
 print("step: %d launches, %.3f ms wall (%s column: %s)" % (len(step), (t1 - t0) / 1e6, "queue", qcol))
