@@ -456,11 +456,12 @@ def test_dgrad_emits_upstream_bn_backward_sums(case):
     nt = ops.conv_dgrad_bnbwd(nhwc(dy.float()).to(dt).to(DEV), wtt.to(DEV), k, k, stride, pad, (h, w), out,
                               nhwc(upx.float()).to(dt).to(DEV), bits if use_bits else None, stats.to(DEV), partial.view(-1),
                               res=nhwc(res.float()).to(dt).to(DEV) if use_res else None)
-    ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt.float(), dy.float(), stride, pad)
+    # float64 textbook gradient of the same bf16 operands (the register-weight epilogue variants included: the cases above)
+    ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt.double(), dy.double(), stride, pad)
     if use_res:
-        ref = ref + res.float()
+        ref = ref + res.double()
     got = out.float().cpu().permute(0, 3, 1, 2)
-    assert (got - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    assert (got.double() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
     gq = got * ((pre.float() > 0) if use_bits else 1.0)             # the sums are over the STORED values
     xhat = (upx.float() - stats[0][None, :, None, None]) * stats[1][None, :, None, None]
     s1, s2 = gq.sum(dim=(0, 2, 3)), (gq * xhat).sum(dim=(0, 2, 3))

@@ -349,8 +349,9 @@ def test_bf16_fused_bn_backward_sums_match_the_reduction_pass(arch, C, B, hw):
         a_, b_ = fused[off:off + rows * pitch], plain[off:off + rows * pitch]
         e = (a_ - b_).norm().item() / max(b_.norm().item(), 1e-12)
         # the stem's BN sits behind all 50 layers of amplification: 5.1e-2 .. 6.2e-2 over three seeds with the round-2 kernels
-        # AND with the round-3 ones (profiles/r3_fused_sums_noise.txt, scripts/dbg_fused_sums.py); every other tensor <= 2.3e-2
-        assert e <= (1e-1 if m_ is net.bn1 else 6e-2), (type(m_).__name__, attr, e)
+        # AND with the round-3 ones (profiles/r3_fused_sums_noise.txt, scripts/dbg_fused_sums.py); every other tensor <= 2.3e-2.
+        # Round 5 (profiles/r5_fused_sums_noise.txt): 5.1e-2 .. 6.0e-2 for bn1.bias, <= 1.8e-2 elsewhere, 1.1e-2 whole
+        assert e <= (8e-2 if m_ is net.bn1 else 3e-2), (type(m_).__name__, attr, e)
 
 
 @pytest.mark.parametrize("streams", ["three_streams", "no_shortcut_stream", "one_stream"])
@@ -392,7 +393,7 @@ def test_bn3_backward_by_algebra_inside_the_step(monkeypatch, pure, streams):
         off = net._offsets[(id(m_), attr)][0]
         a_, b_ = alg[off:off + rows * pitch], std[off:off + rows * pitch]
         e = (a_ - b_).norm().item() / max(b_.norm().item(), 1e-12)
-        assert e <= (1e-1 if m_ is net.bn1 else 6e-2), (type(m_).__name__, attr, e)
+        assert e <= (8e-2 if m_ is net.bn1 else 3e-2), (type(m_).__name__, attr, e)
 
 
 def test_stride1_shortcut_bn_backward_by_algebra(monkeypatch):
@@ -428,7 +429,7 @@ def test_stride1_shortcut_bn_backward_by_algebra(monkeypatch):
         if m_ is ds[0] or m_ is ds[1]:
             assert e <= 2e-2, (type(m_).__name__, attr, e)  # the shortcut's own weight / BN gradients: nothing amplifies them
         else:
-            assert e <= (1e-1 if m_ is net.bn1 else 6e-2), (type(m_).__name__, attr, e)
+            assert e <= (8e-2 if m_ is net.bn1 else 3e-2), (type(m_).__name__, attr, e)
 
 
 @pytest.mark.parametrize("arch,C,B,hw,alg3", [("resnet50", 1000, 16, 64, False), ("resnet50", 1000, 16, 64, True),
