@@ -777,3 +777,30 @@ def test_side_streams_follow_the_size_of_the_step(monkeypatch):
     on_b, _, _ = run(big, (48, 3, 224, 224), {})
     off_b, _, _ = run(big, (48, 3, 224, 224), {"IIF_SIDE_STREAMS": "0"})
     assert on_b and not off_b
+
+
+@pytest.mark.parametrize("arch,C,B,hw", [("resnet50", 1000, 8, 64), ("resnext50_32x4d", 365, 8, 64)])
+def test_two_weight_gradient_streams_give_the_same_gradients(arch, C, B, hw, monkeypatch):
+    """IIF_WG_STREAMS=2 (weight gradients round robin over two streams, every split-K round sized for half of the device:
+    iif_conv_wgrad splits = -2) against the default single stream: the same gradients up to the fp32 summation order of the
+    split-K slabs, and bit-identical when repeated (events order every hand-over between the streams)."""
+    from iif_amd.custom import IIFLoss
+    counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
+    x, y = _data(B, hw, counts, seed=31)
+    xd, yd = x.to(DEV), y.to(DEV)
+    crit = IIFLoss(DS(counts), variant="raw")
+    monkeypatch.setenv("IIF_SIDE_STREAMS", "1")
+    grads = []
+    for nws in ("1", "2"):
+        monkeypatch.setenv("IIF_WG_STREAMS", nws)
+        net, sd = _build(arch, C, torch.bfloat16)
+        net.load_state_dict(damp_residual_branches(sd, arch))
+        net.train()
+        net.loss_and_backward(xd, yd, crit)
+        assert len(net._saved.wg_streams) == int(nws)
+        g1 = net._grad_arena.clone()
+        net.loss_and_backward(xd, yd, crit)
+        assert torch.equal(net._grad_arena, g1)
+        grads.append(g1)
+    err = (grads[1] - grads[0]).norm().item() / grads[0].norm().item()
+    assert err <= 1e-5, err
