@@ -94,6 +94,7 @@ SIGNATURES = {
     "iif_maxpool_bn_forward": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "iif_bn_backward_relu_recompute": [_P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _L, _P],
     "iif_bn_backward_relu_recompute_pooled": [_P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P],
+    "iif_bn_backward_pool_fused": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P],
     "iif_rowmap_forward": [_P, _I, _I, _I, _L, _I, _F, _F, _P, _I, _L, _P, _P],
     "iif_rowmap_backward": [_P, _I, _P, _P, _I, _I, _I, _L, _L, _I, _F, _F, _P, _I, _L, _P],
     "iif_transpose_f32": [_P, _I, _I, _L, _P, _L, _P],

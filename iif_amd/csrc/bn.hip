@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "vec16.h"
+#include "pool_gather.h"
 
 namespace {
 
@@ -760,6 +761,117 @@ inline bool bad_align(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+// Stem, round 5: the max-pool backward gathered INSIDE the normalisation pass.  The scattered gradient (the stem's resolution,
+// three quarters zeros: 411 MB written by iif_maxpool_backward and read again here) is never formed: a thread gathers its vector
+// from the (at most four) pooled windows whose arg max points at its pixel (pool_gather.h), rounds it to the storage type as the
+// stored tensor was, and goes on as bn_bwd_apply_kernel<T, 3>: 1.64 -> 0.98 GB, one launch less at the end of backward where little
+// else runs.  One image row per block; 256 % (C / V) == 0, so a thread keeps one channel vector's coefficients.
+// the four windows of pool321_gather (pool_gather.h) as one batch of loads: (row B, col B), (row B, col A), (row A, col B),
+// (row A, col A) - clamped addresses, the predicates kept for the sum, which adds in that same order
+template <typename T> struct PoolTaps {
+    u32x4 g[4];
+    unsigned code[4][2];
+    int want[4];
+    bool use[4];
+};
+template <typename T>
+__device__ __forceinline__ void pool321_issue(const T* gy, const unsigned char* idx, int n, int h, int w, int c, int C, int Ho, int Wo,
+                                              PoolTaps<T>& t) {
+    constexpr int V = VT<T>::V;
+    const int th = h + 1, tw = w + 1;
+    const int hoA = th >> 1, woA = tw >> 1;
+    const int rA = th & 1, sA = tw & 1;
+    const bool vhA = hoA < Ho, vwA = woA < Wo;
+    const bool vhB = rA == 0, vwB = sA == 0;
+    const int hA = vhA ? hoA : Ho - 1, wA = vwA ? woA : Wo - 1;
+    const int hB = vhB ? hoA - 1 : hA, wB = vwB ? woA - 1 : wA;
+    const int64_t base = (int64_t)n * Ho;
+    const int hh[4] = {hB, hB, hA, hA}, ww[4] = {wB, wA, wB, wA};
+    t.want[0] = 2 * 3 + 2; t.want[1] = 2 * 3 + sA; t.want[2] = rA * 3 + 2; t.want[3] = rA * 3 + sA;
+    t.use[0] = vhB && vwB; t.use[1] = vhB && vwA; t.use[2] = vhA && vwB; t.use[3] = vhA && vwA;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t o = ((base + hh[k]) * Wo + ww[k]) * C + c;
+        t.g[k] = VT<T>::raw(gy + o);
+        if constexpr (V == 8) {
+            const uint2 cc = *reinterpret_cast<const uint2*>(idx + o);
+            t.code[k][0] = cc.x; t.code[k][1] = cc.y;
+        } else {
+            t.code[k][0] = *reinterpret_cast<const unsigned int*>(idx + o); t.code[k][1] = 0;
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void pool321_sum(const PoolTaps<T>& t, float (&acc)[VT<T>::V]) {
+    constexpr int V = VT<T>::V;
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float g[V];
+        VT<T>::unpack(t.g[k], g);
+#pragma unroll
+        for (int q = 0; q < V; ++q)
+            if (t.use[k] && (int)((t.code[k][q >> 2] >> (8 * (q & 3))) & 0xffu) == t.want[k]) acc[q] += g[q];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) pool_bn_bwd_apply_kernel(const T* gp, const unsigned char* idx, const T* x, const float* stats,
+                                                                const float* coef, T* dx, int H, int W, int C, int Ho, int Wo,
+                                                                int total_rows, int rows_per_block) {
+    constexpr int V = VT<T>::V;
+    const unsigned cv = (unsigned)C / V, rowv = (unsigned)W * cv;
+    // Blocks go round the 8 XCDs; a pooled row is gathered by three image rows.  XCD k walks the k-th eighth of the row groups in
+    // order, so neighbouring rows meet in one L2.
+    const unsigned ngroups = gridDim.x, per = ngroups >> 3;
+    const unsigned grp = (ngroups & 7u) == 0 ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const unsigned r0 = grp * (unsigned)rows_per_block;
+    unsigned nr = (unsigned)rows_per_block;
+    if (r0 + nr > (unsigned)total_rows) nr = (unsigned)total_rows - r0;
+    const unsigned nvec = nr * rowv;                                     // this block's vectors: thread t takes t, t + 256, ...
+    const int c0 = (int)(threadIdx.x % cv) * V;                          // (rowv % cv == 0 and 256 % cv == 0: one channel vector per thread)
+    float k1[V], k2[V], k3[V], mu[V], aa[V], bb[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        k1[k] = coef[c0 + k]; k2[k] = coef[C + c0 + k]; k3[k] = coef[2 * C + c0 + k]; mu[k] = stats[c0 + k];
+        aa[k] = stats[2 * C + c0 + k]; bb[k] = stats[3 * C + c0 + k];
+    }
+    const int64_t base = (int64_t)r0 * W * C;
+    // one vector per step, the NEXT step's seven loads requested before this step's arithmetic: a block is one stream of
+    // round trips instead of load / compute / store phases (3 blocks per CU at 136 VGPRs did not hide those: 297 us)
+    u32x4 xr[2];
+    PoolTaps<T> taps[2];
+    auto issue = [&](unsigned t, int slot) {
+        const unsigned tt = t < nvec ? t : threadIdx.x;
+        const unsigned rr = tt / rowv, j = tt - rr * rowv;
+        const unsigned row = r0 + rr, n = row / (unsigned)H, h = row - n * (unsigned)H;
+        xr[slot] = VT<T>::raw_nt(x + base + (int64_t)tt * V);
+        pool321_issue<T>(gp, idx, (int)n, (int)h, (int)(j / cv), c0, C, Ho, Wo, taps[slot]);
+    };
+    auto finish = [&](unsigned t, int slot) {
+        float g[V], xv[V];
+        pool321_sum<T>(taps[slot], g);
+        VT<T>::unpack(xr[slot], xv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float d = fmaf(aa[k], xv[k], bb[k]) > 0.f ? VT<T>::round_trip(g[k]) : 0.f;
+            xv[k] = k1[k] * (d - k2[k] - (xv[k] - mu[k]) * k3[k]);
+        }
+        VT<T>::template store_as<false>(dx + base + (int64_t)t * V, xv);
+    };
+    if (threadIdx.x >= nvec) return;
+    issue(threadIdx.x, 0);
+    for (unsigned t = threadIdx.x; t < nvec; t += 512) {
+        issue(t + 256, 1);
+        finish(t, 0);
+        if (t + 256 < nvec) {
+            issue(t + 512, 0);
+            finish(t + 256, 1);
+        }
+    }
+}
+
 extern "C" {
 
 int64_t iif_bn_workspace_bytes(int64_t m, int c) { return ((int64_t)1100 * 2 * c + 3 * (int64_t)c) * 4 + 256; }
@@ -903,6 +1015,54 @@ int iif_bn_backward_relu_recompute_pooled(const void* gy, const void* x, int dty
     IIF_LAUNCH_CHECK();
     return bn_backward_t<unsigned short>((const unsigned short*)gy, nullptr, nullptr, (const unsigned short*)x, stats, gamma, m, c, dgamma,
                                          dbeta, (unsigned short*)dx, nullptr, ws, workspace_bytes, st, rows, nblk, true);
+}
+
+int iif_bn_backward_pool_fused(const void* g_pool, const uint8_t* argmax, const void* pool_x, const void* x, int dtype, int n, int h,
+                               int w, int c, int ho, int wo, const float* stats, const float* gamma, float* dgamma, float* dbeta,
+                               void* dx, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!g_pool || !argmax || !pool_x || !x || !stats || !gamma || !dgamma || !dbeta || !dx || !workspace || n <= 0 || h <= 0 ||
+        w <= 0 || c <= 0)
+        return IIF_EINVAL;
+    if (ho != (h + 2 - 3) / 2 + 1 || wo != (w + 2 - 3) / 2 + 1) return IIF_EINVAL;            // 3x3 / stride 2 / pad 1 only
+    const int64_t m = (int64_t)n * h * w, pool_pixels = (int64_t)n * ho * wo;
+    if (m > 0x7fffff00LL || bad_align(g_pool) || bad_align(pool_x) || bad_align(x) || bad_align(dx)) return IIF_EUNSUPPORTED;
+    const int v = dtype == IIF_F32 ? 4 : 8;
+    if ((dtype != IIF_F32 && dtype != IIF_BF16) || c % v || 256 % (c / v) || 2 * c > 256) return IIF_EUNSUPPORTED;
+    int nblk = (int)(pool_pixels / 64 < 512 ? (pool_pixels + 63) / 64 : 512);
+    const int64_t ppb = (pool_pixels + nblk - 1) / nblk;
+    nblk = (int)((pool_pixels + ppb - 1) / ppb);
+    const int64_t need = ((int64_t)nblk * 2 * c + 3 * c) * 4;
+    if (need > workspace_bytes) return IIF_EINVAL;
+    float* rows = (float*)workspace;
+    float* coef = rows + (int64_t)nblk * 2 * c;
+    hipStream_t st = as_stream(stream);
+    const dim3 blk(256);
+    // the sums exactly as iif_bn_backward_relu_recompute_pooled forms them (same kernel, same rows, same finalisation)
+    if (dtype == IIF_F32)
+        hipLaunchKernelGGL(pool_bwd_sums_kernel<float>, dim3(nblk), blk, 0, st, (const float*)g_pool, (const float*)pool_x, stats, pool_pixels, c,
+                           ppb, rows);
+    else
+        hipLaunchKernelGGL(pool_bwd_sums_kernel<unsigned short>, dim3(nblk), blk, 0, st, (const unsigned short*)g_pool,
+                           (const unsigned short*)pool_x, stats, pool_pixels, c, ppb, rows);
+    IIF_LAUNCH_CHECK();
+    const int cb = finalize_cb(nblk);
+    const dim3 fgrid((c + cb - 1) / cb);
+    if (cb == 4) hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, fgrid, blk, 0, st, rows, nblk, c, (double)m, gamma, stats, dgamma, dbeta, coef);
+    else if (cb == 8) hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, fgrid, blk, 0, st, rows, nblk, c, (double)m, gamma, stats, dgamma, dbeta, coef);
+    else hipLaunchKernelGGL(bn_bwd_finalize_kernel<32>, fgrid, blk, 0, st, rows, nblk, c, (double)m, gamma, stats, dgamma, dbeta, coef);
+    IIF_LAUNCH_CHECK();
+    const int total_rows = n * h;
+    int rpb = 8;                     // rows per block: 28 pipelined steps per thread at 112 x 64 channels (2: 247 us, 4: 238, 8-28: 230)
+    if ((int64_t)rpb * w * (c / v) < 2048) rpb = (int)((2048 + (int64_t)w * (c / v) - 1) / ((int64_t)w * (c / v)));
+    const dim3 agrid((unsigned)((total_rows + rpb - 1) / rpb));
+    if (dtype == IIF_F32)
+        hipLaunchKernelGGL(pool_bn_bwd_apply_kernel<float>, agrid, blk, 0, st, (const float*)g_pool, argmax, (const float*)x, stats, coef,
+                           (float*)dx, h, w, c, ho, wo, total_rows, rpb);
+    else
+        hipLaunchKernelGGL(pool_bn_bwd_apply_kernel<unsigned short>, agrid, blk, 0, st, (const unsigned short*)g_pool, argmax,
+                           (const unsigned short*)x, stats, coef, (unsigned short*)dx, h, w, c, ho, wo, total_rows, rpb);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
 }
 
 int iif_bn_backward_partials_fused(const void* gy, const uint8_t* relu_bits, const void* x, int dtype, int64_t m, int c,

@@ -25,6 +25,7 @@ template <> struct VT<float> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(t[i]);
     }
+    static __device__ __forceinline__ float round_trip(float v) { return v; }       // a value as the storage type holds it
     template <bool NT> static __device__ __forceinline__ void store_as(float* p, const float (&v)[4]) {
         const f32x4 t{v[0], v[1], v[2], v[3]};
         if (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p)); else *reinterpret_cast<f32x4*>(p) = t;
@@ -58,6 +59,7 @@ template <> struct VT<unsigned short> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_bits_to_f32(t[i] & 0xffffu); v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u); }
     }
+    static __device__ __forceinline__ float round_trip(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
     template <bool NT> static __device__ __forceinline__ void store_as(unsigned short* p, const float (&v)[8]) {
         u32x4 t;
 #pragma unroll

@@ -1694,13 +1694,26 @@ class _Plan(object):
         # ---- stem
         u = self.stem
         g_pooled = g
-        if net.style == "imagenet":
+        # bf16 with the fused forward pool: the max-pool backward is gathered inside the BN-backward normalisation pass; the
+        # scattered gradient at the stem's resolution (411 MB at batch 256, written and read back) is never formed
+        pool_bwd_fused = (net.style == "imagenet" and self.pool_fused and self.dt != torch.float32
+                          and not os.environ.get("IIF_NO_POOL_BWD_FUSED"))
+        if net.style == "imagenet" and not pool_bwd_fused:
             dy0 = self._gbuf(("dy0",), u.y.shape)
             _lib.check(_lib.lib().iif_maxpool_backward(_lib.ptr(g), _lib.ptr(self.pool_idx), _lib.dtype_code(g), u.n, u.ho,
                                                        u.wo, u.conv.cout, 3, 2, 1, _lib.ptr(dy0), _lib.stream_ptr()),
                        "iif_maxpool_backward")
             g = dy0
-        if self.pool_fused:
+        if pool_bwd_fused:
+            cv, bn = u.conv, u.bn
+            dy0 = self._gbuf(("dy0",), u.y.shape)
+            ph, pw = g_pooled.shape[1], g_pooled.shape[2]
+            _lib.check(_lib.lib().iif_bn_backward_pool_fused(
+                _lib.ptr(g_pooled), _lib.ptr(self.pool_idx), _lib.ptr(self.pool_x), _lib.ptr(u.x), _lib.dtype_code(u.x), u.n, u.ho, u.wo,
+                cv.cout, ph, pw, _lib.ptr(u.stats), _lib.ptr(bn.weight), _lib.ptr(bn._dgamma), _lib.ptr(bn._dbeta), _lib.ptr(dy0),
+                _lib.ptr(self.bn_ws), self.bn_ws.numel(), _lib.stream_ptr()), "iif_bn_backward_pool_fused")
+            self._stem_wgrad(u, dy0)
+        elif self.pool_fused:
             cv, bn = u.conv, u.bn
             m = u.n * u.ho * u.wo
             g2 = g.view(m, cv.cout)

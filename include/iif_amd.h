@@ -567,6 +567,13 @@ int iif_bn_backward_relu_recompute_pooled(const void* gy, const void* x, int dty
                                           const float* gamma, float* dgamma, float* dbeta, void* dx, void* workspace,
                                           int64_t workspace_bytes, const void* g_pool, const void* pool_x, int64_t pool_pixels,
                                           void* stream);
+/* iif_maxpool_backward (3x3 / stride 2 / pad 1) + iif_bn_backward_relu_recompute_pooled in one: the pooled gradient g_pool
+ * [n][ho][wo][c] is gathered through `argmax` inside the normalisation pass, the scattered gradient at the stem's resolution
+ * [n][h][w][c] is never formed.  dx and dgamma / dbeta bit-identical to the two calls (the gathered value is rounded to the
+ * storage type as the stored tensor was).  workspace >= (min(512, ceil(n*ho*wo/64)) * 2c + 3c) * 4 bytes. */
+int iif_bn_backward_pool_fused(const void* g_pool, const uint8_t* argmax, const void* pool_x, const void* x, int dtype, int n,
+                               int h, int w, int c, int ho, int wo, const float* stats, const float* gamma, float* dgamma,
+                               float* dbeta, void* dx, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Compute-unit budget of the persistent grids (the weights-in-registers kernels, the stem, the streaming 1x1 kernel size their
  * grids to one or two resident blocks per CU).  Process-wide, default 0 = every CU of the device; a rank whose gradient

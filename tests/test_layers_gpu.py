@@ -573,8 +573,18 @@ def test_stem_bn_backward_sums_from_the_pooled_tensors(dt, gains):
                                         _lib.ptr(idx), _lib.ptr(pool_x), _lib.stream_ptr()), "pool")
     gp = torch.randn(n, ho, wo, c, generator=g).to(dt).to(DEV)
     out = {}
-    for mode in ("standard", "pooled"):
+    for mode in ("standard", "pooled", "fused"):
         dy0 = torch.empty(n, h, w, c, dtype=dt, device=DEV)
+        if mode == "fused":
+            # round 5: the max-pool backward gathered inside the normalisation pass (iif_bn_backward_pool_fused); no scattered tensor
+            dy0.fill_(float("nan"))
+            dgam, dbet = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+            ws = ops.bn_workspace(m, c, DEV)
+            _lib.check(L.iif_bn_backward_pool_fused(_lib.ptr(gp), _lib.ptr(idx), _lib.ptr(pool_x), _lib.ptr(x), _lib.dtype_code(x), n, h, w, c,
+                                                    ho, wo, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(dgam), _lib.ptr(dbet), _lib.ptr(dy0),
+                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "fused")
+            out[mode] = (dgam.cpu(), dbet.cpu(), dy0.float().cpu())
+            continue
         _lib.check(L.iif_maxpool_backward(_lib.ptr(gp), _lib.ptr(idx), _lib.dtype_code(gp), n, h, w, c, 3, 2, 1, _lib.ptr(dy0),
                                           _lib.stream_ptr()), "pool bwd")
         dgam, dbet = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
@@ -591,6 +601,8 @@ def test_stem_bn_backward_sums_from_the_pooled_tensors(dt, gains):
         out[mode] = (dgam.cpu(), dbet.cpu(), dy0.float().cpu())
     # bf16: the scattered gradient of a pixel that is the arg max of several windows was rounded to bf16 once more than the
     # pooled gradients themselves; everything else is summation order
+    for a, b in zip(out["fused"], out["pooled"]):            # dgamma, dbeta, dx: bit-identical to the two calls
+        assert torch.equal(a, b)
     tol = 2e-5 if dt == torch.float32 else 4e-3
     ref = out["standard"]
     got = out["pooled"]
