@@ -69,7 +69,7 @@ class ConvTimer(object):
     def wrap(self, ops):
         timer = self
         orig = {k: getattr(ops, k) for k in ("conv_forward", "conv_dgrad", "conv_wgrad", "conv_forward_bnstats",
-                                             "conv_dgrad_bnbwd", "conv_dgrad_masksum", "conv_dgrad2_bnbwd")}
+                                             "conv_dgrad_bnbwd", "conv_dgrad_masksum", "conv_dgrad2_bnbwd", "wgrad1x1_stacked")}
 
         def alg_k(r, s, stride, pad, cin):
             # algorithmic K of one output: the space-to-depth stem (4x4/1 pad 2 on 16 padded channels) is charged
@@ -133,6 +133,14 @@ class ConvTimer(object):
             by = nbytes(src, src2, wt, out, a[0] if a else kw.get("up_x"))
             return timer._timed("dgrad", fl, by, orig["conv_dgrad2_bnbwd"], src, src2, wt, bias, out, *a, **kw)
 
+        def wgrad1x1_stacked(x2d, dy2d, dy2_2d, out, workspace, **kw):
+            # [g~ | a2]^T a2: P is conv3's weight gradient (charged as conv_wgrad charges it), the Gram rows are work this design
+            # adds (0 FLOPs, as for conv_wgrad(a2, a2)); bytes: a2 and g~ once (dy2 IS x), the fp32 result
+            fl = 2.0 * x2d.shape[0] * x2d.shape[1] * dy2d.shape[1]
+            by = nbytes(x2d, dy2d) + 4.0 * (dy2d.shape[1] + dy2_2d.shape[1]) * x2d.shape[1]
+            return timer._timed("wgrad", fl, by, orig["wgrad1x1_stacked"], x2d, dy2d, dy2_2d, out, workspace, **kw)
+
+        ops.wgrad1x1_stacked = wgrad1x1_stacked
         ops.conv_forward, ops.conv_dgrad, ops.conv_wgrad = conv_forward, conv_dgrad, conv_wgrad
         ops.conv_dgrad_masksum, ops.conv_dgrad2_bnbwd = conv_dgrad_masksum, conv_dgrad2_bnbwd
         ops.conv_forward_bnstats = conv_forward_bnstats
@@ -184,7 +192,7 @@ def streaming_pass_bytes(net, batch, image):
                                                                                    pass over the unit's input)
         block outputs:                + read the residual                  1 s E
     plus the stem's max-pool (forward: the stem's activation is never stored, only the pooled tensor is written; backward:
-    read pooled gradient, write stem gradient), the global average pool, SGD = 20 B / parameter (read p, g, m; write p, m)
+    the pooled gradient and the index bytes are read inside the stem's backward normalise), the global average pool, SGD = 20 B / parameter (read p, g, m; write p, m)
     and the fused IIF loss (B*C*(4+4) + 8B + 4C + 4).  ReLU decisions are 1 bit per element (s E / 16 bytes, written once,
     read once).  Returns (bytes, formula text)."""
     plan = net._plan(batch, image, image)
@@ -208,6 +216,10 @@ def streaming_pass_bytes(net, batch, image):
         # fused bn1+relu+maxpool: the generic unit terms above charged write-a / read-a-side passes the fusion removes
         total += s * e_pool * 2 + e_pool          # pooled tensor written + index byte; pooled gradient read
         total -= s * e_stem                       # the activation a is never written
+        if plan.dt == torch.bfloat16 and getattr(plan, "pool_fused", False) and not os.environ.get("IIF_NO_POOL_BWD_FUSED"):
+            # round 5: the pool backward is gathered inside the stem's backward normalise (iif_bn_backward_pool_fused): that pass
+            # reads the pooled gradient (charged above) and the index bytes instead of a gradient at the stem's resolution
+            total += e_pool - s * e_stem
     total += 2 * s * float(plan.final.numel())    # global average pool forward read + backward write
     params = float(sum(p.numel() for p in net.parameters()))
     total += 20.0 * params
