@@ -699,7 +699,7 @@ def test_stream1x1_forward_stats_and_dgrad_epilogues(case, conv_env):
         return out, partial, nt
     out_s, part_s, nt_s = run(True)
     out_t, part_t, nt_t = run(False)
-    assert nt_s == (m + 127) // 128
+    assert 0 < nt_s <= (m + 127) // 128               # one partial row per tile SEQUENCE of the persistent grid (round 5; per tile before)
     assert (out_s.float().cpu().view(m, cout) - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
     assert torch.equal(out_s, out_t)                                  # same fp32 accumulation order per element
     sums_s = part_s[:nt_s * 2 * cout].view(nt_s, 2, cout).sum(0)
@@ -747,7 +747,7 @@ def test_stream1x1_forward_stats_and_dgrad_epilogues(case, conv_env):
     dx_s, out2_s, ps, nt = got[True][:4]
     out3_s, ps3, nt3, bits2 = got[True][4:]
     assert torch.equal(out3_s, got[False][4]) and torch.equal(out3_s, dx_s)           # the sums do not touch the stored tensor
-    assert nt3 == (m + 127) // 128 and not torch.isnan(ps3).any()
+    assert 0 < nt3 <= (m + 127) // 128 and not torch.isnan(ps3).any()
     mask2 = ((bits2.view(-1, 1).int() >> torch.arange(8).view(1, 8)) & 1).view(m, cin).float()
     g3 = out3_s.float().cpu().view(m, cin) * mask2
     t1, t2 = g3.sum(0), (g3 * ((upx.float() - stats[0]) * stats[1])).sum(0)
@@ -759,7 +759,7 @@ def test_stream1x1_forward_stats_and_dgrad_epilogues(case, conv_env):
     gq = out2_s.float().cpu().view(m, cin) * (pre.float() > 0)
     xhat = (upx.float() - stats[0]) * stats[1]
     s1, s2 = gq.sum(0), (gq * xhat).sum(0)
-    assert not torch.isnan(ps).any() and nt == (m + 127) // 128
+    assert not torch.isnan(ps).any() and 0 < nt <= (m + 127) // 128
     assert (ps[0] - s1).abs().max().item() <= 2e-6 * max(1.0, s1.abs().max().item()) * 8
     assert (ps[1] - s2).abs().max().item() <= 2e-6 * max(1.0, s2.abs().max().item()) * 8
 
