@@ -493,7 +493,10 @@ inline int stage1_slices(int n_partials, int c, int64_t scratch_floats) {
 
 // partial rows above which the sums are pre-reduced into 64 slices by a separate launch
 inline int two_stage_rows() {
-    return 512;
+    // round 5, same-call A/B of the step (ms): 512 rows 17.56, 1024 17.52, 2048 17.61, 4096 17.58 (784-row sums of the 28 x 28
+    // stage are quicker in one stage of 8 channels x 32 lanes than through slices + ticket)
+    static const int v = [] { const char* e = getenv("IIF_BN_TWO_STAGE_ROWS"); return e ? atoi(e) : 1024; }();
+    return v;
 }
 
 // channels per finalize block: few channels x many lanes when there are many partial rows
