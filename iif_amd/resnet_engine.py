@@ -1019,22 +1019,27 @@ class _Plan(object):
 
     def prepare_weights(self, need_transposed, part="all"):
         """Low-precision / transposed / fragment-packed copies of the fp32 master weights.  part = "stem": only the stem's
-        packed matrix; "rest": everything else (forward() runs that on the idle weight-gradient stream under the stem)."""
+        packed matrix; "rest": everything else (forward() runs that on the idle weight-gradient stream under the stem), or its
+        two halves: "rest_fwd" (what the forward pass reads) and "rest_bwd" (the dense transposed copies and their fragments:
+        data-gradient operands, first read in backward)."""
         net = self.net
-        if part != "rest":
+        if part not in ("rest", "rest_fwd", "rest_bwd"):
             for u in self.units:
                 if u.s2d:
                     ops.stem_s2d_pack(u.conv._w2d, u.conv.cout, u.conv.cin, u.conv.k, S2D_CPAD, u.w)
             if part == "stem":
                 return
+        if part != "rest_fwd":
+            if need_transposed and self.wt_n:
+                ops.weight_transpose_batched(net._arena, self.wt_table, self.wt_n, self.wt_blocks, self.wt_arena)
+            if need_transposed and self.frag_bwd is not None:
+                ops.pack_fragments(self.wt_arena, self.frag_bwd[0], self.frag_bwd[2], self.frag_bwd[1], self.frag_arena)
+            if part == "rest_bwd":
+                return
         if self.lp_arena is not None:
             ops.cast(net._arena, self.lp_arena)
-        if need_transposed and self.wt_n:
-            ops.weight_transpose_batched(net._arena, self.wt_table, self.wt_n, self.wt_blocks, self.wt_arena)
         if self.frag_fwd is not None:
             ops.pack_fragments(self.lp_arena, self.frag_fwd[0], self.frag_fwd[2], self.frag_fwd[1], self.frag_arena)
-        if need_transposed and self.frag_bwd is not None:
-            ops.pack_fragments(self.wt_arena, self.frag_bwd[0], self.frag_bwd[2], self.frag_bwd[1], self.frag_arena)
         # grouped layers: block-diagonal chunk weights, both orientations, ONE launch (the fragment table packs both, so the
         # transposed chunks are filled in evaluation too)
         tab = self._group_pack_table(need_transposed or self.gfrag is not None)
@@ -1121,10 +1126,17 @@ class _Plan(object):
             ev.record()
             with torch.cuda.stream(self.wg_stream):
                 self.wg_stream.wait_event(ev)
-                self.prepare_weights(training, "rest")
+                split = not os.environ.get("IIF_PREP_ONE_PART")
+                self.prepare_weights(training, "rest_fwd" if split else "rest")
                 net._nbt += 1                  # (a 10 us launch nothing in the step reads: not on the compute stream)
                 prep_done = torch.cuda.Event()
                 prep_done.record()
+                if split:
+                    # the transposed copies (~170 us of the ~260) are data-gradient operands: backward waits for them, the
+                    # forward pass does not (round 5: the compute stream idled ~50 us behind the stem convolution for them)
+                    self.prepare_weights(training, "rest_bwd")
+                    self._prep_bwd_done = torch.cuda.Event()
+                    self._prep_bwd_done.record()
         else:
             self.prepare_weights(training)
             if training:
@@ -1538,6 +1550,10 @@ class _Plan(object):
         net = self.net
         head = net._head
         n = self.n
+        pb = getattr(self, "_prep_bwd_done", None)
+        if pb is not None:
+            torch.cuda.current_stream().wait_event(pb)        # transposed weight copies of this step (forward())
+            self._prep_bwd_done = None
         if self.wg_stream is not None:
             # fork the side streams off the compute stream before anything is recorded on them: under hipGraph capture
             # every event of the step then belongs to the capture (the first fence used to be recorded on a stream that
