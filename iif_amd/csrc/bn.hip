@@ -284,8 +284,12 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* parti
     coef[2 * C + c] = (float)(s2 / count) * invstd;
 }
 
+// Waves per SIMD asked of the compiler: 8 (<= 64 VGPRs, no spills) for the one-vector form - the small tensors (the two- and
+// four-vector forms spill under such a bound and keep the compiler's 113-138).  At 98 VGPRs
+// a wave of this kernel did not fit beside the nine-tap weight-gradient blocks of the other stream (two per CU, 448 of a SIMD's
+// 512 registers): the launch waited for that kernel to END, 80-90 us for a 15 us pass at 7 x 7 (profiles/r5_g_step_listing.txt).
 template <typename T, int MASK, bool GMOUT, int U, bool NTS>      // (loop form: see bn_apply_kernel)
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* g_, const T* ymask, const unsigned char* bits, const T* x,
+__global__ void __launch_bounds__(256, (U == 1 ? 8 : 1)) bn_bwd_apply_kernel(const T* g_, const T* ymask, const unsigned char* bits, const T* x,
                                                            const float* stats, const float* coef, T* dx, T* gm,
                                                            int64_t total_vec, int cv, int C) {
     constexpr int V = VT<T>::V;
