@@ -69,7 +69,8 @@ class ConvTimer(object):
     def wrap(self, ops):
         timer = self
         orig = {k: getattr(ops, k) for k in ("conv_forward", "conv_dgrad", "conv_wgrad", "conv_forward_bnstats",
-                                             "conv_dgrad_bnbwd", "conv_dgrad_masksum", "conv_dgrad2_bnbwd", "wgrad1x1_stacked")}
+                                             "conv_dgrad_bnbwd", "conv_dgrad_masksum", "conv_dgrad2_bnbwd", "wgrad1x1_stacked",
+                                             "conv_forward_stats_acc", "conv_forward_bn_relu2", "conv_dgrad_masksum_rx")}
 
         def alg_k(r, s, stride, pad, cin):
             # algorithmic K of one output: the space-to-depth stem (4x4/1 pad 2 on 16 padded channels) is charged
@@ -125,6 +126,14 @@ class ConvTimer(object):
             by = nbytes(dy, wt, kw.get("res"), kw.get("up_x"), out)
             return timer._timed("dgrad", fl, by, orig["conv_dgrad_masksum"], dy, wt, in_hw, out, up_bits, partial, **kw)
 
+        def conv_dgrad_masksum_rx(dy, wt, in_hw, out, up_bits, partial, up_a2, up_w3, up_stats, **kw):
+            # the producer that recomputes the upstream conv3 tile: charged the data gradient's FLOPs (the recomputation is work this
+            # design adds), bytes: its operands plus the narrow a2 and the weights it recomputes from
+            n, ho, wo, cout = dy.shape
+            fl = 2.0 * n * ho * wo * cout * wt.shape[0]
+            by = nbytes(dy, wt, kw.get("res"), out, up_a2, up_w3)
+            return timer._timed("dgrad", fl, by, orig["conv_dgrad_masksum_rx"], dy, wt, in_hw, out, up_bits, partial, up_a2, up_w3, up_stats, **kw)
+
         def conv_dgrad2_bnbwd(src, src2, wt, bias, out, *a, **kw):
             # the data gradient of conv3 with BN3's backward folded into the weights: charged the FLOPs of the plain
             # data gradient (K = src's channels); the second K source is overhead of the design, its bytes are counted
@@ -140,6 +149,18 @@ class ConvTimer(object):
             by = nbytes(x2d, dy2d) + 4.0 * (dy2d.shape[1] + dy2_2d.shape[1]) * x2d.shape[1]
             return timer._timed("wgrad", fl, by, orig["wgrad1x1_stacked"], x2d, dy2d, dy2_2d, out, workspace, **kw)
 
+        def conv_forward_stats_acc(x, w, partial):
+            # pass 1 of the never-stored forward: the convolution repeated for its statistics - work this design adds (0 FLOPs
+            # charged), bytes: the narrow input and the weights
+            return timer._timed("fwd", 0.0, nbytes(x, w), orig["conv_forward_stats_acc"], x, w, partial)
+
+        def conv_forward_bn_relu2(x, w, out, stats, relu_bits, **kw):
+            # pass 2: THE convolution (charged once), BN + residual + ReLU in its epilogue: input, weights, residual, block output
+            fl = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * w.shape[0]
+            return timer._timed("fwd", fl, nbytes(x, w, kw.get("res"), out), orig["conv_forward_bn_relu2"], x, w, out, stats, relu_bits, **kw)
+
+        ops.conv_forward_stats_acc, ops.conv_forward_bn_relu2 = conv_forward_stats_acc, conv_forward_bn_relu2
+        ops.conv_dgrad_masksum_rx = conv_dgrad_masksum_rx
         ops.wgrad1x1_stacked = wgrad1x1_stacked
         ops.conv_forward, ops.conv_dgrad, ops.conv_wgrad = conv_forward, conv_dgrad, conv_wgrad
         ops.conv_dgrad_masksum, ops.conv_dgrad2_bnbwd = conv_dgrad_masksum, conv_dgrad2_bnbwd
@@ -187,6 +208,8 @@ def streaming_pass_bytes(net, batch, image):
     """Algorithmic HBM bytes per step of everything that is NOT a convolution launch, for the dataflow this design
     cannot go below: per conv+BN unit with an output of E elements (s = element size)
         forward  normalise (+ReLU):   read y, write a                     2 s E   (batch statistics ride on the conv epilogue: 0)
+                                                                                  (round 6, never-stored conv3 units: 0 - the normalise sits in the
+                                                                                   convolution's epilogue; their residual read is charged there)
         backward normalise:           read g, read y, write dy            3 s E   (the two BN-backward sums ride on the dgrad epilogue: 0;
                                                                                    units routed through the algebraic BN3 backward: 0 + a column-sum
                                                                                    pass over the unit's input)
@@ -206,8 +229,15 @@ def streaming_pass_bytes(net, batch, image):
             # BN3 backward by algebra: no backward normalise pass; one column-sum pass over the unit's input
             # (its Gram matrix and the second K source of the data gradient are convolution launches, counted there)
             total += -3 * s * e + s * float(u.n * u.ho * u.wo * u.conv.cin)
+    nostore = getattr(plan, "nostore_units", set())
+    for u in nostore:
+        # round 6: conv3's raw output is never stored - no forward normalise pass (BN + residual + ReLU sit in the convolution's
+        # epilogue, whose launch is charged the residual and the block output; its statistics pass is charged its input)
+        total -= 2 * s * float(u.n * u.ho * u.wo * u.conv.cout)
     for b in plan.blocks:
         last = b["units"][-1]
+        if last in nostore:
+            continue
         total += s * float(last.n * last.ho * last.wo * last.conv.cout)        # residual read of the block-end normalise
     if net.style == "imagenet":
         u = plan.stem

@@ -77,7 +77,12 @@ SIGNATURES = {
     "iif_conv_reload_env": [],
     "iif_conv_igemm_stats_only": [_P, _P, _P, _P, _L, _P, _P],
     "iif_conv_igemm_bn_relu": [_P, _P, _P, _P, _P, _P, _P, _P],
+    "iif_conv_fwdbn_ok": [_P],
+    "iif_conv_igemm_stats_acc": [_P, _P, _P, _P, _L, _P, _P],
+    "iif_conv_igemm_bn_relu2": [_P, _P, _P, _P, _P, _P, _P, _P, _P],
     "iif_conv_igemm_dgrad_masksum": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
+    "iif_conv_dgrad_rx_ok": [_P, _I],
+    "iif_conv_igemm_dgrad_masksum_rx": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _L, _P, _P],
     "iif_conv_igemm_dgrad2_bnbwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "iif_bn3_algebra_prep": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _P],
     "iif_bn3_algebra_prep_scratch_floats": [_I, _I],

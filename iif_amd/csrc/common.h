@@ -61,10 +61,20 @@ int iif_stem4x4_launch(const void* src, const void* wgt, void* dst, float* bn_pa
 // sums; with an epilogue descriptor the data-gradient options of staged_drain (residual / its bits / gated store / upstream sums)
 struct iif_regw_epilogue {
     const void* res; const unsigned char* res_bits; const void* bw_x; const unsigned char* bw_bits; const float* bw_stats; int mask_store;
+    // round 6: instead of bw_x, the operands it is recomputed from per tile: the upstream block's a2 [M, rx_k2] and its conv3 weights [N, rx_ldw3]
+    const void* rx_src2; const void* rx_w3; int rx_k2, rx_ldw3;
 };
 bool iif_regw1x1_ok(int M, int K, int N, int epi);
+bool iif_regw1x1_rx_ok(int M, int K, int N, int k2);
 int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
                        int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, int no_store, hipStream_t st);
+// the two passes of the never-stored conv + BN (+ identity / normalised shortcut) + ReLU forward (K in {64, 128, 256}, N a multiple
+// of 256): statistics from the accumulators (no store), and the convolution with bn_apply's arithmetic in its epilogue
+bool iif_regw1x1_fwdbn_ok(int M, int K, int N);
+int iif_regw1x1_fwdbn_launch(const void* src, const void* wgt, void* dst, int M, int K, int N, int spitch, int ldw, int dpitch,
+                             const void* res, const float* aff, const float* aff2, unsigned char* relu_out, hipStream_t st);
+int iif_regw1x1_stats_launch(const void* src, const void* wgt, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
+                             int M, int K, int N, int spitch, int ldw, int dpitch, hipStream_t st);
 // 3x3 / stride 1 / pad 1, C -> C channels (64, 128), forward or data gradient (explicit tap list), optional upstream BN-backward sums
 bool iif_regw3x3_ok(int N, int H, int W, int C);
 int iif_regw3x3_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,

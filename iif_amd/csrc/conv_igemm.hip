@@ -59,8 +59,14 @@ struct ConvArgs {
     //   no_store: the tile is rounded to bf16 and summed into bn_partial exactly as if it were stored, and dropped;
     //   aff (stats base: a at [2 Cd + c], b at [3 Cd + c]): dst = relu(fmaf(a, bf16(conv), b) + res) with the arithmetic of
     //   bn_apply_kernel, relu_out one byte of ReLU decisions per 16-byte vector (as bn_apply writes them).
+    //   no_store == 2 / aff2 (round 6, register-weight kernel only): the sums come from the ACCUMULATORS (unrounded, no staging);
+    //   the residual is normalised by its own BN, fmaf(a2, res, b2), aff2 laid out like aff (convolutional shortcut).
+    //   rx_* (round 6, register-weight kernel only): the upstream x of the backward sums is recomputed per tile from the upstream
+    //   block's a2 (rx_src2, [M, rx_k2]) and conv3 weights (rx_w3, [Cd, rx_ldw3]) instead of being read from bw_x.
+    const unsigned char* rx_src2; const unsigned char* rx_w3; int rx_k2, rx_ldw3;
     int no_store;
     const float* aff;
+    const float* aff2;
     unsigned char* relu_out;
     int bn_row0;           // first partial row of this launch (launches that share one partial buffer)
     int* rows_out;         // host only: receives bn_row0 + tiles of the launch (the partial rows written so far)
@@ -1699,7 +1705,7 @@ __global__ void __launch_bounds__(64 * (4 + STREAM_SW)) gemm1x1_stream_kernel(Co
 //   IIF_CONV_NO_HALO / IIF_CONV_HALO_FORCE   3x3 halo kernel off / also on small grids
 //   IIF_CONV_NO_V2 / IIF_CONV_V2_FORCE       3x3 fragment kernel (64 channels) off / also on small grids
 struct ConvSwitches {
-    bool no_stream, force_stream, regstage, no_v2, no_halo, force_halo, v2_force, no_regw;
+    bool no_stream, force_stream, regstage, no_v2, no_halo, force_halo, v2_force, no_regw, no_regw_fwdbn;
     static ConvSwitches read() {
         ConvSwitches c;
         c.no_stream = getenv("IIF_CONV_NO_STREAM1X1") != nullptr;
@@ -1710,6 +1716,7 @@ struct ConvSwitches {
         c.v2_force = getenv("IIF_CONV_V2_FORCE") != nullptr;
         c.force_halo = getenv("IIF_CONV_HALO_FORCE") != nullptr;
         c.no_regw = getenv("IIF_CONV_NO_REGW") != nullptr;
+        c.no_regw_fwdbn = getenv("IIF_CONV_NO_REGW_FWDBN") != nullptr;      // tests: the BN epilogue on the tile kernels
         return c;
     }
 };
@@ -1940,18 +1947,36 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
             const int rc = iif_stem4x4_launch(a.src, a.wgt, a.dst, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.N, a.Hd, a.Wd, st);
             if (rc != IIF_EUNSUPPORTED) return rc;
         }
+        // the two passes of the never-stored forward (conv_regw.hip: statistics from the accumulators / BN epilogue)
+        const bool geo1x1 = dma_ok && !g_sw.no_regw && a.R == 1 && a.S == 1 && a.sshift == 0 && a.pad == 0 && a.groups == 1 && a.spitch == a.Cs &&
+                            a.dpitch == a.Cd && a.Hs == a.Hd && a.Ws == a.Wd && !a.bias && !a.src2 && !a.sbias && !a.transposed;
+        const bool geo1x1x = dma_ok && !g_sw.no_regw && a.R == 1 && a.S == 1 && a.sshift == 0 && a.pad == 0 && a.groups == 1 && a.spitch == a.Cs &&
+                             a.dpitch == a.Cd && a.Hs == a.Hd && a.Ws == a.Wd && !a.bias && !a.src2 && !a.sbias;
+        if (a.no_store == 2) {
+            if (!geo1x1 || !a.bn_partial || a.res || a.bw_x || a.mask_store || a.aff) return IIF_EUNSUPPORTED;
+            return iif_regw1x1_stats_launch(a.src, a.wgt, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.M, a.Cs, a.Cd, a.spitch, a.ldw, a.dpitch, st);
+        }
+        if (a.aff && geo1x1 && a.relu_out && !a.bn_partial && !a.res_bits && !a.bw_x && !a.mask_store && !g_sw.no_regw_fwdbn &&
+            iif_regw1x1_fwdbn_ok(a.M, a.Cs, a.Cd)) {
+            const int rc = iif_regw1x1_fwdbn_launch(a.src, a.wgt, a.dst, a.M, a.Cs, a.Cd, a.spitch, a.ldw, a.dpitch, a.res, a.aff, a.aff2, a.relu_out, st);
+            if (rc != IIF_EUNSUPPORTED) return rc;
+        }
+        if (a.aff2) return IIF_EUNSUPPORTED;                  // (the tile kernels' BN epilogue takes a plain residual only)
+        if (a.rx_src2 && !(geo1x1x && iif_regw1x1_rx_ok(a.M, a.Cs, a.Cd, a.rx_k2))) return IIF_EUNSUPPORTED;
         // narrow -> wide 1x1 layers: weights in registers (conv_regw.hip)
         const bool epi = a.res || a.res_bits || a.bw_x || a.bw_bits || a.mask_store;
         if (dma_ok && !g_sw.no_regw && a.R == 1 && a.S == 1 && a.sshift == 0 && a.pad == 0 && a.groups == 1 && a.spitch == a.Cs && a.dpitch == a.Cd &&
             a.Hs == a.Hd && a.Ws == a.Wd && !a.bias && !a.src2 && !a.sbias && !a.aff && (!epi || (a.bn_partial && !a.no_store)) &&
             iif_regw1x1_ok(a.M, a.Cs, a.Cd, epi))
         {
-            const iif_regw_epilogue e{a.res, a.res_bits, a.bw_x, a.bw_bits, a.bw_stats, a.mask_store};
+            const iif_regw_epilogue e{a.res, a.res_bits, a.bw_x, a.bw_bits, a.bw_stats, a.mask_store, a.rx_src2, a.rx_w3, a.rx_k2, a.rx_ldw3};
             const int rc = iif_regw1x1_launch(a.src, a.wgt, a.dst, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.M, a.Cs, a.Cd, a.spitch,
                                               a.ldw, a.dpitch, epi ? &e : nullptr, a.no_store, st);
             if (rc != IIF_EUNSUPPORTED) return rc;
         }
+        if (a.rx_src2) return IIF_EUNSUPPORTED;               // (no other kernel recomputes the upstream x)
     }
+    if (a.rx_src2) return IIF_EUNSUPPORTED;
     if (!utap) return (a.src2 || a.sbias || a.mask_store || a.no_store || a.aff) ? IIF_EUNSUPPORTED : launch_one<T, OUTF32>(a, false, src_bytes, wgt_bytes, st);
     if (!a.transposed || a.sshift == 0) {
         for (int r = 0; r < a.R; ++r)
@@ -2041,7 +2066,8 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
 }  // namespace
 
 namespace {
-struct ConvExtra { int mask_store; const void* src2; int cs2; const float* sbias; int no_store; const float* aff; unsigned char* relu_out; };
+struct ConvExtra { int mask_store; const void* src2; int cs2; const float* sbias; int no_store; const float* aff; unsigned char* relu_out; const float* aff2;
+                   const void* rx_src2; const void* rx_w3; int rx_k2, rx_ldw3; };
 int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                const unsigned char* res_bits, const float* bias, float* bn_partial, int64_t bn_partial_floats,
                int32_t* n_partials, void* stream, const void* bw_x = nullptr, const unsigned char* bw_bits = nullptr,
@@ -2090,9 +2116,27 @@ extern "C" int iif_conv_igemm_dgrad_masksum(const iif_conv_desc* d, const void* 
     if (!d || !up_bits || !partial || !n_partials || !d->transposed) return IIF_EINVAL;
     if (res_bits && !res) return IIF_EINVAL;
     if (up_x && !up_stats) return IIF_EINVAL;
-    const ConvExtra ex{1, nullptr, 0, nullptr, 0, nullptr, nullptr};
+    const ConvExtra ex{1, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     return conv_entry(d, src, wgt, dst, res, res_bits, nullptr, partial, partial_floats, n_partials, stream, up_x, up_bits,
                       up_x ? up_stats : nullptr, &ex);
+}
+
+extern "C" int iif_conv_dgrad_rx_ok(const iif_conv_desc* d, int c2) {
+    if (!d || g_sw.no_regw || g_sw.regstage || !d->transposed) return 0;
+    if (d->dtype != IIF_BF16 || d->dst_dtype != IIF_BF16 || d->r != 1 || d->s != 1 || d->stride != 1 || d->pad != 0 || d->groups > 1) return 0;
+    if (d->hs != d->hd || d->ws != d->wd) return 0;
+    return iif_regw1x1_rx_ok(d->n * d->hd * d->wd, d->cs, d->cd, c2) ? 1 : 0;
+}
+
+extern "C" int iif_conv_igemm_dgrad_masksum_rx(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                                               const unsigned char* res_bits, const void* up_a2, int up_c2, const void* up_w3, int up_ldw3,
+                                               const unsigned char* up_bits, const float* up_stats, float* partial, int64_t partial_floats,
+                                               int32_t* n_partials, void* stream) {
+    if (!d || !up_bits || !partial || !n_partials || !d->transposed || !up_a2 || !up_w3 || !up_stats) return IIF_EINVAL;
+    if (res_bits && !res) return IIF_EINVAL;
+    if (!iif_conv_dgrad_rx_ok(d, up_c2) || ((reinterpret_cast<uintptr_t>(up_a2) | reinterpret_cast<uintptr_t>(up_w3)) & 15)) return IIF_EUNSUPPORTED;
+    const ConvExtra ex{1, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, up_a2, up_w3, up_c2, up_ldw3};
+    return conv_entry(d, src, wgt, dst, res, res_bits, nullptr, partial, partial_floats, n_partials, stream, nullptr, up_bits, up_stats, &ex);
 }
 
 extern "C" int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* src, const void* src2, int cs2, const void* wgt,
@@ -2101,7 +2145,7 @@ extern "C" int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* s
                                            void* stream) {
     if (!d || !src2 || !d->transposed) return IIF_EINVAL;
     if (up_x && (!up_stats || !partial || !n_partials)) return IIF_EINVAL;
-    const ConvExtra ex{0, src2, cs2, bias, 0, nullptr, nullptr};
+    const ConvExtra ex{0, src2, cs2, bias, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     return conv_entry(d, src, wgt, dst, nullptr, nullptr, nullptr, up_x ? partial : nullptr, partial_floats, n_partials, stream, up_x,
                       up_bits, up_stats, &ex);
 }
@@ -2109,7 +2153,7 @@ extern "C" int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* s
 extern "C" int iif_conv_igemm_stats_only(const iif_conv_desc* d, const void* src, const void* wgt, float* bn_partial,
                                          int64_t bn_partial_floats, int32_t* n_partials, void* stream) {
     if (!d || !bn_partial || !n_partials || d->transposed) return IIF_EINVAL;
-    const ConvExtra ex{0, nullptr, 0, nullptr, 1, nullptr, nullptr};
+    const ConvExtra ex{0, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     // dst is never written; the source pointer stands in for the non-null / alignment checks
     return conv_entry(d, src, wgt, const_cast<void*>(src), nullptr, nullptr, nullptr, bn_partial, bn_partial_floats, n_partials, stream,
                       nullptr, nullptr, nullptr, &ex);
@@ -2118,7 +2162,31 @@ extern "C" int iif_conv_igemm_stats_only(const iif_conv_desc* d, const void* src
 extern "C" int iif_conv_igemm_bn_relu(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                                       const float* stats, unsigned char* relu_bits, void* stream) {
     if (!d || !stats || d->transposed) return IIF_EINVAL;
-    const ConvExtra ex{0, nullptr, 0, nullptr, 0, stats, relu_bits};
+    const ConvExtra ex{0, nullptr, 0, nullptr, 0, stats, relu_bits, nullptr, nullptr, nullptr, 0, 0};
+    return conv_entry(d, src, wgt, dst, res, nullptr, nullptr, nullptr, 0, nullptr, stream, nullptr, nullptr, nullptr, &ex);
+}
+
+extern "C" int iif_conv_fwdbn_ok(const iif_conv_desc* d) {
+    if (!d || g_sw.no_regw || g_sw.regstage || g_sw.no_regw_fwdbn) return 0;
+    if (d->dtype != IIF_BF16 || d->dst_dtype != IIF_BF16 || d->r != 1 || d->s != 1 || d->stride != 1 || d->pad != 0 || d->groups > 1 || d->transposed) return 0;
+    if (d->hs != d->hd || d->ws != d->wd) return 0;
+    return iif_regw1x1_fwdbn_ok(d->n * d->hd * d->wd, d->cs, d->cd) ? 1 : 0;
+}
+
+extern "C" int iif_conv_igemm_stats_acc(const iif_conv_desc* d, const void* src, const void* wgt, float* bn_partial,
+                                        int64_t bn_partial_floats, int32_t* n_partials, void* stream) {
+    if (!d || !bn_partial || !n_partials || d->transposed) return IIF_EINVAL;
+    if (!iif_conv_fwdbn_ok(d)) return IIF_EUNSUPPORTED;
+    const ConvExtra ex{0, nullptr, 0, nullptr, 2, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    return conv_entry(d, src, wgt, const_cast<void*>(src), nullptr, nullptr, nullptr, bn_partial, bn_partial_floats, n_partials, stream,
+                      nullptr, nullptr, nullptr, &ex);
+}
+
+extern "C" int iif_conv_igemm_bn_relu2(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                                       const float* res_stats, const float* stats, unsigned char* relu_bits, void* stream) {
+    if (!d || !stats || !relu_bits || d->transposed || (res_stats && !res)) return IIF_EINVAL;
+    if (res_stats && !iif_conv_fwdbn_ok(d)) return IIF_EUNSUPPORTED;
+    const ConvExtra ex{0, nullptr, 0, nullptr, 0, stats, relu_bits, res_stats, nullptr, nullptr, 0, 0};
     return conv_entry(d, src, wgt, dst, res, nullptr, nullptr, nullptr, 0, nullptr, stream, nullptr, nullptr, nullptr, &ex);
 }
 
@@ -2194,7 +2262,8 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
     }
     if (ex) {
         a.mask_store = ex->mask_store; a.src2 = (const unsigned char*)ex->src2; a.Cs2 = ex->cs2; a.sbias = ex->sbias;
-        a.no_store = ex->no_store; a.aff = ex->aff; a.relu_out = ex->relu_out;
+        a.no_store = ex->no_store; a.aff = ex->aff; a.relu_out = ex->relu_out; a.aff2 = ex->aff2;
+        a.rx_src2 = (const unsigned char*)ex->rx_src2; a.rx_w3 = (const unsigned char*)ex->rx_w3; a.rx_k2 = ex->rx_k2; a.rx_ldw3 = ex->rx_ldw3;
     }
     a.N = d->n; a.Hs = d->hs; a.Ws = d->ws; a.Cs = d->cs; a.Hd = d->hd; a.Wd = d->wd; a.Cd = d->cd;
     a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.transposed = d->transposed ? 1 : 0;

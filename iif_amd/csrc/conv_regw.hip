@@ -23,6 +23,14 @@ struct RegwArgs {
     const unsigned char* res; const unsigned char* res_bits; const unsigned char* bw_x; const unsigned char* bw_bits;
     const float* bw_stats; int mask_store;
     int no_store;          // forward only: the tile is rounded and summed exactly as if it were stored, and dropped (two-pass forward)
+    // EPI 2 (forward BN epilogue, round 6): dst = relu(fma(a, bf16(conv), b) + r) with (a, b) at aff[2 Cd + c] / aff[3 Cd + c], r the
+    // residual `res` as it is (aff2 null) or normalised by ITS batch norm, fma(a2, res, b2) with aff2 laid out like aff (the
+    // convolutional shortcut of a downsample block); relu_out: one byte of ReLU decisions per 16-byte vector.  bn_apply_kernel's arithmetic.
+    const float* aff; const float* aff2; unsigned char* relu_out;
+    // EPI 4 (round 6): the data-gradient epilogue of EPI 1 whose upstream x (bw_x: the raw output of the upstream block's conv3)
+    // is RECOMPUTED per tile instead of read: x = src2 (that block's a2, [M, KK2]) times w3^T (its conv3 weights as the forward
+    // multiplied them, [Cd, ldw3] bf16), rounded to bf16 as the stored tensor would have been.  The upstream output need not exist.
+    const unsigned char* src2; const unsigned char* w3; int spitch2, ldw3; unsigned src2_bytes;
 };
 
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 2; }      // as conv_igemm.hip's swz: 64-byte LDS rows
@@ -31,16 +39,23 @@ __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 2; }      //
 // BN-backward sums with or without the upstream x).  Everything a tile's epilogue reads from memory is requested ONE TILE AHEAD
 // into registers (the MFMA phase of a tile is a fraction of a microsecond: nothing to hide a load behind), unconditionally (an
 // operand the launch does not have is read from one dummy line), 10 registers per staged 16-byte vector.
-template <int KK, int CW, int MT, bool EPI>
+// EPI 0: plain forward (+ sums of the stored tile); 1: the data-gradient epilogue; 2: the forward BN epilogue (pass 2 of the
+// two-pass forward); 3: statistics only, taken from the ACCUMULATORS (pass 1: no staging, no store; sums of the unrounded tile);
+// 4: EPI 1 with the upstream x recomputed from (src2, w3) over KK2 channels
+template <int KK, int CW, int MT, int EPI, int KK2 = 0>
 __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsigned src_bytes) {
+    constexpr bool RX = EPI == 4, DG = EPI == 1 || EPI == 4;
+    constexpr int NK2 = RX ? KK2 / 32 : 1, TILE2 = RX ? NK2 * MT * 64 : 0, NAP2 = RX ? NK2 * (MT / 16) / 8 : 0;
+    static_assert(!RX || (KK2 >= 64 && (NK2 * (MT / 16)) % 8 == 0), "second source");
     constexpr int NK = KK / 32, CB = CW / 16, RB = MT / 16;
     constexpr int SLAB = MT * 64, TILE = NK * SLAB;       // NK slabs of [MT rows x 64 B]
     constexpr int NAP = NK * RB / 8;                       // 1-KB DMA pieces (16 rows of a slab) per wave and tile
     constexpr int PITCH = CW * 2 + 16, STG = MT * PITCH;
     constexpr int LPR = CW / 8, RPI = 64 / LPR, NST = MT / RPI;      // lanes per staged row, rows per store instruction, stores per tile
     constexpr unsigned OOB = 0x80000000u;
-    static_assert((NK * RB) % 8 == 0 && MT % RPI == 0 && 2 * TILE + 8 * STG <= 160 * 1024, "shape");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * TILE + 8 * STG];
+    constexpr int STGB = EPI == 3 ? 0 : 8 * STG;
+    static_assert((NK * RB) % 8 == 0 && MT % RPI == 0 && 2 * TILE + STGB + 2 * TILE2 <= 160 * 1024, "shape");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * TILE + STGB + 2 * TILE2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fc = lane >> 4;
@@ -62,35 +77,85 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(smem + buf * TILE + ks * SLAB + p * 1024), 16, off, 0, 0, 0);
         }
     };
+    const auto rs_src2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(RX ? a.src2 : a.src), 0, RX ? a.src2_bytes : src_bytes, 0x00020000);
+    unsigned char* const smem2 = smem + 2 * TILE + STGB;       // EPI 4: the two [MT x KK2] tiles of the second source
+    auto issue_tile2 = [&](int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < NAP2; ++i) {
+            const int q = wave + 8 * i, ks = q / RB, p = q % RB;
+            const int row = p * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ swz64(row);
+            const int m = t * MT + row;
+            const unsigned off = m < a.M ? ((unsigned)m * (unsigned)a.spitch2 + (unsigned)(ks * 32 + chunk * 8)) * 2u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src2, (lds_void*)(smem2 + buf * TILE2 + ks * SLAB + p * 1024), 16, off, 0, 0, 0);
+        }
+    };
     // epilogue operands of one tile: vector k of this lane = row k * RPI + lane / LPR, channels n0 + (lane % LPR) * 8 ..
     const unsigned char* const dummy = a.wgt;
-    const bool has_res = EPI && a.res != nullptr, has_rb = EPI && a.res_bits != nullptr, has_bx = EPI && a.bw_x != nullptr;
-    const bool has_bb = EPI && a.bw_bits != nullptr;
-    constexpr int NOP = EPI ? NST : 1;
-    auto load_ops = [&](int t, u32x4 (&r)[NOP], u32x4 (&x)[NOP], unsigned (&rbv)[NOP], unsigned (&mbv)[NOP]) {
-        if constexpr (EPI) {
+    const bool has_res = (DG || EPI == 2) && a.res != nullptr, has_rb = DG && a.res_bits != nullptr;
+    const bool has_bx = EPI == 1 && a.bw_x != nullptr, has_bb = DG && a.bw_bits != nullptr;
+    const bool has_aff2 = EPI == 2 && a.aff2 != nullptr;
+    constexpr int NOP = (DG || EPI == 2) ? NST : 1;
+    constexpr int NOX = EPI == 1 ? NST : 1;
+    constexpr int NOB = DG ? NST : 1;
+    const unsigned char* const p_res = has_res ? a.res : dummy; const size_t m_res = has_res ? ~(size_t)0 : 0;
+    const unsigned char* const p_bx = has_bx ? a.bw_x : dummy; const size_t m_bx = has_bx ? ~(size_t)0 : 0;
+    const unsigned char* const p_rb = has_rb ? a.res_bits : dummy; const size_t m_rb = has_rb ? ~(size_t)0 : 0;
+    const unsigned char* const p_bb = has_bb ? a.bw_bits : dummy; const size_t m_bb = has_bb ? ~(size_t)0 : 0;
+    auto load_ops = [&](int t, u32x4 (&r)[NOP], u32x4 (&x)[NOX], unsigned (&rbv)[NOB], unsigned (&mbv)[NOB]) {
+        if constexpr (EPI == 2) {                      // the residual rows only (last forward use of the block input: streamed)
             const size_t base = ((size_t)t * MT * a.dpitch + n0) * 2;
 #pragma unroll
             for (int k = 0; k < NST; ++k) {
                 const size_t o = base + ((size_t)(k * RPI + lane / LPR) * a.dpitch + (lane % LPR) * 8) * 2;
-                r[k] = *reinterpret_cast<const u32x4*>(has_res ? a.res + o : dummy);
-                x[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(has_bx ? a.bw_x + o : dummy));
-                rbv[k] = *(has_rb ? a.res_bits + (o >> 4) : dummy);
-                mbv[k] = *(has_bb ? a.bw_bits + (o >> 4) : dummy);
+                r[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(has_res ? a.res + o : dummy));
+            }
+        }
+        if constexpr (DG) {
+            // base pointer and offset mask per operand instead of a select per load: the loads stay straight-line code (a branchy
+            // form - some paths with fewer loads - makes the compiler's own wait in front of the first use of these registers a
+            // vmcnt(0), i.e. a wait for the tile's STORES: seen in the EPI 4 instances, 373 instead of ~200 us at 56 x 56)
+            const size_t base = ((size_t)t * MT * a.dpitch + n0) * 2;
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const size_t o = base + ((size_t)(k * RPI + lane / LPR) * a.dpitch + (lane % LPR) * 8) * 2;
+                r[k] = *reinterpret_cast<const u32x4*>(p_res + (o & m_res));
+                if constexpr (EPI == 1) x[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p_bx + (o & m_bx)));
+                rbv[k] = *(p_rb + ((o >> 4) & m_rb));
+                mbv[k] = *(p_bb + ((o >> 4) & m_bb));
             }
         }
     };
-    u32x4 c_res[NOP], c_x[NOP], n_res[NOP], n_x[NOP];
-    unsigned c_rb[NOP], c_mb[NOP], n_rb[NOP], n_mb[NOP];
+    u32x4 c_res[NOP], c_x[NOX], n_res[NOP], n_x[NOX];
+    unsigned c_rb[NOB], c_mb[NOB], n_rb[NOB], n_mb[NOB];
     float bmean[8], bistd[8];
+    float ra[8], rb2[8];                               // EPI 2: bmean / bistd hold (a, b) of the unit, ra / rb2 those of the residual's BN
 #pragma unroll
     for (int q = 0; q < 8; ++q) { bmean[q] = 0.f; bistd[q] = 0.f; }
-    if (has_bx) {
+    if (has_bx || RX) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) { bmean[q] = a.bw_stats[n0 + (lane % LPR) * 8 + q]; bistd[q] = a.bw_stats[a.dpitch + n0 + (lane % LPR) * 8 + q]; }
     }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { ra[q] = 1.f; rb2[q] = 0.f; }
+    if constexpr (EPI == 2) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ch = n0 + (lane % LPR) * 8 + q;
+            bmean[q] = a.aff[2 * a.Cd + ch]; bistd[q] = a.aff[3 * a.Cd + ch];
+            if (has_aff2) { ra[q] = a.aff2[2 * a.Cd + ch]; rb2[q] = a.aff2[3 * a.Cd + ch]; }
+        }
+    }
     int tile = seq;
-    if (tile < a.mtiles) { issue_tile(tile, 0); load_ops(tile, c_res, c_x, c_rb, c_mb); }
+    if (tile < a.mtiles) { issue_tile(tile, 0); issue_tile2(tile, 0); load_ops(tile, c_res, c_x, c_rb, c_mb); }
+    u32x4 w3reg[NK2][CB];                              // EPI 4: this wave's columns of the upstream conv3, all KK2 input channels
+    if constexpr (RX) {
+#pragma unroll
+        for (int ks = 0; ks < NK2; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+                w3reg[ks][cb] = *reinterpret_cast<const u32x4*>(a.w3 + ((size_t)(n0 + cb * 16 + fr) * a.ldw3 + ks * 32 + fc * 8) * 2);
+    }
     u32x4 wreg[NK][CB];
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks)
@@ -104,9 +169,21 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
     for (int ks = 0; ks < NK; ++ks)
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) asm volatile("" : "+v"(wreg[ks][cb]));
-    if constexpr (EPI) {
+    if constexpr (EPI == 1) {
 #pragma unroll
         for (int k = 0; k < NST; ++k) asm volatile("" : "+v"(c_res[k]), "+v"(c_x[k]), "+v"(c_rb[k]), "+v"(c_mb[k]));
+    }
+    if constexpr (RX) {
+#pragma unroll
+        for (int ks = 0; ks < NK2; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) asm volatile("" : "+v"(w3reg[ks][cb]));
+#pragma unroll
+        for (int k = 0; k < NST; ++k) asm volatile("" : "+v"(c_res[k]), "+v"(c_rb[k]), "+v"(c_mb[k]));
+    }
+    if constexpr (EPI == 2) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) asm volatile("" : "+v"(c_res[k]));
     }
     int xo[RB];
 #pragma unroll
@@ -114,16 +191,19 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
     float bs[8], bq[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { bs[q] = 0.f; bq[q] = 0.f; }
+    // EPI 3: this lane's running sums of channels n0 + cb * 16 + fc * 4 + {0..3} over its rows (fr + 16 rb of every tile)
+    f32x4 as[EPI == 3 ? CB : 1], aq[EPI == 3 ? CB : 1];
+#pragma unroll
+    for (int cb = 0; cb < (EPI == 3 ? CB : 1); ++cb) { as[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; aq[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     unsigned char* const stg = smem + 2 * TILE + wave * STG;
     int buf = 0;
-    bool first = true;
+    // The first tile (and everything the prologue asked for) has landed; inside the loop the wait for the NEXT tile sits at the
+    // bottom of the body, behind the stores it counts over (round 6: at the top behind a `first` flag before - two paths into the
+    // loop body made the compiler's own waits conservative, vmcnt(0), in some instances).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (; tile < a.mtiles; tile += G, buf ^= 1) {
-        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (!EPI && a.no_store) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no stores behind the DMA to count over)
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");     // the previous tile's stores may stay in flight
-        first = false;
         __builtin_amdgcn_s_barrier();
-        if (tile + G < a.mtiles) { issue_tile(tile + G, buf ^ 1); load_ops(tile + G, n_res, n_x, n_rb, n_mb); }
+        if (tile + G < a.mtiles) { issue_tile(tile + G, buf ^ 1); issue_tile2(tile + G, buf ^ 1); load_ops(tile + G, n_res, n_x, n_rb, n_mb); }
         const unsigned char* Ab = smem + buf * TILE;
         f32x4 acc[CB][RB];
 #pragma unroll
@@ -143,6 +223,16 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
                                                                          __builtin_bit_cast(bf16x8, xf[rb]), acc[cb][rb], 0, 0, 0);
         }
         // lane holds channels cb * 16 + fc * 4 + {0..3} of row rb * 16 + fr
+        if constexpr (EPI == 3) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { as[cb][j] += acc[cb][rb][j]; aq[cb][j] = fmaf(acc[cb][rb][j], acc[cb][rb][j], aq[cb][j]); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next tile (nothing else is in flight)
+            continue;
+        }
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -153,11 +243,32 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
                 *reinterpret_cast<u32x2*>(stg + (rb * 16 + fr) * PITCH + (cb * 16 + fc * 4) * 2) = w;
             }
         unsigned char* const dcol = a.dst + ((size_t)tile * MT * a.dpitch + n0) * 2;
+        u32x4 gv[RX ? NST : 1];
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int row = k * RPI + lane / LPR, chunk = lane % LPR;
             u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * PITCH + chunk * 16);
-            if constexpr (EPI) {                        // (the arithmetic of staged_drain, element for element)
+            if constexpr (EPI == 2) {                   // (the arithmetic of bn_apply_kernel, element for element)
+                const u32x4 rr = c_res[k];
+                unsigned bits = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float lo = fmaf(bmean[2 * q], bf16_bits_to_f32(v[q] & 0xffffu), bistd[2 * q]);
+                    float hi = fmaf(bmean[2 * q + 1], __uint_as_float(v[q] & 0xffff0000u), bistd[2 * q + 1]);
+                    if (has_aff2) {
+                        lo += fmaf(ra[2 * q], bf16_bits_to_f32(rr[q] & 0xffffu), rb2[2 * q]);
+                        hi += fmaf(ra[2 * q + 1], __uint_as_float(rr[q] & 0xffff0000u), rb2[2 * q + 1]);
+                    } else if (has_res) {
+                        lo += bf16_bits_to_f32(rr[q] & 0xffffu); hi += __uint_as_float(rr[q] & 0xffff0000u);
+                    }
+                    bits |= (lo > 0.f ? 1u : 0u) << (2 * q);
+                    bits |= (hi > 0.f ? 1u : 0u) << (2 * q + 1);
+                    v[q] = pack_bf16x2(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
+                }
+                const size_t ob = ((size_t)row * a.dpitch + chunk * 8) * 2;
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dcol + ob));
+                a.relu_out[(((size_t)tile * MT * a.dpitch + n0) * 2 + ob) >> 4] = (unsigned char)bits;
+            } else if constexpr (DG) {                  // (the arithmetic of staged_drain, element for element)
                 if (has_res) {
                     const u32x4 rr = c_res[k];
                     const unsigned rb = has_rb ? c_rb[k] : 0xffu;
@@ -175,11 +286,13 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
                         const unsigned lo = (mb >> (2 * q)) & 1u ? (v[q] & 0xffffu) : 0u;
                         const unsigned hi = (mb >> (2 * q + 1)) & 1u ? (v[q] & 0xffff0000u) : 0u;
                         v[q] = lo | hi;
-                        if (!has_bx) { bs[2 * q] += bf16_bits_to_f32(lo); bs[2 * q + 1] += __uint_as_float(hi); }
+                        if (!has_bx && !RX) { bs[2 * q] += bf16_bits_to_f32(lo); bs[2 * q + 1] += __uint_as_float(hi); }
                     }
                 }
                 __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dcol + ((size_t)row * a.dpitch + chunk * 8) * 2));
-                if (has_bx) {
+                if constexpr (RX) {
+                    gv[k] = v;                          // meets the recomputed x below
+                } else if (has_bx) {
                     const u32x4 xv = c_x[k];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -208,12 +321,89 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
                 }
             }
         }
-        if constexpr (EPI) {
+        if constexpr (RX) {
+            // the upstream block's conv3 on this tile: x[row][n0 + ..] = a2[row][:] . w3[n0 + ..][:], through the same wave-private
+            // staging transpose (LDS operations of a wave execute in order: the reads above are done), then sum g~ and sum g~ xhat
+            const unsigned char* A2 = smem2 + buf * TILE2;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NK2; ++ks) {
+                u32x4 xf[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) xf[rb] = *reinterpret_cast<const u32x4*>(A2 + ks * SLAB + xo[rb]);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+                        acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w3reg[ks][cb]),
+                                                                             __builtin_bit_cast(bf16x8, xf[rb]), acc[cb][rb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    u32x2 w;
+                    w.x = pack_bf16x2(acc[cb][rb].x, acc[cb][rb].y);
+                    w.y = pack_bf16x2(acc[cb][rb].z, acc[cb][rb].w);
+                    *reinterpret_cast<u32x2*>(stg + (rb * 16 + fr) * PITCH + (cb * 16 + fc * 4) * 2) = w;
+                }
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int row = k * RPI + lane / LPR, chunk = lane % LPR;
+                const u32x4 xv = *reinterpret_cast<const u32x4*>(stg + row * PITCH + chunk * 16);
+                const u32x4 v = gv[k];
+                const unsigned mb = has_bb ? c_mb[k] : 0xffu;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float glo = (mb >> (2 * q)) & 1u ? bf16_bits_to_f32(v[q] & 0xffffu) : 0.f;
+                    const float ghi = (mb >> (2 * q + 1)) & 1u ? __uint_as_float(v[q] & 0xffff0000u) : 0.f;
+                    const float xlo = (bf16_bits_to_f32(xv[q] & 0xffffu) - bmean[2 * q]) * bistd[2 * q];
+                    const float xhi = (__uint_as_float(xv[q] & 0xffff0000u) - bmean[2 * q + 1]) * bistd[2 * q + 1];
+                    bs[2 * q] += glo; bq[2 * q] += glo * xlo;
+                    bs[2 * q + 1] += ghi; bq[2 * q + 1] += ghi * xhi;
+                }
+            }
+        }
+        if constexpr (EPI == 1) {
 #pragma unroll
             for (int k = 0; k < NST; ++k) { c_res[k] = n_res[k]; c_x[k] = n_x[k]; c_rb[k] = n_rb[k]; c_mb[k] = n_mb[k]; }
         }
+        if constexpr (RX) {
+#pragma unroll
+            for (int k = 0; k < NST; ++k) { c_res[k] = n_res[k]; c_rb[k] = n_rb[k]; c_mb[k] = n_mb[k]; }
+        }
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int k = 0; k < NST; ++k) c_res[k] = n_res[k];
+        }
+        // the next tile's DMA pieces (and epilogue operands) of THIS wave have landed; this tile's stores may stay in flight
+        if (EPI == 0 && a.no_store) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no stores behind the DMA to count over)
+        else if (EPI == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST) : "memory");     // NST vectors + NST bit bytes
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     }
     if (a.bn_partial == nullptr || seq >= G) return;
+    if constexpr (EPI == 3) {
+        // rows of a channel sit on the 16 lanes that share fc: butterfly over fr, lane fr == 0 writes its four channels
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { as[cb][j] += __shfl_xor(as[cb][j], o, 64); aq[cb][j] += __shfl_xor(aq[cb][j], o, 64); }
+            }
+        if (fr == 0) {
+            float* p = a.bn_partial + (int64_t)(a.bn_row0 + seq) * 2 * a.dpitch + n0 + fc * 4;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                *reinterpret_cast<f32x4*>(p + cb * 16) = as[cb];
+                *reinterpret_cast<f32x4*>(p + a.dpitch + cb * 16) = aq[cb];
+            }
+        }
+        return;
+    }
     // lanes that share the channel chunk (lane % LPR); every wave owns its own columns of the sequence's partial row
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -248,6 +438,13 @@ static bool regw_plan(int K, int N, bool epi, int* cw, int* mt) {
     return false;
 }
 
+// the data-gradient epilogue with the upstream x recomputed over k2 channels: the (K, k2) pairs that have an instance
+bool iif_regw1x1_rx_ok(int M, int K, int N, int k2) {
+    const bool pair = (K == 64 && k2 == 64) || (K == 128 && (k2 == 64 || k2 == 128)) || (K == 256 && k2 == 128);
+    // (M >= 1024: at least eight partial rows' worth of 128-row groups, as for the statistics pass - there is no other kernel to fall back to)
+    return pair && M >= 1024 && iif_regw1x1_ok(M, K, N, 1);
+}
+
 bool iif_regw1x1_ok(int M, int K, int N, int epi) {
     int cw, mt;
     if (M <= 0 || (int64_t)M * K * 2 >= 0x7f000000LL || !regw_plan(K, N, epi != 0, &cw, &mt)) return false;
@@ -265,9 +462,17 @@ int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_pa
     const int S = N / (8 * cw);
     RegwArgs a{(const unsigned char*)src, (const unsigned char*)wgt, (unsigned char*)dst, bn_partial, M, M / mt, spitch, ldw, N, dpitch,
                bn_row0, S, nullptr, nullptr, nullptr, nullptr, nullptr, 0, no_store};
+    int k2 = 0;
     if (epi) {
         a.res = (const unsigned char*)e->res; a.res_bits = e->res_bits; a.bw_x = (const unsigned char*)e->bw_x; a.bw_bits = e->bw_bits;
         a.bw_stats = e->bw_stats; a.mask_store = e->mask_store;
+        if (e->rx_src2) {                                  // the upstream x recomputed from (a2, w3)
+            k2 = e->rx_k2;
+            if (!iif_regw1x1_rx_ok(M, K, N, k2) || !e->rx_w3 || !e->bw_stats || e->bw_x || e->rx_ldw3 < k2 || bn_partial == nullptr) return IIF_EUNSUPPORTED;
+            if ((int64_t)M * k2 * 2 >= 0x7f000000LL) return IIF_EUNSUPPORTED;
+            a.src2 = (const unsigned char*)e->rx_src2; a.w3 = (const unsigned char*)e->rx_w3; a.spitch2 = k2; a.ldw3 = e->rx_ldw3;
+            a.src2_bytes = (unsigned)((int64_t)M * k2 * 2);
+        }
     }
     const int unit = 8 * S;
     int grid = cus / unit * unit;
@@ -285,20 +490,84 @@ int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_pa
     const unsigned sb = (unsigned)((int64_t)M * spitch * 2);
     const dim3 g((unsigned)grid), b(512);
 #define IIF_REGW(KK, CW, MT, EP) hipLaunchKernelGGL((gemm1x1_regw_kernel<KK, CW, MT, EP>), g, b, 0, st, a, sb)
-    if (epi) {
-        if (K == 64) IIF_REGW(64, 32, 64, true);
-        else if (K == 128) IIF_REGW(128, 32, 64, true);
-        else IIF_REGW(256, 32, 64, true);
+#define IIF_REGWX(KK, K2) hipLaunchKernelGGL((gemm1x1_regw_kernel<KK, 32, 64, 4, K2>), g, b, 0, st, a, sb)
+    if (k2) {
+        if (K == 64 && k2 == 64) IIF_REGWX(64, 64);
+        else if (K == 128 && k2 == 64) IIF_REGWX(128, 64);
+        else if (K == 128 && k2 == 128) IIF_REGWX(128, 128);
+        else if (K == 256 && k2 == 128) IIF_REGWX(256, 128);
+        else return IIF_EUNSUPPORTED;
+    } else if (epi) {
+        if (K == 64) IIF_REGW(64, 32, 64, 1);
+        else if (K == 128) IIF_REGW(128, 32, 64, 1);
+        else IIF_REGW(256, 32, 64, 1);
     } else {
-        if (K == 128 && cw == 64) IIF_REGW(128, 64, 64, false);
-        else if (K == 128) IIF_REGW(128, 32, 64, false);
-        else if (K == 256) IIF_REGW(256, 32, 64, false);
-        else if (K == 512) IIF_REGW(512, 16, 64, false);
-        else IIF_REGW(1024, 16, 32, false);
+        if (K == 128 && cw == 64) IIF_REGW(128, 64, 64, 0);
+        else if (K == 128) IIF_REGW(128, 32, 64, 0);
+        else if (K == 256) IIF_REGW(256, 32, 64, 0);
+        else if (K == 512) IIF_REGW(512, 16, 64, 0);
+        else IIF_REGW(1024, 16, 32, 0);
     }
-#undef IIF_REGW
     IIF_LAUNCH_CHECK();
     return IIF_OK;
+}
+
+// ---- the two passes of the never-stored conv + BN (+ shortcut) + ReLU forward (round 6): 32 columns per wave, N / 256 slices
+static bool regw_plan2(int K, int N) { return (K == 64 || K == 128 || K == 256) && N >= 256 && N <= 2048 && (N % 256) == 0; }
+
+bool iif_regw1x1_fwdbn_ok(int M, int K, int N) {
+    // (at least eight 128-row groups: one partial row per tile sequence, never more rows than ceil(M / 128), sequences in eights)
+    return M >= 1024 && (M % 64) == 0 && (int64_t)M * K * 2 < 0x7f000000LL && regw_plan2(K, N);
+}
+
+// mode 2: forward BN epilogue; mode 3: statistics from the accumulators (dst / res / aff unused)
+static int regw_launch2(int mode, const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
+                        int M, int K, int N, int spitch, int ldw, int dpitch, const void* res, const float* aff, const float* aff2,
+                        unsigned char* relu_out, hipStream_t st) {
+    if (!src || !wgt || !iif_regw1x1_fwdbn_ok(M, K, N) || spitch != K || dpitch != N) return IIF_EUNSUPPORTED;
+    if (mode == 2 && (!dst || !aff || !relu_out || (aff2 && !res))) return IIF_EINVAL;
+    if (mode == 3 && !bn_partial) return IIF_EINVAL;
+    const int cus = iif_persistent_cus();
+    const int S = N / 256;
+    RegwArgs a{(const unsigned char*)src, (const unsigned char*)wgt, (unsigned char*)dst, bn_partial, M, M / 64, spitch, ldw, N, dpitch,
+               bn_row0, S, (const unsigned char*)res, nullptr, nullptr, nullptr, nullptr, 0, 0, aff, aff2, relu_out};
+    const int unit = 8 * S;
+    int grid = cus / unit * unit;
+    const int need = (a.mtiles + 7) / 8 * unit;
+    if (need < grid) grid = need;
+    const int rows128 = (M + 127) / 128;
+    if (bn_partial && grid / S > rows128) grid = rows128 / 8 * unit;
+    if (grid < unit) return IIF_EUNSUPPORTED;
+    const int G = grid / S;
+    if (bn_partial) {
+        if ((long long)(bn_row0 + G) * 2 * dpitch > bn_cap) return IIF_EINVAL;
+        if (rows_out) *rows_out = bn_row0 + G;
+    }
+    const unsigned sb = (unsigned)((int64_t)M * spitch * 2);
+    const dim3 g((unsigned)grid), b(512);
+    if (mode == 2) {
+        if (K == 64) IIF_REGW(64, 32, 64, 2);
+        else if (K == 128) IIF_REGW(128, 32, 64, 2);
+        else IIF_REGW(256, 32, 64, 2);
+    } else {
+        if (K == 64) IIF_REGW(64, 32, 64, 3);
+        else if (K == 128) IIF_REGW(128, 32, 64, 3);
+        else IIF_REGW(256, 32, 64, 3);
+    }
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+#undef IIF_REGW
+
+int iif_regw1x1_fwdbn_launch(const void* src, const void* wgt, void* dst, int M, int K, int N, int spitch, int ldw, int dpitch,
+                             const void* res, const float* aff, const float* aff2, unsigned char* relu_out, hipStream_t st) {
+    return regw_launch2(2, src, wgt, dst, nullptr, 0, 0, nullptr, M, K, N, spitch, ldw, dpitch, res, aff, aff2, relu_out, st);
+}
+
+int iif_regw1x1_stats_launch(const void* src, const void* wgt, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
+                             int M, int K, int N, int spitch, int ldw, int dpitch, hipStream_t st) {
+    return regw_launch2(3, src, wgt, nullptr, bn_partial, bn_cap, bn_row0, rows_out, M, K, N, spitch, ldw, dpitch, nullptr, nullptr, nullptr,
+                        nullptr, st);
 }
 
 // =====================================================================================================================

@@ -486,6 +486,38 @@ def conv_forward_bn_relu(x, w, out, stats, res=None, relu_bits=None):
     return out
 
 
+def conv_fwdbn_ok(n, h, w, cin, cout, dtype):
+    """Whether the never-stored forward (statistics from the accumulators + BN epilogue, register-weight kernel) takes a
+    1x1 / stride-1 layer of this shape."""
+    if dtype != torch.bfloat16:
+        return False
+    d = _desc(n, h, w, cin, h, w, cout, 1, 1, 1, 0, 0, cin, _lib.IIF_BF16, _lib.IIF_BF16, 1)
+    return bool(lib().iif_conv_fwdbn_ok(ctypes.byref(d)))
+
+
+def conv_forward_stats_acc(x, w, partial):
+    """Pass 1 on the register-weight kernel: partial rows of (sum, sum of squares) of the unrounded accumulators; no output."""
+    require_gpu(x, w, partial)
+    n, h, w_, cin = x.shape
+    cout, ldw = w.shape
+    d = _desc(n, h, w_, cin, h, w_, cout, 1, 1, 1, 0, 0, ldw, dtype_code(x), dtype_code(x), 1)
+    nt = ctypes.c_int32(0)
+    check(lib().iif_conv_igemm_stats_acc(ctypes.byref(d), ptr(x), ptr(w), ptr(partial), partial.numel(), ctypes.byref(nt),
+                                         stream_ptr()), "iif_conv_igemm_stats_acc")
+    return nt.value
+
+
+def conv_forward_bn_relu2(x, w, out, stats, relu_bits, res=None, res_stats=None):
+    """Pass 2: out = relu(stats[2] * bf16(conv) + stats[3] + r), r = res or res_stats[2] * res + res_stats[3]."""
+    require_gpu(x, w, out, res, stats, relu_bits)
+    n, h, w_, cin = x.shape
+    cout, ldw = w.shape
+    d = _desc(n, h, w_, cin, h, w_, cout, 1, 1, 1, 0, 0, ldw, dtype_code(x), dtype_code(out), 1)
+    check(lib().iif_conv_igemm_bn_relu2(ctypes.byref(d), ptr(x), ptr(w), ptr(out), ptr(res), ptr(res_stats), ptr(stats),
+                                        ptr(relu_bits), stream_ptr()), "iif_conv_igemm_bn_relu2")
+    return out
+
+
 def conv_dgrad_masksum(dy, wt, in_hw, out, up_bits, partial, res=None, res_bits=None, up_x=None, up_stats=None):
     """1x1 / stride-1 conv_dgrad whose result is stored gated by ``up_bits`` (the ReLU decisions of the block output it is the
     gradient of) and whose per-tile column sums go to ``partial`` (second half of every row: zero, or with ``up_x`` /
@@ -500,6 +532,29 @@ def conv_dgrad_masksum(dy, wt, in_hw, out, up_bits, partial, res=None, res_bits=
                                              ptr(up_bits), ptr(up_stats), ptr(partial), partial.numel(), ctypes.byref(nt),
                                              stream_ptr()),
           "iif_conv_igemm_dgrad_masksum")
+    return nt.value
+
+
+def conv_dgrad_rx_ok(n, h, w, cs, cd, c2, dtype):
+    """Whether iif_conv_igemm_dgrad_masksum_rx takes a 1x1 data gradient cs -> cd with the upstream x recomputed over c2 channels."""
+    if dtype != torch.bfloat16:
+        return False
+    d = _desc(n, h, w, cs, h, w, cd, 1, 1, 1, 0, 1, cs, _lib.IIF_BF16, _lib.IIF_BF16, 1)
+    return bool(lib().iif_conv_dgrad_rx_ok(ctypes.byref(d), c2))
+
+
+def conv_dgrad_masksum_rx(dy, wt, in_hw, out, up_bits, partial, up_a2, up_w3, up_stats, res=None, res_bits=None):
+    """conv_dgrad_masksum with (sum g~, sum g~ xhat) rows whose xhat comes from the upstream conv3 RECOMPUTED per tile
+    (up_a2 [n, h, w, c2], up_w3 [cd, ldw3] bf16) instead of read from memory; returns the row count."""
+    require_gpu(dy, wt, res, out, up_a2, up_w3)
+    n, ho, wo, cout = dy.shape
+    cin, ldw = wt.shape
+    h, w_ = in_hw
+    d = _desc(n, ho, wo, cout, h, w_, cin, 1, 1, 1, 0, 1, ldw, dtype_code(dy), dtype_code(out), 1)
+    nt = ctypes.c_int32(0)
+    check(lib().iif_conv_igemm_dgrad_masksum_rx(ctypes.byref(d), ptr(dy), ptr(wt), ptr(out), ptr(res), ptr(res_bits), ptr(up_a2),
+                                                up_a2.shape[3], ptr(up_w3), up_w3.stride(0), ptr(up_bits), ptr(up_stats), ptr(partial),
+                                                partial.numel(), ctypes.byref(nt), stream_ptr()), "iif_conv_igemm_dgrad_masksum_rx")
     return nt.value
 
 

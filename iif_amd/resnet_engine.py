@@ -763,7 +763,9 @@ class _Plan(object):
         # still reads conv3's output once for sum g~ xhat (3 passes saved) and P moves to the weight-gradient stream.
         self.wg_lag = 2      # blocks the weight-gradient stream may lag (explained where the side streams are created; 3 / 4 / 6 measured level)
         self.alg3_units = set()
-        self.a3_pure_min = float(os.environ.get("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "1.5e8"))
+        # (round 6: 9e7 = the 56 x 56 and 28 x 28 stages at batch 256 - "sums from P" is what lets the forward pass never store
+        # conv3's output, see nostore_units below; 1.5e8 = the 56 x 56 stage only, as in rounds 3-5)
+        self.a3_pure_min = float(os.environ.get("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "9e7"))
         if self.fuse_bwd and net._sync_bn is None and not os.environ.get("IIF_NO_BN3_ALGEBRA"):
             for bi, b in enumerate(self.blocks[:-1]):
                 if "se" in b or "sc" in b or len(b["units"]) != 3:
@@ -794,6 +796,30 @@ class _Plan(object):
                 if (u3 in self.alg3_units and self._a3_is_pure(u3) and "ds" not in b and "se" not in nxt and f.conv.k == 1
                         and f.conv.stride == 1 and f.groups == 1 and _dma_ok(f.y) and _dma_ok(u3.src)):
                     self.twopass_units.add(u3)
+        # Never-stored forward on the register-weight kernel (round 6): pass 1 = the convolution's statistics straight from the
+        # accumulators (iif_conv_igemm_stats_acc: nothing staged, nothing stored, ~the time of reading a2 once), finalisation,
+        # pass 2 = the convolution again with bn3 + identity (or the NORMALISED output of the block's convolutional shortcut) +
+        # ReLU + ReLU bits in its epilogue (iif_conv_igemm_bn_relu2).  conv3's raw output - the widest tensor of the block - is
+        # neither written nor read: -2 passes over [M, C] per block for one more pass over [M, c].  Units: every "sums from P"
+        # algebra unit whose shape the kernel takes, downsample blocks included.  IIF_NO_NOSTORE=1 switches it off.
+        # "sums from the producer" WITHOUT the stored output (round 6, iif_conv_igemm_dgrad_masksum_rx): the data gradient that
+        # produces g~ recomputes conv3's tile from a2 and W3 on the matrix pipe for its sum g~ xhat.  P leaves the compute stream again
+        # (7 launches, 1.4 ms at batch 256: profiles/r6 timeline) and nothing reads conv3's output.  Preferred over "sums from P"
+        # wherever the register-weight kernel has the (K, c) instance.  IIF_NO_RX=1 switches it off.
+        self.rx_units = set()
+        if self.alg3_units and not os.environ.get("IIF_NO_RX"):
+            for bi, b in enumerate(self.blocks[:-1]):
+                u3 = b["units"][-1]
+                f = self.blocks[bi + 1]["units"][0]
+                if u3 in self.alg3_units and ops.conv_dgrad_rx_ok(f.n, f.hi, f.wi, f.conv.cout, f.conv.cin, u3.conv.cin, dt):
+                    self.rx_units.add(u3)
+        self.nostore_units = set()
+        if self.alg3_units and not os.environ.get("IIF_NO_NOSTORE"):
+            for b in self.blocks[:-1]:
+                u3 = b["units"][-1]
+                if (u3 in self.alg3_units and (self._a3_is_pure(u3) or u3 in self.rx_units) and u3 not in self.twopass_units
+                        and ops.conv_fwdbn_ok(u3.n, u3.ho, u3.wo, u3.conv.cin, u3.conv.cout, dt) and _dma_ok(u3.src)):
+                    self.nostore_units.add(u3)
         self.a3 = None
         if self.alg3_units:
             cm = max(u.conv.cin for u in self.alg3_units)
@@ -1176,6 +1202,23 @@ class _Plan(object):
                 x2 = self._conv_bn(uu, training)
                 ops.bn_apply(x2, uu.stats, uu.y.view(x2.shape), relu=True, relu_bits=uu.bits)
             last = units[-1]
+            if training and last in self.nostore_units and last in self.alg3_units and self.fuse_bwd:
+                cv = last.conv
+                m = last.n * last.ho * last.wo
+                nt = ops.conv_forward_stats_acc(last.src, last.w, self.bn_partial)
+                ops.bn_finalize_stats(self.bn_partial, nt, m, cv.cout, last.bn.weight, last.bn.bias, last.bn.running_mean,
+                                      last.bn.running_var, last.stats, BN_EPS, BN_MOMENTUM, scratch=self.bn_scratch,
+                                      tickets=self.bn_tickets)
+                if "ds" in b:
+                    du = b["ds"]
+                    if ds_done is not None:
+                        torch.cuda.current_stream().wait_event(ds_done)
+                    else:
+                        self._conv_bn(du, training)
+                    ops.conv_forward_bn_relu2(last.src, last.w, last.y, last.stats, last.bits, res=du.x, res_stats=du.stats)
+                else:
+                    ops.conv_forward_bn_relu2(last.src, last.w, last.y, last.stats, last.bits, res=b["inp"])
+                continue
             if training and last in self.twopass_units:
                 cv = last.conv
                 m = last.n * last.ho * last.wo
@@ -1374,7 +1417,7 @@ class _Plan(object):
                                        gmasked=None if gmasked is None else gmasked.view(m, cv.cout), relu_bits=bits)
         elif ready is not None and ready[0] is u and len(ready) == 3:
             return self._bn3_algebra(u, gy, ready[1], par, self._cur_block, dgrad_out, fuse_up, ready[2])
-        elif u in self.twopass_units:
+        elif u in self.twopass_units or (u in self.nostore_units and u in self.alg3_units):
             raise RuntimeError("two-pass unit reached the standard BN backward: its convolution output was never stored")
         elif ready is not None and ready[0] is u and gmasked is None:
             # the data gradient that wrote gy already reduced (sum g, sum g*xhat) per tile: no reduction pass
@@ -1413,6 +1456,11 @@ class _Plan(object):
                 # the upstream unit's BN backward runs by algebra: store the gradient gated by its block's ReLU, emit its
                 # column sums only (conv3's output is not read)
                 rows = self._alg_rows.get(id(up), self.bw_partial)
+                if up in self.rx_units:
+                    nt = ops.conv_dgrad_masksum_rx(dx4, u.wt, (u.hi, u.wi), dgrad_out, up_bits, rows, up.src, up.w, up.stats,
+                                                   res=dgrad_res, res_bits=dgrad_res_bits)
+                    self._bw_ready = (up, nt, rows)
+                    return dgrad_out
                 nt = ops.conv_dgrad_masksum(dx4, u.wt, (u.hi, u.wi), dgrad_out, up_bits, rows, res=dgrad_res,
                                             res_bits=dgrad_res_bits, up_x=None if self._a3_is_pure(up) else up.x,
                                             up_stats=None if self._a3_is_pure(up) else up.stats)
@@ -1426,7 +1474,8 @@ class _Plan(object):
                               groups=u.groups, res_bits=dgrad_res_bits, w_frag=u.wtf)
 
     def _a3_is_pure(self, u):
-        return u.n * u.ho * u.wo * u.conv.cout >= self.a3_pure_min
+        """"Sums from P" (P = g~^T a2 on the compute stream before the coefficients); never where the producer recomputes x."""
+        return u not in getattr(self, "rx_units", ()) and u.n * u.ho * u.wo * u.conv.cout >= self.a3_pure_min
 
     def _a3_gram_stacked(self, u):
         """The Gram matrix a2^T a2 rides in the launch that forms P on the weight-gradient stream ([g~ | a2]^T a2,

@@ -444,10 +444,35 @@ int iif_conv_igemm_stats_only(const iif_conv_desc* d, const void* src, const voi
                               int64_t bn_partial_floats, int32_t* n_partials, void* stream);
 int iif_conv_igemm_bn_relu(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                            const float* stats, unsigned char* relu_bits, void* stream);
+/* Round 6: the same two passes on the register-weight kernel (cs in {64, 128, 256}, cd a multiple of 256, n*hd*wd a multiple
+ * of 64; iif_conv_fwdbn_ok says whether a descriptor qualifies), which is what makes the never-stored forward pay
+ * (resnet_pytorch.py:160-167: conv3 -> bn3 -> += identity -> relu):
+ *   iif_conv_igemm_stats_acc    pass 1: (sum, sum of squares) of the UNROUNDED fp32 accumulators, one partial row per tile
+ *                               sequence, nothing staged or stored (the statistics of the convolution itself rather than of
+ *                               its bf16 rounding; feed iif_bn_finalize_stats as usual);
+ *   iif_conv_igemm_bn_relu2     pass 2: as iif_conv_igemm_bn_relu; with res_stats the residual is the RAW output of the
+ *                               block's convolutional shortcut and is normalised on the way in, fma(a2, res, b2) with a2 / b2 at
+ *                               res_stats[2 Cd + c] / [3 Cd + c] (iif_bn_apply's residual_stats arithmetic).  relu_bits required. */
+int iif_conv_fwdbn_ok(const iif_conv_desc* d);
+int iif_conv_igemm_stats_acc(const iif_conv_desc* d, const void* src, const void* wgt, float* bn_partial,
+                             int64_t bn_partial_floats, int32_t* n_partials, void* stream);
+int iif_conv_igemm_bn_relu2(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                            const float* res_stats, const float* stats, unsigned char* relu_bits, void* stream);
 int iif_conv_igemm_dgrad_masksum(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                                  const unsigned char* res_bits, const void* up_x, const unsigned char* up_bits,
                                  const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,
                                  void* stream);
+/* Round 6: iif_conv_igemm_dgrad_masksum whose (sum dst, sum dst * xhat) rows are formed WITHOUT the upstream block's conv3 output:
+ * each tile of it is recomputed on the matrix pipe from that block's a2 (up_a2, [n*h*w, up_c2] bf16) and conv3 weights as the
+ * forward multiplied them (up_w3, [cd, up_ldw3] bf16), rounded to bf16 as the stored tensor would have been.  Together with
+ * iif_conv_igemm_stats_acc / iif_conv_igemm_bn_relu2 this lets the forward pass never store that output, with "sums from the
+ * producer" (P and Gram off the critical path).  Register-weight kernel only: iif_conv_dgrad_rx_ok(d, up_c2) says whether the
+ * (cs, up_c2) pair has an instance ((64, 64), (128, 64), (128, 128), (256, 128)). */
+int iif_conv_dgrad_rx_ok(const iif_conv_desc* d, int up_c2);
+int iif_conv_igemm_dgrad_masksum_rx(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                                    const unsigned char* res_bits, const void* up_a2, int up_c2, const void* up_w3, int up_ldw3,
+                                    const unsigned char* up_bits, const float* up_stats, float* partial, int64_t partial_floats,
+                                    int32_t* n_partials, void* stream);
 int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* src, const void* src2, int cs2, const void* wgt,
                                 const float* bias, void* dst, const void* up_x, const unsigned char* up_bits,
                                 const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,

@@ -3,7 +3,7 @@
 set -e -o pipefail
 tag=${1:-kt}; filt=${2:-.}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out/r4; mkdir -p $out
+out=$root/gpurun_out/${KT_DIR:-r6}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_$tag
 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/p_$tag -- python3 $root/bench.py --no-cpu-baseline --no-kernel-events --no-fp32-step --steps 10 --warmup 3 $KT_ARGS > $out/$tag.log 2>&1

@@ -931,6 +931,88 @@ def test_two_pass_forward_is_bit_identical_to_conv_then_bn_apply(case, stream, c
     assert torch.equal(a_two, a_ref) and torch.equal(bits_two, bits_ref)
 
 
+@pytest.mark.parametrize("case", [(4, 16, 64, 256), (2, 32, 128, 512), (4, 16, 256, 1024), (16, 56, 64, 256), (4, 16, 128, 256),
+                                  (2, 24, 256, 512)], ids=lambda c: "%dx%dx%d_%d_%d" % (c[0], c[1], c[1], c[2], c[3]))
+def test_never_stored_forward_on_the_register_weight_kernel(case):
+    """Round 6: iif_conv_igemm_stats_acc + iif_conv_igemm_bn_relu2 (weights in registers).  Pass 2 with given statistics is
+    bit-identical to convolution + iif_bn_apply (plain residual, normalised residual of a convolutional shortcut, none);
+    pass 1's rows sum to the column sums of the fp32 product (the unrounded accumulators), 1e-5 of sum |y| / sum y^2."""
+    from iif_amd import ops
+    n, hw, c, C = case
+    m = n * hw * hw
+    assert ops.conv_fwdbn_ok(n, hw, hw, c, C, torch.bfloat16)
+    g = torch.Generator().manual_seed(13 * c + hw)
+    dt = torch.bfloat16
+    x = torch.relu(torch.randn(n, hw, hw, c, generator=g)).to(dt).to(DEV)
+    w = (torch.randn(C, c, generator=g) / c ** 0.5).to(dt).to(DEV)
+    res = torch.randn(n, hw, hw, C, generator=g).to(dt).to(DEV)
+    rows = (m + 127) // 128 + 8
+    # pass 1 against the fp32 product
+    p = torch.full((rows, 2, C), float("nan"), device=DEV)
+    nt = ops.conv_forward_stats_acc(x, w, p.view(-1))
+    assert 0 < nt <= (m + 127) // 128
+    yf = x.view(m, c).float() @ w.float().t()
+    s, q = p[:nt, 0].double().sum(0), p[:nt, 1].double().sum(0)
+    assert not torch.isnan(p[:nt]).any()
+    assert ((s - yf.double().sum(0)).abs() <= 1e-5 * yf.double().abs().sum(0) + 1e-6).all()
+    assert ((q - (yf.double() ** 2).sum(0)).abs() <= 1e-5 * (yf.double() ** 2).sum(0) + 1e-6).all()
+    # pass 2 against convolution + bn_apply, same statistics
+    gamma, beta = torch.rand(C, generator=g).to(DEV) + 0.5, torch.randn(C, generator=g).to(DEV) * 0.1
+    stats = torch.zeros(4, C, device=DEV)
+    ops.bn_finalize_stats(p.view(-1), nt, m, C, gamma, beta, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), stats, 1e-5, 0.1)
+    stats2 = torch.zeros(4, C, device=DEV)
+    stats2[2] = torch.rand(C, generator=g).to(DEV) + 0.5
+    stats2[3] = torch.randn(C, generator=g).to(DEV) * 0.2
+    y = ops.conv_forward(x, w, 1, 1, 1, 0)
+    a_ref = torch.empty_like(y)
+    bits_ref = torch.zeros(m * C // 8, dtype=torch.uint8, device=DEV)
+    for r_, rs_ in ((res, None), (res, stats2), (None, None)):
+        ops.bn_apply(y.view(m, C), stats, a_ref.view(m, C), relu=True, residual=None if r_ is None else r_.view(m, C),
+                     residual_stats=rs_, relu_bits=bits_ref)
+        a_two = torch.full_like(y, float("nan"))
+        bits_two = torch.full_like(bits_ref, 0xAA)
+        ops.conv_forward_bn_relu2(x, w, a_two, stats, bits_two, res=r_, res_stats=rs_)
+        assert torch.equal(a_two, a_ref) and torch.equal(bits_two, bits_ref)
+
+
+@pytest.mark.parametrize("case", [(4, 16, 64, 256, 64), (4, 16, 128, 256, 64), (2, 32, 128, 512, 128), (4, 16, 256, 512, 128),
+                                  (16, 56, 64, 256, 64)], ids=lambda c: "%dx%dx%d_k%d_n%d_c%d" % (c[0], c[1], c[1], c[2], c[3], c[4]))
+@pytest.mark.parametrize("with_res", [False, True], ids=["plain", "residual"])
+def test_dgrad_masksum_with_the_upstream_output_recomputed(case, with_res):
+    """Round 6: iif_conv_igemm_dgrad_masksum_rx (the upstream block's conv3 tile recomputed from its a2 and weights) against
+    iif_conv_igemm_dgrad_masksum reading that output from memory: gated data gradient and partial rows bit-identical (the
+    recomputed tile is the stored one, value for value: same K order, same bf16 rounding)."""
+    from iif_amd import ops
+    n, hw, k, C, c2 = case
+    m = n * hw * hw
+    dt = torch.bfloat16
+    assert ops.conv_dgrad_rx_ok(n, hw, hw, k, C, c2, dt)
+    g = torch.Generator().manual_seed(7 * k + c2 + hw)
+    a2 = torch.relu(torch.randn(n, hw, hw, c2, generator=g)).to(dt).to(DEV)
+    w3 = (torch.randn(C, c2, generator=g) / c2 ** 0.5).to(dt).to(DEV)
+    y3 = ops.conv_forward(a2, w3, 1, 1, 1, 0)                          # what the forward pass would have stored
+    dy = torch.randn(n, hw, hw, k, generator=g).to(dt).to(DEV)          # dL/dx1 of the next block's conv1
+    wt = (torch.randn(C, k, generator=g) / k ** 0.5).to(dt).to(DEV)     # its transposed weights [cin = C][cout = k]
+    ubits = torch.randint(0, 256, (m * C // 8,), dtype=torch.uint8, generator=g).to(DEV)
+    res = torch.randn(n, hw, hw, C, generator=g).to(dt).to(DEV) if with_res else None
+    rbits = torch.randint(0, 256, (m * C // 8,), dtype=torch.uint8, generator=g).to(DEV) if with_res else None
+    stats = torch.zeros(4, C)
+    stats[0] = torch.randn(C, generator=g) * 0.1
+    stats[1] = torch.rand(C, generator=g) + 0.5
+    stats = stats.to(DEV)
+    rows = (m + 127) // 128 + 8
+    o1 = torch.full((n, hw, hw, C), float("nan"), dtype=dt, device=DEV)
+    p1 = torch.full((rows, 2, C), float("nan"), device=DEV)
+    nt1 = ops.conv_dgrad_masksum(dy, wt, (hw, hw), o1, ubits, p1.view(-1), res=res, res_bits=rbits, up_x=y3, up_stats=stats)
+    o2 = torch.full((n, hw, hw, C), float("nan"), dtype=dt, device=DEV)
+    p2 = torch.full((rows, 2, C), float("nan"), device=DEV)
+    nt2 = ops.conv_dgrad_masksum_rx(dy, wt, (hw, hw), o2, ubits, p2.view(-1), a2, w3, stats, res=res, res_bits=rbits)
+    assert nt1 == nt2 and nt1 > 0
+    assert torch.equal(o1, o2)
+    assert not torch.isnan(p2[:nt2]).any()
+    assert torch.equal(p1[:nt1], p2[:nt2])
+
+
 @pytest.mark.parametrize("case", [(4, 128, 14, 14, 32), (2, 256, 28, 28, 32), (1, 512, 7, 7, 32), (3, 64, 9, 11, 8)],
                          ids=lambda c: "n%d_w%d_%dx%d_g%d" % c)
 def test_grouped_conv3x3_on_the_fragment_kernel(case, conv_env):

@@ -317,7 +317,7 @@ def test_decoupled_classifier_stage():
 
 
 @pytest.mark.parametrize("arch,C,B,hw", [("resnet50", 1000, 32, 64), ("resnet18", 100, 16, 64)])
-def test_bf16_fused_bn_backward_sums_match_the_reduction_pass(arch, C, B, hw):
+def test_bf16_fused_bn_backward_sums_match_the_reduction_pass(arch, C, B, hw, monkeypatch):
     """bf16 mode: the BN-backward sums emitted by the data-gradient epilogues (iif_conv_igemm_dgrad_bnbwd +
     iif_bn_backward_partials) against the standalone reduction pass over (dy, x).  The sums themselves agree to
     1e-6 (tests/test_conv_gpu.py::test_dgrad_emits_upstream_bn_backward_sums); the fp32 summation order differs,
@@ -325,6 +325,7 @@ def test_bf16_fused_bn_backward_sums_match_the_reduction_pass(arch, C, B, hw):
     that layer by layer (measured at 8 images: 1.5e-4 at layer4.1 growing to ~1e-2 at layer1), so the whole-net bound is loose and
     the per-tensor bound only excludes O(1) errors (a wrong partial row or mask)."""
     from iif_amd.custom import IIFLoss
+    monkeypatch.setenv("IIF_NO_NOSTORE", "1")       # both runs on the stored forward (the never-stored one normalises with other statistics)
     counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
     net, sd = _build(arch, C, torch.bfloat16)
     net.load_state_dict(damp_residual_branches(sd, arch))
@@ -364,6 +365,8 @@ def test_bn3_backward_by_algebra_inside_the_step(monkeypatch, pure, streams):
     from iif_amd.custom import IIFLoss
     monkeypatch.setenv("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "0" if pure else "1e30")
     monkeypatch.setenv("IIF_TWOPASS", "1")                  # with sums from P: conv3's output is not even stored in forward
+    monkeypatch.setenv("IIF_NO_NOSTORE", "1")               # (the round-6 forward has a test of its own below: its statistics are not bit-identical)
+    monkeypatch.setenv("IIF_NO_RX", "1")                    # (and so has the producer that recomputes conv3's tile: these are the round-3 routes)
     if streams == "no_shortcut_stream":                     # the shortcut's BN backward then runs on the compute stream, in front
         monkeypatch.setenv("IIF_NO_BWD_SIDE", "1")          # of a weight-gradient stream that may still read the block's g
     elif streams == "one_stream":
@@ -394,6 +397,59 @@ def test_bn3_backward_by_algebra_inside_the_step(monkeypatch, pure, streams):
         a_, b_ = alg[off:off + rows * pitch], std[off:off + rows * pitch]
         e = (a_ - b_).norm().item() / max(b_.norm().item(), 1e-12)
         assert e <= (8e-2 if m_ is net.bn1 else 3e-2), (type(m_).__name__, attr, e)
+
+
+@pytest.mark.parametrize("streams", ["three_streams", "one_stream"])
+def test_never_stored_conv3_forward_inside_the_step(monkeypatch, streams):
+    """Round 6: conv3's raw output is neither written nor read (statistics from the accumulators, BN + identity / normalised
+    shortcut + ReLU in the convolution's epilogue, "sums from P" backward).  Its statistics are those of the unrounded
+    convolution instead of its bf16 rounding, so its forward is NOT bit-identical to the standard route's: a few ReLU decisions
+    flip and the 50 layers amplify that (measured, scripts/dbg_nostore.py: the two bf16 routes are 2e-1 apart at this
+    initialisation and both 3.1e-1 from the fp32 step).  What is asserted: the loss agrees to bf16-noise level; the route is no
+    further from the fp32-compute step of the same network than the standard bf16 route is (whole gradient and per tensor);
+    nothing reads conv3's raw output (NaN-filled); repeated steps are bit-identical."""
+    from iif_amd.custom import IIFLoss
+    monkeypatch.setenv("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "0")
+    if streams == "one_stream":
+        monkeypatch.setenv("IIF_NO_WGRAD_STREAM", "1")
+    arch, C, B, hw = "resnet50", 1000, 32, 128
+    counts = [max(int(1000 * (5 / 1000) ** (i / (C - 1.0))), 1) for i in range(C)]
+    x, y = _data(B, hw, counts, seed=23)
+    crit = IIFLoss(DS(counts), variant="raw")
+    xd, yd = x.to(DEV), y.to(DEV)
+    net32, sd = _build(arch, C, torch.float32)
+    net32.load_state_dict(damp_residual_branches(sd, arch))
+    net32.train()
+    loss32, _ = net32.loss_and_backward(xd, yd, crit)
+    ref = net32._grad_arena.clone()
+    del net32
+    net, sd = _build(arch, C, torch.bfloat16)
+    net.load_state_dict(damp_residual_branches(sd, arch))
+    net.train()
+    loss_ns, _ = net.loss_and_backward(xd, yd, crit)
+    loss_ns = loss_ns.item()
+    plan = net._saved
+    assert len(plan.alg3_units) == 13
+    # 32 x 32, 16 x 16 and 8 x 8 pixels at batch 32: every algebra unit has >= 1024 rows, downsample blocks included
+    assert len(plan.nostore_units) == 13 and not plan.twopass_units
+    for u in plan.nostore_units:
+        u.x.fill_(float("nan"))                             # nothing may read conv3's raw output
+    ns = net._grad_arena.clone()
+    loss_again, _ = net.loss_and_backward(xd, yd, crit)
+    assert loss_again.item() == loss_ns and torch.equal(net._grad_arena, ns)
+    assert not torch.isnan(ns).any()
+    keep, plan.alg3_units = plan.alg3_units, set()
+    loss_std, _ = net.loss_and_backward(xd, yd, crit)
+    std = net._grad_arena.clone()
+    plan.alg3_units = keep
+    assert abs(loss_ns - loss_std.item()) <= 2e-3 * abs(loss_std.item())
+    assert abs(loss_ns - loss32.item()) <= 2e-3 * abs(loss32.item())
+    rel = lambda a_, b_: (a_ - b_).norm().item() / max(b_.norm().item(), 1e-12)      # noqa: E731
+    assert rel(ns, ref) <= 1.05 * rel(std, ref) + 5e-3, (rel(ns, ref), rel(std, ref))
+    for (m_, attr, rows, pitch) in net._param_specs():
+        off = net._offsets[(id(m_), attr)][0]
+        sl = slice(off, off + rows * pitch)
+        assert rel(ns[sl], ref[sl]) <= 1.25 * rel(std[sl], ref[sl]) + 2e-2, (type(m_).__name__, attr, rel(ns[sl], ref[sl]), rel(std[sl], ref[sl]))
 
 
 def test_stride1_shortcut_bn_backward_by_algebra(monkeypatch):
@@ -731,11 +787,13 @@ def test_bf16_loss_curve_of_the_default_routes_against_the_standard_backward(mon
             losses.append(float(loss.item()))
         if mode == "default":
             plan = net._saved
-            assert len(plan.alg3_units) == 13 and any(plan._a3_is_pure(u) for u in plan.alg3_units) \
-                and not all(plan._a3_is_pure(u) for u in plan.alg3_units)               # the mixed configuration
+            # the mixed configuration of the benchmark: the 56 x 56 and 28 x 28 stages never store conv3's output (statistics pass +
+            # BN epilogue forward, producer-recomputed sums backward), the 14 x 14 stage takes the stored route
+            assert len(plan.alg3_units) == 13 and len(plan.rx_units) == 7 and len(plan.nostore_units) == 7
         curves[mode] = losses
         del net
-    for a, b, tol in zip(curves["default"], curves["standard"], (1e-6, 1e-3, 2e-3, 5e-3, 1e-2, 2e-2)):
+    # (the first loss is no longer bit-equal: the never-stored forward normalises with the statistics of the unrounded convolution)
+    for a, b, tol in zip(curves["default"], curves["standard"], (1e-3, 2e-3, 3e-3, 5e-3, 1e-2, 2e-2)):
         assert abs(a - b) <= tol * abs(b), (curves["default"], curves["standard"])
     assert curves["default"][-1] < curves["default"][0]              # (lr 0.002: the raw IIF recipe descends smoothly)
 
