@@ -70,7 +70,8 @@ class ConvTimer(object):
         timer = self
         orig = {k: getattr(ops, k) for k in ("conv_forward", "conv_dgrad", "conv_wgrad", "conv_forward_bnstats",
                                              "conv_dgrad_bnbwd", "conv_dgrad_masksum", "conv_dgrad2_bnbwd", "wgrad1x1_stacked",
-                                             "conv_forward_stats_acc", "conv_forward_bn_relu2", "conv_dgrad_masksum_rx")}
+                                             "conv_forward_stats_acc", "conv_forward_bn_relu2", "conv_dgrad_masksum_rx",
+                                             "conv_forward_bnstats_pro")}
 
         def alg_k(r, s, stride, pad, cin):
             # algorithmic K of one output: the space-to-depth stem (4x4/1 pad 2 on 16 padded channels) is charged
@@ -159,6 +160,14 @@ class ConvTimer(object):
             fl = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * w.shape[0]
             return timer._timed("fwd", fl, nbytes(x, w, kw.get("res"), out), orig["conv_forward_bn_relu2"], x, w, out, stats, relu_bits, **kw)
 
+        def conv_forward_bnstats_pro(x_raw, x_stats, act_out, act_bits, w, out, partial, **kw):
+            # conv3 (out given: charged its FLOPs) or its statistics pass (out None: 0) with bn2 + ReLU in the operand path: reads the raw
+            # conv2 output, writes the activation as a by-product (the bn_apply pass it replaces is taken off streaming_pass_bytes)
+            fl = 0.0 if out is None else 2.0 * x_raw.shape[0] * x_raw.shape[1] * x_raw.shape[2] * x_raw.shape[3] * w.shape[0]
+            return timer._timed("fwd", fl, nbytes(x_raw, w, act_out, out), orig["conv_forward_bnstats_pro"], x_raw, x_stats, act_out, act_bits,
+                                w, out, partial, **kw)
+
+        ops.conv_forward_bnstats_pro = conv_forward_bnstats_pro
         ops.conv_forward_stats_acc, ops.conv_forward_bn_relu2 = conv_forward_stats_acc, conv_forward_bn_relu2
         ops.conv_dgrad_masksum_rx = conv_dgrad_masksum_rx
         ops.wgrad1x1_stacked = wgrad1x1_stacked
@@ -234,6 +243,12 @@ def streaming_pass_bytes(net, batch, image):
         # round 6: conv3's raw output is never stored - no forward normalise pass (BN + residual + ReLU sit in the convolution's
         # epilogue, whose launch is charged the residual and the block output; its statistics pass is charged its input)
         total -= 2 * s * float(u.n * u.ho * u.wo * u.conv.cout)
+    for u3, pro in getattr(plan, "pro_units", {}).items():
+        # round 6: bn2's forward normalise runs inside conv3's launch (charged there: raw input read, activation written)
+        u2 = pro[0]
+        total -= 2 * s * float(u2.n * u2.ho * u2.wo * u2.conv.cout)
+        if pro[1] is not None:
+            total -= s * float(u3.n * u3.ho * u3.wo * u3.conv.cin)             # and so do the column sums of a2 the algebra route needs
     for b in plan.blocks:
         last = b["units"][-1]
         if last in nostore:

@@ -81,6 +81,8 @@ SIGNATURES = {
     "iif_conv_igemm_stats_acc": [_P, _P, _P, _P, _L, _P, _P],
     "iif_conv_igemm_bn_relu2": [_P, _P, _P, _P, _P, _P, _P, _P, _P],
     "iif_conv_igemm_dgrad_masksum": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
+    "iif_conv_pro_ok": [_P, _I],
+    "iif_conv_igemm_bnstats_pro": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "iif_conv_dgrad_rx_ok": [_P, _I],
     "iif_conv_igemm_dgrad_masksum_rx": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _L, _P, _P],
     "iif_conv_igemm_dgrad2_bnbwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],

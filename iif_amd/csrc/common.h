@@ -64,17 +64,23 @@ struct iif_regw_epilogue {
     // round 6: instead of bw_x, the operands it is recomputed from per tile: the upstream block's a2 [M, rx_k2] and its conv3 weights [N, rx_ldw3]
     const void* rx_src2; const void* rx_w3; int rx_k2, rx_ldw3;
 };
+// round 6: `src` is the raw output of the previous convolution; its BN + ReLU (stats laid out as iif_bn_finalize_stats writes them) is
+// applied to each tile in LDS and the activation written out as a by-product (out [M, K] bf16, bits one byte per 16-byte vector;
+// csum nullable: one row [2][K] = (column sums of the activation, zeros) per partial row of the launch: iif_bn_partial_sums reduces them)
+struct iif_regw_prologue { const float* stats; void* out; unsigned char* bits; float* csum; };
 bool iif_regw1x1_ok(int M, int K, int N, int epi);
 bool iif_regw1x1_rx_ok(int M, int K, int N, int k2);
+bool iif_regw1x1_pro_ok(int M, int K, int N);
 int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
-                       int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, int no_store, hipStream_t st);
+                       int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, int no_store, hipStream_t st,
+                       const iif_regw_prologue* pro = nullptr);
 // the two passes of the never-stored conv + BN (+ identity / normalised shortcut) + ReLU forward (K in {64, 128, 256}, N a multiple
 // of 256): statistics from the accumulators (no store), and the convolution with bn_apply's arithmetic in its epilogue
 bool iif_regw1x1_fwdbn_ok(int M, int K, int N);
 int iif_regw1x1_fwdbn_launch(const void* src, const void* wgt, void* dst, int M, int K, int N, int spitch, int ldw, int dpitch,
                              const void* res, const float* aff, const float* aff2, unsigned char* relu_out, hipStream_t st);
 int iif_regw1x1_stats_launch(const void* src, const void* wgt, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
-                             int M, int K, int N, int spitch, int ldw, int dpitch, hipStream_t st);
+                             int M, int K, int N, int spitch, int ldw, int dpitch, hipStream_t st, const iif_regw_prologue* pro = nullptr);
 // 3x3 / stride 1 / pad 1, C -> C channels (64, 128), forward or data gradient (explicit tap list), optional upstream BN-backward sums
 bool iif_regw3x3_ok(int N, int H, int W, int C);
 int iif_regw3x3_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
@@ -85,3 +91,4 @@ int iif_regw3x3_launch(const void* src, const void* wgt, void* dst, float* bn_pa
 // sizes itself to: the device's count, or the budget set by iif_set_cu_budget() when that is smaller (a rank that overlaps
 // RCCL's reduction kernels with backward leaves them a few CUs instead of making their blocks queue behind a persistent grid).
 int iif_persistent_cus();
+int iif_persistent_grid(int unit);      // blocks of a grid launched in whole units of `unit` blocks, within the budget (see iif_host.cpp)

@@ -64,6 +64,9 @@ struct ConvArgs {
     //   rx_* (round 6, register-weight kernel only): the upstream x of the backward sums is recomputed per tile from the upstream
     //   block's a2 (rx_src2, [M, rx_k2]) and conv3 weights (rx_w3, [Cd, rx_ldw3]) instead of being read from bw_x.
     const unsigned char* rx_src2; const unsigned char* rx_w3; int rx_k2, rx_ldw3;
+    //   pro_* (round 6, register-weight kernel only): src is the previous convolution's RAW output; its BN + ReLU (pro_stats) is applied
+    //   per tile in LDS, the activation (pro_out, pro_bits; pro_csum nullable: column-sum rows) is written as a by-product.
+    const float* pro_stats; unsigned char* pro_out; unsigned char* pro_bits; float* pro_csum;
     int no_store;
     const float* aff;
     const float* aff2;
@@ -1848,13 +1851,12 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
     }
     StreamPlan sp{0, 0, 0};
     if (!force_v1_ && src_bytes < 0x7f000000LL && wgt_bytes < 0x7f000000LL && use_stream1x1(a, utap, (int)sizeof(T), OUTF32, &sp)) {
-        const int cus = iif_persistent_cus();
         a.mtiles = (a.M + 127) / 128;
         a.ntiles = sp.slices;
         // one block per CU, in whole groups of 8 S (the S slices of a tile sequence on one XCD); a short layer takes fewer
         // sequences, never more than it has tiles
         const int unit = 8 * sp.slices;
-        int grid = cus / unit * unit;
+        int grid = iif_persistent_grid(unit);
         const int need = (a.mtiles + 7) / 8 * unit;         // sequences in multiples of 8, S blocks each
         if (need < grid) grid = need;
         if (grid >= unit) {
@@ -1952,9 +1954,16 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
                             a.dpitch == a.Cd && a.Hs == a.Hd && a.Ws == a.Wd && !a.bias && !a.src2 && !a.sbias && !a.transposed;
         const bool geo1x1x = dma_ok && !g_sw.no_regw && a.R == 1 && a.S == 1 && a.sshift == 0 && a.pad == 0 && a.groups == 1 && a.spitch == a.Cs &&
                              a.dpitch == a.Cd && a.Hs == a.Hd && a.Ws == a.Wd && !a.bias && !a.src2 && !a.sbias;
+        const iif_regw_prologue pro{a.pro_stats, a.pro_out, a.pro_bits, a.pro_csum};
         if (a.no_store == 2) {
             if (!geo1x1 || !a.bn_partial || a.res || a.bw_x || a.mask_store || a.aff) return IIF_EUNSUPPORTED;
-            return iif_regw1x1_stats_launch(a.src, a.wgt, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.M, a.Cs, a.Cd, a.spitch, a.ldw, a.dpitch, st);
+            return iif_regw1x1_stats_launch(a.src, a.wgt, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.M, a.Cs, a.Cd, a.spitch, a.ldw, a.dpitch, st,
+                                            a.pro_stats ? &pro : nullptr);
+        }
+        if (a.pro_stats) {                                    // plain forward + statistics with the prologue: no other kernel has it
+            if (!geo1x1 || !a.bn_partial || a.res || a.bw_x || a.mask_store || a.aff || a.no_store || !iif_regw1x1_pro_ok(a.M, a.Cs, a.Cd)) return IIF_EUNSUPPORTED;
+            return iif_regw1x1_launch(a.src, a.wgt, a.dst, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.M, a.Cs, a.Cd, a.spitch, a.ldw, a.dpitch,
+                                      nullptr, 0, st, &pro);
         }
         if (a.aff && geo1x1 && a.relu_out && !a.bn_partial && !a.res_bits && !a.bw_x && !a.mask_store && !g_sw.no_regw_fwdbn &&
             iif_regw1x1_fwdbn_ok(a.M, a.Cs, a.Cd)) {
@@ -1976,7 +1985,7 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
         }
         if (a.rx_src2) return IIF_EUNSUPPORTED;               // (no other kernel recomputes the upstream x)
     }
-    if (a.rx_src2) return IIF_EUNSUPPORTED;
+    if (a.rx_src2 || a.pro_stats) return IIF_EUNSUPPORTED;
     if (!utap) return (a.src2 || a.sbias || a.mask_store || a.no_store || a.aff) ? IIF_EUNSUPPORTED : launch_one<T, OUTF32>(a, false, src_bytes, wgt_bytes, st);
     if (!a.transposed || a.sshift == 0) {
         for (int r = 0; r < a.R; ++r)
@@ -2067,7 +2076,8 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
 
 namespace {
 struct ConvExtra { int mask_store; const void* src2; int cs2; const float* sbias; int no_store; const float* aff; unsigned char* relu_out; const float* aff2;
-                   const void* rx_src2; const void* rx_w3; int rx_k2, rx_ldw3; };
+                   const void* rx_src2; const void* rx_w3; int rx_k2, rx_ldw3;
+                   const float* pro_stats; void* pro_out; unsigned char* pro_bits; float* pro_csum; };
 int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                const unsigned char* res_bits, const float* bias, float* bn_partial, int64_t bn_partial_floats,
                int32_t* n_partials, void* stream, const void* bw_x = nullptr, const unsigned char* bw_bits = nullptr,
@@ -2116,7 +2126,7 @@ extern "C" int iif_conv_igemm_dgrad_masksum(const iif_conv_desc* d, const void* 
     if (!d || !up_bits || !partial || !n_partials || !d->transposed) return IIF_EINVAL;
     if (res_bits && !res) return IIF_EINVAL;
     if (up_x && !up_stats) return IIF_EINVAL;
-    const ConvExtra ex{1, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const ConvExtra ex{1, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr};
     return conv_entry(d, src, wgt, dst, res, res_bits, nullptr, partial, partial_floats, n_partials, stream, up_x, up_bits,
                       up_x ? up_stats : nullptr, &ex);
 }
@@ -2135,7 +2145,7 @@ extern "C" int iif_conv_igemm_dgrad_masksum_rx(const iif_conv_desc* d, const voi
     if (!d || !up_bits || !partial || !n_partials || !d->transposed || !up_a2 || !up_w3 || !up_stats) return IIF_EINVAL;
     if (res_bits && !res) return IIF_EINVAL;
     if (!iif_conv_dgrad_rx_ok(d, up_c2) || ((reinterpret_cast<uintptr_t>(up_a2) | reinterpret_cast<uintptr_t>(up_w3)) & 15)) return IIF_EUNSUPPORTED;
-    const ConvExtra ex{1, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, up_a2, up_w3, up_c2, up_ldw3};
+    const ConvExtra ex{1, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, up_a2, up_w3, up_c2, up_ldw3, nullptr, nullptr, nullptr, nullptr};
     return conv_entry(d, src, wgt, dst, res, res_bits, nullptr, partial, partial_floats, n_partials, stream, nullptr, up_bits, up_stats, &ex);
 }
 
@@ -2145,7 +2155,7 @@ extern "C" int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* s
                                            void* stream) {
     if (!d || !src2 || !d->transposed) return IIF_EINVAL;
     if (up_x && (!up_stats || !partial || !n_partials)) return IIF_EINVAL;
-    const ConvExtra ex{0, src2, cs2, bias, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const ConvExtra ex{0, src2, cs2, bias, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr};
     return conv_entry(d, src, wgt, dst, nullptr, nullptr, nullptr, up_x ? partial : nullptr, partial_floats, n_partials, stream, up_x,
                       up_bits, up_stats, &ex);
 }
@@ -2153,7 +2163,7 @@ extern "C" int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* s
 extern "C" int iif_conv_igemm_stats_only(const iif_conv_desc* d, const void* src, const void* wgt, float* bn_partial,
                                          int64_t bn_partial_floats, int32_t* n_partials, void* stream) {
     if (!d || !bn_partial || !n_partials || d->transposed) return IIF_EINVAL;
-    const ConvExtra ex{0, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const ConvExtra ex{0, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr};
     // dst is never written; the source pointer stands in for the non-null / alignment checks
     return conv_entry(d, src, wgt, const_cast<void*>(src), nullptr, nullptr, nullptr, bn_partial, bn_partial_floats, n_partials, stream,
                       nullptr, nullptr, nullptr, &ex);
@@ -2162,7 +2172,7 @@ extern "C" int iif_conv_igemm_stats_only(const iif_conv_desc* d, const void* src
 extern "C" int iif_conv_igemm_bn_relu(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                                       const float* stats, unsigned char* relu_bits, void* stream) {
     if (!d || !stats || d->transposed) return IIF_EINVAL;
-    const ConvExtra ex{0, nullptr, 0, nullptr, 0, stats, relu_bits, nullptr, nullptr, nullptr, 0, 0};
+    const ConvExtra ex{0, nullptr, 0, nullptr, 0, stats, relu_bits, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr};
     return conv_entry(d, src, wgt, dst, res, nullptr, nullptr, nullptr, 0, nullptr, stream, nullptr, nullptr, nullptr, &ex);
 }
 
@@ -2177,7 +2187,7 @@ extern "C" int iif_conv_igemm_stats_acc(const iif_conv_desc* d, const void* src,
                                         int64_t bn_partial_floats, int32_t* n_partials, void* stream) {
     if (!d || !bn_partial || !n_partials || d->transposed) return IIF_EINVAL;
     if (!iif_conv_fwdbn_ok(d)) return IIF_EUNSUPPORTED;
-    const ConvExtra ex{0, nullptr, 0, nullptr, 2, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const ConvExtra ex{0, nullptr, 0, nullptr, 2, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr};
     return conv_entry(d, src, wgt, const_cast<void*>(src), nullptr, nullptr, nullptr, bn_partial, bn_partial_floats, n_partials, stream,
                       nullptr, nullptr, nullptr, &ex);
 }
@@ -2186,8 +2196,26 @@ extern "C" int iif_conv_igemm_bn_relu2(const iif_conv_desc* d, const void* src, 
                                        const float* res_stats, const float* stats, unsigned char* relu_bits, void* stream) {
     if (!d || !stats || !relu_bits || d->transposed || (res_stats && !res)) return IIF_EINVAL;
     if (res_stats && !iif_conv_fwdbn_ok(d)) return IIF_EUNSUPPORTED;
-    const ConvExtra ex{0, nullptr, 0, nullptr, 0, stats, relu_bits, res_stats, nullptr, nullptr, 0, 0};
+    const ConvExtra ex{0, nullptr, 0, nullptr, 0, stats, relu_bits, res_stats, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr};
     return conv_entry(d, src, wgt, dst, res, nullptr, nullptr, nullptr, 0, nullptr, stream, nullptr, nullptr, nullptr, &ex);
+}
+
+extern "C" int iif_conv_pro_ok(const iif_conv_desc* d, int stats_only) {
+    if (!d || g_sw.no_regw || g_sw.regstage) return 0;
+    if (d->dtype != IIF_BF16 || d->dst_dtype != IIF_BF16 || d->r != 1 || d->s != 1 || d->stride != 1 || d->pad != 0 || d->groups > 1 || d->transposed) return 0;
+    if (d->hs != d->hd || d->ws != d->wd) return 0;
+    const int M = d->n * d->hd * d->wd;
+    return (stats_only ? (!g_sw.no_regw_fwdbn && iif_regw1x1_fwdbn_ok(M, d->cs, d->cd)) : iif_regw1x1_pro_ok(M, d->cs, d->cd)) ? 1 : 0;
+}
+
+extern "C" int iif_conv_igemm_bnstats_pro(const iif_conv_desc* d, const void* src_raw, const float* src_stats, void* act_out,
+                                          unsigned char* act_bits, float* act_csum, const void* wgt, void* dst /* NULL: statistics only */,
+                                          float* bn_partial, int64_t bn_partial_floats, int32_t* n_partials, void* stream) {
+    if (!d || !src_raw || !src_stats || !act_out || !act_bits || !bn_partial || !n_partials || d->transposed) return IIF_EINVAL;
+    if (!iif_conv_pro_ok(d, dst == nullptr) || ((reinterpret_cast<uintptr_t>(act_out)) & 15)) return IIF_EUNSUPPORTED;
+    const ConvExtra ex{0, nullptr, 0, nullptr, dst ? 0 : 2, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, src_stats, act_out, act_bits, act_csum};
+    return conv_entry(d, src_raw, wgt, dst ? dst : const_cast<void*>(src_raw), nullptr, nullptr, nullptr, bn_partial, bn_partial_floats, n_partials,
+                      stream, nullptr, nullptr, nullptr, &ex);
 }
 
 extern "C" int iif_conv_igemm_bnstats(const iif_conv_desc* d, const void* src, const void* wgt, void* dst,
@@ -2224,7 +2252,7 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
     if (d->dst_dtype != d->dtype && d->dst_dtype != IIF_F32) return IIF_EINVAL;
     const int pe = d->dtype == IIF_F32 ? 4 : 8;
     if (d->cs % pe != 0 || d->ldw % pe != 0 || d->ldw < d->r * d->s * d->cs + (ex && ex->src2 ? ex->cs2 : 0)) return IIF_EUNSUPPORTED;
-    if (ex && (ex->src2 || ex->sbias || ex->mask_store || ex->no_store || ex->aff)) {
+    if (ex && (ex->src2 || ex->sbias || ex->mask_store || ex->no_store || ex->aff || ex->pro_stats)) {
         // round-3 epilogue / operand options: bf16 1x1 stride-1 launches on the LDS-staged epilogue only
         if (d->dtype != IIF_BF16 || d->dst_dtype != IIF_BF16 || d->r != 1 || d->s != 1 || d->stride != 1 || d->pad != 0 || d->groups > 1 ||
             (d->cd % 8) || bias || (d->cs % 32))
@@ -2264,6 +2292,7 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
         a.mask_store = ex->mask_store; a.src2 = (const unsigned char*)ex->src2; a.Cs2 = ex->cs2; a.sbias = ex->sbias;
         a.no_store = ex->no_store; a.aff = ex->aff; a.relu_out = ex->relu_out; a.aff2 = ex->aff2;
         a.rx_src2 = (const unsigned char*)ex->rx_src2; a.rx_w3 = (const unsigned char*)ex->rx_w3; a.rx_k2 = ex->rx_k2; a.rx_ldw3 = ex->rx_ldw3;
+        a.pro_stats = ex->pro_stats; a.pro_out = (unsigned char*)ex->pro_out; a.pro_bits = ex->pro_bits; a.pro_csum = ex->pro_csum;
     }
     a.N = d->n; a.Hs = d->hs; a.Ws = d->ws; a.Cs = d->cs; a.Hd = d->hd; a.Wd = d->wd; a.Cd = d->cd;
     a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.transposed = d->transposed ? 1 : 0;

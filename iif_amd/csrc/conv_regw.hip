@@ -31,6 +31,11 @@ struct RegwArgs {
     // is RECOMPUTED per tile instead of read: x = src2 (that block's a2, [M, KK2]) times w3^T (its conv3 weights as the forward
     // multiplied them, [Cd, ldw3] bf16), rounded to bf16 as the stored tensor would have been.  The upstream output need not exist.
     const unsigned char* src2; const unsigned char* w3; int spitch2, ldw3; unsigned src2_bytes;
+    // PRO (round 6): `src` is the RAW output of the previous convolution; its batch norm + ReLU (pro_stats: a at [2 K + c], b at
+    // [3 K + c], bn_apply_kernel's arithmetic) is applied to the tile in LDS before the MFMA phase, and the activated tile is written
+    // out as a by-product (pro_out [M, K] bf16, pro_bits one byte per 16-byte vector) by slice 0: the bn_apply launch and one
+    // pass over the activation disappear.  pro_csum (nullable): per sequence one row [2][K] (column sums of the activated tiles, zeros).
+    const float* pro_stats; unsigned char* pro_out; unsigned char* pro_bits; float* pro_csum;
 };
 
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 2; }      // as conv_igemm.hip's swz: 64-byte LDS rows
@@ -42,9 +47,11 @@ __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 2; }      //
 // EPI 0: plain forward (+ sums of the stored tile); 1: the data-gradient epilogue; 2: the forward BN epilogue (pass 2 of the
 // two-pass forward); 3: statistics only, taken from the ACCUMULATORS (pass 1: no staging, no store; sums of the unrounded tile);
 // 4: EPI 1 with the upstream x recomputed from (src2, w3) over KK2 channels
-template <int KK, int CW, int MT, int EPI, int KK2 = 0>
+template <int KK, int CW, int MT, int EPI, int KK2 = 0, bool PRO = false>
 __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsigned src_bytes) {
     constexpr bool RX = EPI == 4, DG = EPI == 1 || EPI == 4;
+    constexpr int VPR = KK / 8, NPV = PRO ? MT * VPR / 512 : 0;         // PRO: vectors per row of the tile, vectors per thread
+    static_assert(!PRO || ((MT * VPR) % 512 == 0 && 512 % VPR == 0 && (EPI == 0 || EPI == 3)), "prologue shape");
     constexpr int NK2 = RX ? KK2 / 32 : 1, TILE2 = RX ? NK2 * MT * 64 : 0, NAP2 = RX ? NK2 * (MT / 16) / 8 : 0;
     static_assert(!RX || (KK2 >= 64 && (NK2 * (MT / 16)) % 8 == 0), "second source");
     constexpr int NK = KK / 32, CB = CW / 16, RB = MT / 16;
@@ -196,6 +203,16 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
 #pragma unroll
     for (int cb = 0; cb < (EPI == 3 ? CB : 1); ++cb) { as[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; aq[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     unsigned char* const stg = smem + 2 * TILE + wave * STG;
+    // PRO: this thread's vectors of a tile: vector tid + 512 i = row (tid + 512 i) / VPR, channel vector tid % VPR (the same for every
+    // i: VPR divides 512), i.e. K step pcv / 4, chunk pcv % 4 of the row's 64-byte slab line
+    const int pcv = PRO ? tid % VPR : 0, prow0 = PRO ? tid / VPR : 0;
+    float pa[8], pb[8], pcs[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { pa[q] = 0.f; pb[q] = 0.f; pcs[q] = 0.f; }
+    if constexpr (PRO) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { pa[q] = a.pro_stats[2 * KK + pcv * 8 + q]; pb[q] = a.pro_stats[3 * KK + pcv * 8 + q]; }
+    }
     int buf = 0;
     // The first tile (and everything the prologue asked for) has landed; inside the loop the wait for the NEXT tile sits at the
     // bottom of the body, behind the stores it counts over (round 6: at the top behind a `first` flag before - two paths into the
@@ -204,6 +221,34 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
     for (; tile < a.mtiles; tile += G, buf ^= 1) {
         __builtin_amdgcn_s_barrier();
         if (tile + G < a.mtiles) { issue_tile(tile + G, buf ^ 1); issue_tile2(tile + G, buf ^ 1); load_ops(tile + G, n_res, n_x, n_rb, n_mb); }
+        if constexpr (PRO) {
+            // normalise + ReLU the raw tile in place (every slice block does, for its own MFMAs), slice 0 writes the activation out
+            unsigned char* Aw = smem + buf * TILE;
+#pragma unroll
+            for (int i = 0; i < NPV; ++i) {
+                const int row = prow0 + (512 / VPR) * i;
+                unsigned char* lp = Aw + (pcv >> 2) * SLAB + row * 64 + (((pcv & 3) ^ swz64(row)) << 4);
+                u32x4 v = *reinterpret_cast<const u32x4*>(lp);
+                unsigned bits = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = fmaf(pa[2 * q], bf16_bits_to_f32(v[q] & 0xffffu), pb[2 * q]);
+                    const float hi = fmaf(pa[2 * q + 1], __uint_as_float(v[q] & 0xffff0000u), pb[2 * q + 1]);
+                    bits |= (lo > 0.f ? 1u : 0u) << (2 * q);
+                    bits |= (hi > 0.f ? 1u : 0u) << (2 * q + 1);
+                    v[q] = pack_bf16x2(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
+                    pcs[2 * q] += bf16_bits_to_f32(v[q] & 0xffffu); pcs[2 * q + 1] += __uint_as_float(v[q] & 0xffff0000u);
+                }
+                *reinterpret_cast<u32x4*>(lp) = v;
+                if (slice == 0) {
+                    const size_t o = ((size_t)(tile * MT + row) * KK + pcv * 8) * 2;
+                    *reinterpret_cast<u32x4*>(a.pro_out + o) = v;
+                    a.pro_bits[o >> 4] = (unsigned char)bits;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // the tile is the activation for every wave
+        }
         const unsigned char* Ab = smem + buf * TILE;
         f32x4 acc[CB][RB];
 #pragma unroll
@@ -230,7 +275,9 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { as[cb][j] += acc[cb][rb][j]; aq[cb][j] = fmaf(acc[cb][rb][j], acc[cb][rb][j], aq[cb][j]); }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next tile (nothing else is in flight)
+            // the next tile (behind it only the prologue's stores of slice 0, which may stay in flight)
+            if (PRO && slice == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPV) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             continue;
         }
 #pragma unroll
@@ -381,8 +428,26 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
         }
         // the next tile's DMA pieces (and epilogue operands) of THIS wave have landed; this tile's stores may stay in flight
         if (EPI == 0 && a.no_store) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no stores behind the DMA to count over)
+        else if (PRO && slice == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + 2 * NPV) : "memory");
         else if (EPI == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST) : "memory");     // NST vectors + NST bit bytes
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    }
+    if constexpr (PRO) {
+        if (a.pro_csum != nullptr && slice == 0 && seq < G) {
+            // threads tid, tid + VPR, ... hold the same channel vector: fixed-order sum through LDS (the tile buffers are free now)
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) red[tid * 8 + q] = pcs[q];
+            __syncthreads();
+            if (tid < KK) {
+                const int cv = tid >> 3, q = tid & 7;
+                float s = 0.f;
+                for (int t = cv; t < 512; t += VPR) s += red[t * 8 + q];
+                a.pro_csum[(size_t)seq * 2 * KK + tid] = s;                 // rows laid out like BN partial rows: (sums, zeros)
+                a.pro_csum[(size_t)seq * 2 * KK + KK + tid] = 0.f;
+            }
+        }
     }
     if (a.bn_partial == nullptr || seq >= G) return;
     if constexpr (EPI == 3) {
@@ -427,7 +492,8 @@ static bool regw_plan(int K, int N, bool epi, int* cw, int* mt) {
     if (K == 512 && N == 2048 && !epi) { *cw = 16; *mt = 64; return true; }       // (with epilogue operands: 77 against 69 us)
     // (the wide -> narrow shapes are level with the tile kernels alone, 59.3 / 60.1 and 43.1 / 42.8 us, and level to +0.05 ms in the step)
     // ResNeXt's conv3 (width -> 2 x width; resnet_pytorch.py:141-143 with groups 32, base width 4): the same kernels, fewer slices
-    if (!getenv("IIF_REGW_NO_X2")) {
+    static const bool no_x2 = getenv("IIF_REGW_NO_X2") != nullptr;      // read once, like every other switch
+    if (!no_x2) {
         if (K == 128 && N == 256) { *cw = 32; *mt = 64; return true; }
         if (K == 256 && N == 512) { *cw = 32; *mt = 64; return true; }
         if (K == 512 && N == 1024 && !epi) { *cw = 16; *mt = 64; return true; }
@@ -451,12 +517,20 @@ bool iif_regw1x1_ok(int M, int K, int N, int epi) {
     return M % mt == 0;
 }
 
+// the plain forward instances that exist with the BN + ReLU prologue (conv3 of the blocks that store its output: 14 x 14, 7 x 7)
+bool iif_regw1x1_pro_ok(int M, int K, int N) {
+    int cw = 0, mt = 0;
+    if (!iif_regw1x1_ok(M, K, N, 0) || !regw_plan(K, N, false, &cw, &mt)) return false;
+    return M >= 1024 && ((K == 256 && cw == 32) || (K == 512 && cw == 16)) && mt == 64;
+}
+
 int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
-                       int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, int no_store, hipStream_t st) {
+                       int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, int no_store, hipStream_t st,
+                       const iif_regw_prologue* pro) {
     const bool epi = e != nullptr;
     if (epi && no_store) return IIF_EUNSUPPORTED;
+    if (pro && (epi || no_store || !bn_partial || spitch != K || !pro->stats || !pro->out || !pro->bits || !iif_regw1x1_pro_ok(M, K, N))) return IIF_EUNSUPPORTED;
     if (!src || !wgt || !dst || !iif_regw1x1_ok(M, K, N, epi)) return IIF_EUNSUPPORTED;
-    const int cus = iif_persistent_cus();
     int cw = 0, mt = 0;
     regw_plan(K, N, epi, &cw, &mt);
     const int S = N / (8 * cw);
@@ -474,8 +548,9 @@ int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_pa
             a.src2_bytes = (unsigned)((int64_t)M * k2 * 2);
         }
     }
+    if (pro) { a.pro_stats = pro->stats; a.pro_out = (unsigned char*)pro->out; a.pro_bits = pro->bits; a.pro_csum = pro->csum; }
     const int unit = 8 * S;
-    int grid = cus / unit * unit;
+    int grid = iif_persistent_grid(unit);
     const int need = (a.mtiles + 7) / 8 * unit;
     if (need < grid) grid = need;
     // one partial row per tile sequence, never more rows than the tile kernels write (ceil(M / 128): what callers size for)
@@ -501,6 +576,9 @@ int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_pa
         if (K == 64) IIF_REGW(64, 32, 64, 1);
         else if (K == 128) IIF_REGW(128, 32, 64, 1);
         else IIF_REGW(256, 32, 64, 1);
+    } else if (pro) {
+        if (K == 256) hipLaunchKernelGGL((gemm1x1_regw_kernel<256, 32, 64, 0, 0, true>), g, b, 0, st, a, sb);
+        else hipLaunchKernelGGL((gemm1x1_regw_kernel<512, 16, 64, 0, 0, true>), g, b, 0, st, a, sb);
     } else {
         if (K == 128 && cw == 64) IIF_REGW(128, 64, 64, 0);
         else if (K == 128) IIF_REGW(128, 32, 64, 0);
@@ -523,16 +601,17 @@ bool iif_regw1x1_fwdbn_ok(int M, int K, int N) {
 // mode 2: forward BN epilogue; mode 3: statistics from the accumulators (dst / res / aff unused)
 static int regw_launch2(int mode, const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
                         int M, int K, int N, int spitch, int ldw, int dpitch, const void* res, const float* aff, const float* aff2,
-                        unsigned char* relu_out, hipStream_t st) {
+                        unsigned char* relu_out, hipStream_t st, const iif_regw_prologue* pro = nullptr) {
     if (!src || !wgt || !iif_regw1x1_fwdbn_ok(M, K, N) || spitch != K || dpitch != N) return IIF_EUNSUPPORTED;
+    if (pro && (mode != 3 || !pro->stats || !pro->out || !pro->bits)) return IIF_EINVAL;
     if (mode == 2 && (!dst || !aff || !relu_out || (aff2 && !res))) return IIF_EINVAL;
     if (mode == 3 && !bn_partial) return IIF_EINVAL;
-    const int cus = iif_persistent_cus();
     const int S = N / 256;
     RegwArgs a{(const unsigned char*)src, (const unsigned char*)wgt, (unsigned char*)dst, bn_partial, M, M / 64, spitch, ldw, N, dpitch,
                bn_row0, S, (const unsigned char*)res, nullptr, nullptr, nullptr, nullptr, 0, 0, aff, aff2, relu_out};
+    if (pro) { a.pro_stats = pro->stats; a.pro_out = (unsigned char*)pro->out; a.pro_bits = pro->bits; a.pro_csum = pro->csum; }
     const int unit = 8 * S;
-    int grid = cus / unit * unit;
+    int grid = iif_persistent_grid(unit);
     const int need = (a.mtiles + 7) / 8 * unit;
     if (need < grid) grid = need;
     const int rows128 = (M + 127) / 128;
@@ -549,6 +628,10 @@ static int regw_launch2(int mode, const void* src, const void* wgt, void* dst, f
         if (K == 64) IIF_REGW(64, 32, 64, 2);
         else if (K == 128) IIF_REGW(128, 32, 64, 2);
         else IIF_REGW(256, 32, 64, 2);
+    } else if (pro) {
+        if (K == 64) hipLaunchKernelGGL((gemm1x1_regw_kernel<64, 32, 64, 3, 0, true>), g, b, 0, st, a, sb);
+        else if (K == 128) hipLaunchKernelGGL((gemm1x1_regw_kernel<128, 32, 64, 3, 0, true>), g, b, 0, st, a, sb);
+        else hipLaunchKernelGGL((gemm1x1_regw_kernel<256, 32, 64, 3, 0, true>), g, b, 0, st, a, sb);
     } else {
         if (K == 64) IIF_REGW(64, 32, 64, 3);
         else if (K == 128) IIF_REGW(128, 32, 64, 3);
@@ -565,9 +648,9 @@ int iif_regw1x1_fwdbn_launch(const void* src, const void* wgt, void* dst, int M,
 }
 
 int iif_regw1x1_stats_launch(const void* src, const void* wgt, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
-                             int M, int K, int N, int spitch, int ldw, int dpitch, hipStream_t st) {
+                             int M, int K, int N, int spitch, int ldw, int dpitch, hipStream_t st, const iif_regw_prologue* pro) {
     return regw_launch2(3, src, wgt, nullptr, bn_partial, bn_cap, bn_row0, rows_out, M, K, N, spitch, ldw, dpitch, nullptr, nullptr, nullptr,
-                        nullptr, st);
+                        nullptr, st, pro);
 }
 
 // =====================================================================================================================

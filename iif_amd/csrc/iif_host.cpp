@@ -29,6 +29,17 @@ int iif_persistent_cus() {
     return (b > 0 && b < n) ? b : n;
 }
 
+// Blocks of a persistent grid launched in whole units (8 * S blocks: the S slices of eight tile sequences, one per XCD).  Under a
+// CU budget the grid is the largest whole-unit count within the budget - unless that rounding would give up more CUs than the
+// reservation itself asked for (budget 240 and units of 64 or 128: 192 / 128 blocks, a 25-50 % smaller grid for a 6 % reservation):
+// such launches keep the device's whole-unit grid (round-5 advice).
+int iif_persistent_grid(int unit) {
+    const int n = device_cus(), b = iif_persistent_cus();
+    if (unit <= 0) return b;
+    const int g = b / unit * unit, full = n / unit * unit;
+    return (full - g > n - b) ? full : g;
+}
+
 extern "C" int iif_set_cu_budget(int cus) {
     if (cus < 0) return IIF_EINVAL;
     // whole groups of 8 (one block per XCD and group), at least 64: below that the persistent kernels refuse small layers

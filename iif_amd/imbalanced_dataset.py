@@ -196,10 +196,15 @@ class TensorTransform(object):
                 self.colour = augment.RandAugment()
             elif auto_augment in ("cifar", "cifar10"):
                 self.colour = augment.AutoAugmentPolicy("cifar10")
-            elif auto_augment not in (None, "", "None"):
-                raise ValueError("--auto-augment %r: the reference knows imagenet, randaugment and cifar" % (auto_augment,))
-            elif color_jitter:
-                self.colour = augment.ColorJitter(0.4, 0.4, 0.4, 0.25 if inat else 0.0)
+            else:
+                if auto_augment not in (None, "", "None"):
+                    # classification/imbalanced_dataset.py:210-225 knows 'imagenet' and 'randaugment' for the list datasets and keeps
+                    # its ColorJitter for every other value, silently; so does this, with a warning
+                    import warnings
+                    warnings.warn("--auto-augment %r is not a policy of the list datasets (imagenet / randaugment / cifar): "
+                                  "ColorJitter stays, as in the reference" % (auto_augment,))
+                if color_jitter:
+                    self.colour = augment.ColorJitter(0.4, 0.4, 0.4, 0.25 if inat else 0.0)
         self.mean = torch.tensor([0.466, 0.471, 0.380] if inat else [0.485, 0.456, 0.406]).view(3, 1, 1)
         self.std = torch.tensor([0.195, 0.194, 0.192] if inat else [0.229, 0.224, 0.225]).view(3, 1, 1)
         self.train, self.size = train, size

@@ -495,6 +495,28 @@ def conv_fwdbn_ok(n, h, w, cin, cout, dtype):
     return bool(lib().iif_conv_fwdbn_ok(ctypes.byref(d)))
 
 
+def conv_pro_ok(n, h, w, cin, cout, dtype, stats_only):
+    """Whether the register-weight kernel takes this 1x1 layer with the previous unit's BN + ReLU in its operand path."""
+    if dtype != torch.bfloat16:
+        return False
+    d = _desc(n, h, w, cin, h, w, cout, 1, 1, 1, 0, 0, cin, _lib.IIF_BF16, _lib.IIF_BF16, 1)
+    return bool(lib().iif_conv_pro_ok(ctypes.byref(d), 1 if stats_only else 0))
+
+
+def conv_forward_bnstats_pro(x_raw, x_stats, act_out, act_bits, w, out, partial, act_csum=None):
+    """1x1 forward (out None: statistics only, from the accumulators) of relu(bn(x_raw)); the activation and its ReLU bits are
+    written to act_out / act_bits on the way (and its column-sum rows to act_csum); returns the partial row count."""
+    require_gpu(x_raw, x_stats, act_out, act_bits, w, out, partial, act_csum)
+    n, h, w_, cin = x_raw.shape
+    cout, ldw = w.shape
+    d = _desc(n, h, w_, cin, h, w_, cout, 1, 1, 1, 0, 0, ldw, dtype_code(x_raw), dtype_code(x_raw), 1)
+    nt = ctypes.c_int32(0)
+    check(lib().iif_conv_igemm_bnstats_pro(ctypes.byref(d), ptr(x_raw), ptr(x_stats), ptr(act_out), ptr(act_bits), ptr(act_csum), ptr(w),
+                                           ptr(out), ptr(partial), partial.numel(), ctypes.byref(nt), stream_ptr()),
+          "iif_conv_igemm_bnstats_pro")
+    return nt.value
+
+
 def conv_forward_stats_acc(x, w, partial):
     """Pass 1 on the register-weight kernel: partial rows of (sum, sum of squares) of the unrounded accumulators; no output."""
     require_gpu(x, w, partial)

@@ -427,11 +427,32 @@ class NativeResNet(nn.Module):
     def run_forward(self, x, training):
         """Native forward.  Returns fp32 logits [N, num_classes] — a VIEW of the plan's buffer, valid until the next
         forward of the same shape (``loss_and_backward`` consumes it in place; ``forward`` clones it)."""
+        self._join_side_work()
         plan = self._plan(x.shape[0], x.shape[2], x.shape[3])
         plan.forward(x, training)
+        if training and not torch.is_grad_enabled():
+            self._join_side_work()          # no backward will follow (BN recalibration under no_grad): nothing stays un-joined
         plan.generation += 1
         self._saved = plan if training else None
         return plan.logits[:, :self.num_classes]
+
+    def _join_side_work(self):
+        """A training-mode forward leaves the transposed weight copies of its step in flight on the weight-gradient stream (backward
+        waits for them).  If no backward follows, whoever next touches the master arena or the BN buffers on the compute stream -
+        sgd_step, another forward, state_dict / load_state_dict, a graph capture's end - joins that work first (round-5 advice)."""
+        for plan in self._plans.values():
+            ev = getattr(plan, "_prep_bwd_done", None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+                plan._prep_bwd_done = None
+
+    def state_dict(self, *args, **kwargs):
+        self._join_side_work()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._join_side_work()
+        return super().load_state_dict(*args, **kwargs)
 
     def run_backward(self, dlogits=None, reducer=None, generation=None):
         """Native backward from d(loss)/d(logits); fills the gradient arena.
@@ -455,6 +476,7 @@ class NativeResNet(nn.Module):
         """ONE launch over the whole parameter arena (classification/train.py:199-204,78); with a
         frozen backbone only the classifier's slice (the tail of the arena) is stepped, as
         torch.optim.SGD skips parameters without gradients."""
+        self._join_side_work()
         lo = self.block_offsets()["head"] if self._head_only else 0
         ops.sgd_step(self._arena[lo:], self._grad_arena[lo:], self._mom_arena[lo:], lr, momentum, weight_decay, nesterov,
                      grad_scale)
@@ -820,6 +842,23 @@ class _Plan(object):
                 if (u3 in self.alg3_units and (self._a3_is_pure(u3) or u3 in self.rx_units) and u3 not in self.twopass_units
                         and ops.conv_fwdbn_ok(u3.n, u3.ho, u3.wo, u3.conv.cin, u3.conv.cout, dt) and _dma_ok(u3.src)):
                     self.nostore_units.add(u3)
+        # bn2 + ReLU in conv3's operand path (round 6, iif_conv_igemm_bnstats_pro): conv3 (or its statistics pass) reads conv2's RAW
+        # output, normalises each tile in LDS and writes a2 / its ReLU bits / its column sums as by-products: one launch and one pass
+        # over a2 less per bottleneck.  pro_units: conv3 unit -> (conv2 unit, rows of column sums or None).  IIF_NO_PROLOGUE=1: off.
+        self.pro_units = {}
+        if dt == torch.bfloat16 and net._sync_bn is None and not os.environ.get("IIF_NO_PROLOGUE"):
+            for b in self.blocks:
+                if "se" in b or len(b["units"]) != 3:
+                    continue
+                u2, u3 = b["units"][1], b["units"][2]
+                cv3 = u3.conv
+                if not (cv3.k == 1 and cv3.stride == 1 and cv3.groups == 1 and _dma_ok(u2.x)) or u3 in self.twopass_units:
+                    continue
+                if ops.conv_pro_ok(u3.n, u3.ho, u3.wo, cv3.cin, cv3.cout, dt, u3 in self.nostore_units):
+                    rows = None
+                    if u3 in self.alg3_units:
+                        rows = torch.zeros(((u3.n * u3.ho * u3.wo + 127) // 128 + 8) * 2 * cv3.cin, dtype=torch.float32, device=dev)
+                    self.pro_units[u3] = [u2, rows, 0, u3 in self.nostore_units]      # (.., partial rows of the last forward, instance kind)
         self.a3 = None
         if self.alg3_units:
             cm = max(u.conv.cin for u in self.alg3_units)
@@ -836,7 +875,7 @@ class _Plan(object):
                         "tickets": torch.zeros(64, dtype=torch.int32, device=dev)}
                        for _ in range(self.wg_lag)]
             self.a3g = [{"gram": F(cm, ldm), "csum": F(2, cm), "ws_gram": torch.empty(64 << 20, dtype=torch.uint8, device=dev),
-                         "ws_sum": ops.bn_workspace(max(u.n * u.ho * u.wo for u in self.alg3_units), cm, dev), "ev": None}
+                         "ws_sum": ops.bn_workspace(max(u.n * u.ho * u.wo for u in self.alg3_units), cm, dev), "ev": None, "ev_csum": None}
                         for _ in range(self.wg_lag + 1)]
             self.a3_ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)          # split-K slabs of P on the compute stream
         wmax = max(max(u.conv.cout * (u.dwp.shape[1] if u.dwp is not None else u.conv.ldw) for u in self.units),
@@ -1110,7 +1149,7 @@ class _Plan(object):
                               u.stats, BN_EPS, BN_MOMENTUM)
 
     # ---------------------------------------------------------------- forward
-    def _conv_bn(self, u, training, side=False):
+    def _conv_bn(self, u, training, side=False, pro=None):
         cv = u.conv
         k, st, pd = u.geom
         m = u.n * u.ho * u.wo
@@ -1119,7 +1158,12 @@ class _Plan(object):
         if training and self.dt == torch.bfloat16 and cv.cout % 8 == 0 and _dma_ok(u.src):
             # statistics come out of the convolution's epilogue: no extra pass over x
             partial, scratch = (self.bn_partial_side, self.bn_scratch_side) if side else (self.bn_partial, self.bn_scratch)
-            nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, partial, groups=u.groups, w_frag=u.wf)
+            if pro is not None:              # the previous unit's BN + ReLU in this launch's operand path (pro_units)
+                u2 = pro[0]
+                nt = ops.conv_forward_bnstats_pro(u2.x, u2.stats, u2.y, u2.bits, u.w, u.x, partial, act_csum=pro[1])
+                pro[2] = nt
+            else:
+                nt = ops.conv_forward_bnstats(u.src, u.w, k, k, st, pd, u.x, partial, groups=u.groups, w_frag=u.wf)
             if sync is not None:
                 self._sync_finalize(u, ops.bn_partial_sums(partial, nt, cv.cout, self._sync_sums(cv.cout, side)), m, sync)
                 return x2
@@ -1198,14 +1242,27 @@ class _Plan(object):
                     self._conv_bn(b["ds"], training, side=True)
                     ds_done = torch.cuda.Event()
                     ds_done.record()
+            last = units[-1]
+            nostore = training and last in self.nostore_units and last in self.alg3_units and self.fuse_bwd
+            pro = self.pro_units.get(last) if (training and self.fuse_bwd) else None
+            if pro is not None and pro[3] != nostore:
+                pro = None                                   # (the instance was chosen for the other route: tests switch routes on a live plan)
+            if last in self.pro_units and pro is None:
+                self.pro_units[last][2] = 0                  # no column-sum rows from this forward
             for uu in units[:-1]:
                 x2 = self._conv_bn(uu, training)
+                if pro is not None and uu is pro[0]:
+                    continue                                 # its normalisation happens in conv3's operand path
                 ops.bn_apply(x2, uu.stats, uu.y.view(x2.shape), relu=True, relu_bits=uu.bits)
-            last = units[-1]
-            if training and last in self.nostore_units and last in self.alg3_units and self.fuse_bwd:
+            if nostore:
                 cv = last.conv
                 m = last.n * last.ho * last.wo
-                nt = ops.conv_forward_stats_acc(last.src, last.w, self.bn_partial)
+                if pro is not None:
+                    u2 = pro[0]
+                    nt = ops.conv_forward_bnstats_pro(u2.x, u2.stats, u2.y, u2.bits, last.w, None, self.bn_partial, act_csum=pro[1])
+                    pro[2] = nt
+                else:
+                    nt = ops.conv_forward_stats_acc(last.src, last.w, self.bn_partial)
                 ops.bn_finalize_stats(self.bn_partial, nt, m, cv.cout, last.bn.weight, last.bn.bias, last.bn.running_mean,
                                       last.bn.running_var, last.stats, BN_EPS, BN_MOMENTUM, scratch=self.bn_scratch,
                                       tickets=self.bn_tickets)
@@ -1228,7 +1285,7 @@ class _Plan(object):
                                       tickets=self.bn_tickets)
                 ops.conv_forward_bn_relu(last.src, last.w, last.y, last.stats, res=b["inp"], relu_bits=last.bits)
                 continue
-            x2 = self._conv_bn(last, training)
+            x2 = self._conv_bn(last, training, pro=pro)
             if "se" in b:
                 self._se_forward(b, last, training)
                 continue
@@ -1491,21 +1548,34 @@ class _Plan(object):
         cv = u.conv
         a2 = u.src
 
-        def work():
+        def csum():
+            pro = self.pro_units.get(u) if self.fuse_bwd else None
+            if pro is not None and pro[1] is not None and pro[2] > 0:
+                # the forward pass left the column sums of a2 as partial rows (bn2's prologue in conv3's launch): a [rows, c] reduction
+                # instead of a pass over the tensor
+                ops.bn_partial_sums(pro[1], pro[2], cv.cin, A["csum"].view(-1)[:2 * cv.cin].view(2, cv.cin))
+                return
+            ops.bn_stats_sums(a2.view(-1, cv.cin), A["csum"].view(-1)[:2 * cv.cin].view(2, cv.cin), A["ws_sum"])
+
+        def gram():
             if not self._a3_gram_stacked(u):
                 ops.conv_wgrad(a2, a2, 1, 1, 1, 0, ldw=cv.ldw, out=A["gram"].view(-1)[:cv.cin * cv.ldw].view(cv.cin, cv.ldw),
                                workspace=A["ws_gram"])
-            ops.bn_stats_sums(a2.view(-1, cv.cin), A["csum"].view(-1)[:2 * cv.cin].view(2, cv.cin), A["ws_sum"])
         st = self.ds_stream if self.ds_stream is not None else self.wg_stream
         if st is None:
-            work()
-            A["ev"] = None
+            csum(); gram()
+            A["ev"] = A["ev_csum"] = None
             return
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(st):
             st.wait_event(ev)
-            work()
+            # the column sums first, with an event of their own: they are all the compute stream's bn3_algebra_prep needs; the Gram
+            # matrix (and its slab reduction) only feeds the weight gradient on the weight-gradient stream (round-5 advice)
+            csum()
+            A["ev_csum"] = torch.cuda.Event()
+            A["ev_csum"].record()
+            gram()
             done = torch.cuda.Event()
             done.record()
         A["ev"] = done
@@ -1528,8 +1598,8 @@ class _Plan(object):
         # colsum(a2) (issued a block ahead with the Gram matrix) keeps the data gradient's column sums at zero through the bf16
         # rounding of the stacked weights (bn3_gm_finish_kernel); the weight gradient needs Gram / colsum too, off the critical path
         gram_ev = Ag["ev"]
-        if gram_ev is not None:
-            torch.cuda.current_stream().wait_event(gram_ev)
+        if Ag.get("ev_csum") is not None:
+            torch.cuda.current_stream().wait_event(Ag["ev_csum"])
         ops.bn3_algebra_prep(P if pure else None, wb, c, rows, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt,
                              A["bias"][:c], A["scr"], A["tickets"], colsum2=Ag["csum"].view(-1)[:c])
 

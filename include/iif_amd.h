@@ -462,6 +462,18 @@ int iif_conv_igemm_dgrad_masksum(const iif_conv_desc* d, const void* src, const 
                                  const unsigned char* res_bits, const void* up_x, const unsigned char* up_bits,
                                  const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,
                                  void* stream);
+/* Round 6: the batch norm + ReLU of the PREVIOUS unit applied in the convolution's operand path (resnet_pytorch.py:157-160:
+ * bn2 -> relu -> conv3).  src_raw is that unit's raw convolution output [n, h, w, cs] and src_stats its statistics as
+ * iif_bn_finalize_stats wrote them; each tile is normalised in LDS (iif_bn_apply's arithmetic) before the matrix pipe reads
+ * it, and the activated tensor is written out as a by-product - act_out [n, h, w, cs] bf16 and act_bits (one byte per 8
+ * channels), bit-identical to iif_bn_apply's - because backward needs it; act_csum (nullable) receives per partial row one
+ * row [2][cs] = (its column sums, zeros), the layout iif_bn_partial_sums reduces.  dst NULL: the statistics-only pass of iif_conv_igemm_stats_acc; otherwise the stored forward
+ * with statistics of iif_conv_igemm_bnstats.  One launch and one pass over the activation less per bottleneck.
+ * iif_conv_pro_ok(d, stats_only) says whether the register-weight kernel has the instance. */
+int iif_conv_pro_ok(const iif_conv_desc* d, int stats_only);
+int iif_conv_igemm_bnstats_pro(const iif_conv_desc* d, const void* src_raw, const float* src_stats, void* act_out,
+                               unsigned char* act_bits, float* act_csum, const void* wgt, void* dst, float* bn_partial,
+                               int64_t bn_partial_floats, int32_t* n_partials, void* stream);
 /* Round 6: iif_conv_igemm_dgrad_masksum whose (sum dst, sum dst * xhat) rows are formed WITHOUT the upstream block's conv3 output:
  * each tile of it is recomputed on the matrix pipe from that block's a2 (up_a2, [n*h*w, up_c2] bf16) and conv3 weights as the
  * forward multiplied them (up_w3, [cd, up_ldw3] bf16), rounded to bf16 as the stored tensor would have been.  Together with

@@ -975,6 +975,53 @@ def test_never_stored_forward_on_the_register_weight_kernel(case):
         assert torch.equal(a_two, a_ref) and torch.equal(bits_two, bits_ref)
 
 
+@pytest.mark.parametrize("case", [(4, 16, 64, 256), (2, 32, 128, 512), (4, 16, 256, 1024), (16, 56, 64, 256), (8, 14, 256, 1024),
+                                  (32, 7, 512, 2048)], ids=lambda c: "%dx%dx%d_%d_%d" % (c[0], c[1], c[1], c[2], c[3]))
+def test_bn_relu_prologue_in_the_convolution_operand_path(case):
+    """Round 6: iif_conv_igemm_bnstats_pro (previous unit's BN + ReLU applied to each tile in LDS, activation written as a
+    by-product) against iif_bn_apply followed by the plain launch: activation, ReLU bits, convolution output and partial rows
+    bit-identical; the column-sum rows sum to the activation's column sums."""
+    from iif_amd import ops
+    n, hw, c, C = case
+    m = n * hw * hw
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(17 * c + hw)
+    x_raw = torch.randn(n, hw, hw, c, generator=g).to(dt).to(DEV)
+    w = (torch.randn(C, c, generator=g) / c ** 0.5).to(dt).to(DEV)
+    st = torch.zeros(4, c)
+    st[2] = torch.rand(c, generator=g) + 0.5
+    st[3] = torch.randn(c, generator=g) * 0.3
+    st = st.to(DEV)
+    a_ref = torch.empty_like(x_raw)
+    bits_ref = torch.zeros(m * c // 8, dtype=torch.uint8, device=DEV)
+    ops.bn_apply(x_raw.view(m, c), st, a_ref.view(m, c), relu=True, relu_bits=bits_ref)
+    rows = (m + 127) // 128 + 8
+    for stats_only in (True, False):
+        if not ops.conv_pro_ok(n, hw, hw, c, C, dt, stats_only):
+            continue
+        p_ref = torch.full((rows, 2, C), float("nan"), device=DEV)
+        p = torch.full((rows, 2, C), float("nan"), device=DEV)
+        act = torch.full_like(x_raw, float("nan"))
+        bits = torch.full_like(bits_ref, 0x55)
+        csum = torch.full((rows, 2, c), float("nan"), device=DEV)
+        if stats_only:
+            nt_ref = ops.conv_forward_stats_acc(a_ref, w, p_ref.view(-1))
+            nt = ops.conv_forward_bnstats_pro(x_raw, st, act, bits, w, None, p.view(-1), act_csum=csum)
+        else:
+            y_ref = torch.empty(n, hw, hw, C, dtype=dt, device=DEV)
+            nt_ref = ops.conv_forward_bnstats(a_ref, w, 1, 1, 1, 0, y_ref, p_ref.view(-1))
+            y = torch.full_like(y_ref, float("nan"))
+            nt = ops.conv_forward_bnstats_pro(x_raw, st, act, bits, w, y, p.view(-1), act_csum=csum)
+            assert torch.equal(y, y_ref)
+        assert nt == nt_ref and nt > 0
+        assert torch.equal(act, a_ref) and torch.equal(bits, bits_ref)
+        assert torch.equal(p[:nt], p_ref[:nt])
+        cs = csum[:nt, 0].double().sum(0)
+        assert (csum[:nt, 1] == 0).all()
+        ref = a_ref.view(m, c).double().sum(0)
+        assert ((cs - ref).abs() <= 1e-5 * a_ref.view(m, c).double().abs().sum(0) + 1e-6).all()
+
+
 @pytest.mark.parametrize("case", [(4, 16, 64, 256, 64), (4, 16, 128, 256, 64), (2, 32, 128, 512, 128), (4, 16, 256, 512, 128),
                                   (16, 56, 64, 256, 64)], ids=lambda c: "%dx%dx%d_k%d_n%d_c%d" % (c[0], c[1], c[1], c[2], c[3], c[4]))
 @pytest.mark.parametrize("with_res", [False, True], ids=["plain", "residual"])
