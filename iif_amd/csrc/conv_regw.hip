@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
 #pragma unroll
             for (int k = 0; k < NST; ++k) {
                 const size_t o = base + ((size_t)(k * RPI + lane / LPR) * a.dpitch + (lane % LPR) * 8) * 2;
-                r[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(has_res ? a.res + o : dummy));
+                r[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p_res + (o & m_res)));      // (straight-line: see below)
             }
         }
         if constexpr (DG) {

@@ -429,10 +429,54 @@ def g8_warmup():
     return out
 
 
+# -------------------------------------------------------------------------- G18
+def g18_ckpt_resnet32():
+    """A checkpoint in the reference's format WRITTEN BY THE REFERENCE'S OWN CLASSES (classification/train.py:265-271:
+    model / optimizer / lr_scheduler / epoch / args), and what the reference computes when it carries on from it:
+    resnet_cifar.resnet32 (100 classes), two SGD steps of epoch 0, lr_scheduler.step(), torch.save; then two more steps of
+    epoch 1.  tests/test_data_ckpt.py resumes the native model from the file and must reproduce those two losses.
+    Writes tests/golden/g18_ckpt_resnet32.pth (data: tensors + a pickled argparse.Namespace) next to the .npz."""
+    import argparse
+    counts = O.img_num_per_cls(100, 50000, "exp", 0.01)
+    sd = R.init_cifar("resnet32", 100, seed=11)
+    model = resnet_cifar.resnet32(num_classes=100, use_norm="None")
+    model.load_state_dict(sd)
+    model.train()
+    args = argparse.Namespace(model="resnet32", dset_name="cifar100", lr=0.1, momentum=0.9, weight_decay=1e-4, opt="sgd",
+                              milestones=[1, 3], lr_gamma=0.1, epochs=5, cosine_scheduler=False, batch_size=16,
+                              classif_norm="None", start_epoch=0)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(16, 3, 32, 32, generator=g)
+    prior = torch.tensor(counts, dtype=torch.float64)
+    y = torch.multinomial(prior / prior.sum(), 16, replacement=True, generator=g)
+    crit = custom.IIFLoss(_DS(counts), variant="raw", device="cpu")
+    opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=args.milestones, gamma=args.lr_gamma)   # train.py:226-228
+    losses, lrs = [], []
+
+    def step():
+        loss = crit(model(x), y)
+        opt.zero_grad()
+        loss.backward()
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        losses.append(float(loss))
+    step(); step()
+    sched.step()                                              # end of epoch 0 (train.py:260)
+    ckpt = {"model": model.state_dict(), "optimizer": opt.state_dict(), "lr_scheduler": sched.state_dict(), "epoch": 0,
+            "args": args}
+    torch.save(ckpt, os.path.join(HERE, "g18_ckpt_resnet32.pth"))
+    step(); step()                                            # epoch 1, as a resumed run continues
+    final = model.state_dict()
+    return {"x": x.numpy(), "y": y.numpy(), "counts": np.array(counts), "losses": np.array(losses), "lrs": np.array(lrs),
+            "final_checksum": _state_checksum(final), "final_linear": final["linear.weight"][:4].numpy(),
+            "final_bn1_rm": final["bn1.running_mean"].numpy()}
+
+
 def main():
     sets = {"g1_class_counts": g1_class_counts, "g2_class_map": g2_class_map, "g3_tables": g3_tables,
             "g4_loss": g4_loss, "g7_nets": g7_nets, "g8_warmup": g8_warmup, "g9_heads": g9_heads, "g10_se": g10_se, "g16_nets_conditioned": g16_nets_conditioned,
-            "g17_resnet50_224": g17_resnet50_224}
+            "g17_resnet50_224": g17_resnet50_224, "g18_ckpt_resnet32": g18_ckpt_resnet32}
     only = sys.argv[1:]
     if only:
         sets = {k: v for k, v in sets.items() if k in only}

@@ -233,3 +233,67 @@ def test_tr_read_results_are_waited_for(tmp_path, src):
             if op.startswith("ds_"):
                 n_lds += 1
     assert reads >= 8, "no transposing reads found in %s" % src
+
+
+def test_counted_vmcnt_waits_of_the_register_weight_kernels(tmp_path):
+    """The persistent 1x1 kernels of conv_regw.hip close every tile with a HAND-COUNTED `s_waitcnt vmcnt(N)`: the next tile's
+    LDS-DMA pieces and epilogue operands must have landed, this tile's N stores may stay in flight (vector-memory operations
+    retire in order).  That is only right if the emitted loop body issues AT LEAST N vector-memory instructions behind the last
+    load it waits for, all of them stores - a compiler that dropped, merged or hoisted one of them would make the wait let a
+    load through (round-5 review: the bit-identity tests were the only net).  Pin the gfx950 ISA: walking the tile loop
+    BACKWARDS from each hand-written counted wait (cyclically: the compiler rotates some of these loops), at least N stores come
+    before the first LDS-DMA / load."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(ROOT, "iif_amd", "csrc")
+    asm_path = tmp_path / "k.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + csrc, "--offload-device-only",
+                    "-S", "-o", str(asm_path), os.path.join(csrc, "conv_regw.hip")], check=True, stderr=subprocess.DEVNULL)
+    cur, hand, kernels = None, False, {}
+    for line in asm_path.read_text().splitlines():
+        t = line.strip()
+        if line and not line[0].isspace() and t.startswith("_Z") and ": ;" in t and "gemm1x1_regw_kernel" in t.split(":")[0]:
+            cur = t.split(":")[0]
+            kernels[cur] = []
+        elif cur is not None:
+            if t.startswith(";;#ASMSTART"):
+                hand = True
+            elif t.startswith(";;#ASMEND"):
+                hand = False
+            elif t.startswith("s_endpgm"):
+                cur = None
+            elif t.startswith(".LBB") and t.split(";")[0].strip().endswith(":"):
+                kernels[cur].append(("LABEL " + t.split(":")[0], False))
+            elif t and not t.startswith((".", ";")):
+                kernels[cur].append((t, hand))
+    assert len(kernels) >= 15, sorted(kernels)
+    checked = 0
+    for name, ins in kernels.items():
+        labels = {t.split()[1]: i for i, (t, _) in enumerate(ins) if t.startswith("LABEL ")}
+        loops = []                                                     # (first, last) of every backward branch
+        for i, (t, _) in enumerate(ins):
+            m = re.match(r"s_c?branch\S*\s+(\.LBB\S+)", t)
+            if m and m.group(1) in labels and labels[m.group(1)] < i:
+                loops.append((labels[m.group(1)], i))
+        for i, (t, h) in enumerate(ins):
+            m = re.match(r"s_waitcnt vmcnt\((\d+)\)$", t)
+            if not (h and m and int(m.group(1)) > 0):
+                continue
+            n = int(m.group(1))
+            inside = [lp for lp in loops if lp[0] <= i <= lp[1]]
+            assert inside, (name, t, "a counted wait outside the tile loop")
+            lo, hi = max(inside, key=lambda lp: lp[1] - lp[0])       # (the tile loop: block placement also produces short backward jumps)
+            body = ins[lo:hi + 1]
+            order = body[:i - lo][::-1] + body[i - lo + 1:][::-1]      # backwards from the wait, wrapping round the loop
+            stores = 0
+            for (u, _) in order:
+                op = u.split()[0]
+                if (op.startswith("buffer_load") and u.rstrip().endswith("lds")) or op.startswith(("global_load", "scratch_load")):
+                    break
+                if op.startswith(("global_store", "scratch_store", "buffer_store")):
+                    stores += 1
+            assert stores >= n, "%s: vmcnt(%d) has only %d stores between it and the last load of the tile loop" % (name, n, stores)
+            checked += 1
+    assert checked >= 15, checked

@@ -168,3 +168,84 @@ def test_get_data_reads_list_files(tmp_path):
     assert tuple(x.shape) == (4, 3, 32, 32) and x.dtype == torch.float32 and y.dtype == torch.int64
     xt, yt = next(iter(loader_test))
     assert tuple(xt.shape) == (4, 3, 32, 32) and yt.tolist() == [2, 2, 0, 0]       # raw 0,0,1,1 through the training class map
+
+
+# ------------------------------------------------------------ a checkpoint written by the reference's own classes (golden G18)
+def _g18():
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g18_ckpt_resnet32.pth")
+    return path, torch.load(path, map_location="cpu", weights_only=False)      # the dict pickles an argparse.Namespace (train.py:270)
+
+
+def test_reference_checkpoint_loads_into_the_native_model():
+    """tests/golden/g18_ckpt_resnet32.pth was saved by classification/resnet_cifar.resnet32 + torch.optim.SGD + MultiStepLR through
+    the dict of classification/train.py:265-271 (tests/golden/make_golden.py::g18_ckpt_resnet32).  `--resume`
+    (train.py:236-241): model strict-loads, the momentum buffers land in the momentum arena, the scheduler state the native
+    loop would have written equals the reference's, the next epoch's learning rate is the reference's.  `--load_from` /
+    `pretrained=<path>` with another class count (resnet_pytorch.py:383-397 `_mismatched_classifier`): backbone taken,
+    classifier left alone."""
+    from iif_amd import resnet_cifar
+    from iif_amd.resnet_pytorch import _load_mismatched
+    from iif_amd.train import lr_at, scheduler_state_dict
+    path, ckpt = _g18()
+    assert set(ckpt) == {"model", "optimizer", "lr_scheduler", "epoch", "args"} and ckpt["epoch"] == 0
+    net = resnet_cifar.resnet32(num_classes=100, use_norm="None", device="cpu", compute_dtype=torch.float32)
+    net.load_state_dict(ckpt["model"])                                   # strict: same keys, same shapes
+    own = net.state_dict()
+    assert list(own.keys()) == list(ckpt["model"].keys())
+    for k, v in ckpt["model"].items():
+        assert torch.equal(own[k].cpu(), v), k
+    assert net.load_optimizer_state_dict(ckpt["optimizer"]) == []
+    for i, v in enumerate(net._arena_views(net._mom_arena)):
+        assert torch.equal(v, ckpt["optimizer"]["state"][i]["momentum_buffer"]), i
+    args = ckpt["args"]
+    mine, ref = scheduler_state_dict(args, ckpt["epoch"] + 1), ckpt["lr_scheduler"]
+    assert mine["last_epoch"] == ref["last_epoch"] and mine["_last_lr"] == ref["_last_lr"] and mine["milestones"] == ref["milestones"]
+    assert lr_at(args, ckpt["epoch"] + 1, 10 ** 9, 10 ** 9) == ckpt["optimizer"]["param_groups"][0]["lr"]
+    # and the native model's own checkpoint of this state is one the reference's optimizer accepts
+    sd = net.optimizer_state_dict(ref["_last_lr"][0], args.momentum, args.weight_decay, False, initial_lr=args.lr)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros_like(p)) for p in net.parameters()], lr=args.lr, momentum=args.momentum)
+    opt.load_state_dict(sd)
+    # another class count: everything but the classifier
+    net10 = resnet_cifar.resnet32(num_classes=10, use_norm="None", device="cpu", compute_dtype=torch.float32)
+    w_before, b_before = net10.linear.weight.detach().clone(), net10.linear.bias.detach().clone()
+    _load_mismatched(net10, path)
+    own10 = net10.state_dict()
+    for k, v in ckpt["model"].items():
+        if k.startswith("linear."):
+            continue
+        assert torch.equal(own10[k].cpu(), v), k
+    assert torch.equal(net10.linear.weight.detach(), w_before) and torch.equal(net10.linear.bias.detach(), b_before)
+
+
+@pytest.mark.gpu
+def test_resume_from_reference_checkpoint_reproduces_the_reference_run(golden):
+    """The two steps the REFERENCE took after writing the checkpoint (epoch 1, lr 0.01 behind the first milestone), taken by the
+    native fp32 step after `--resume`: same losses (1e-6 for the first: weights and BN buffers alone; 1e-5 for the second: the
+    momentum buffers and the update too), same final classifier rows and running statistics."""
+    from iif_amd import resnet_cifar
+    from iif_amd.custom import IIFLoss
+    from iif_amd.train import lr_at
+    g = golden("g18_ckpt_resnet32")
+    path, ckpt = _g18()
+    args = ckpt["args"]
+
+    class DS:
+        def get_cls_num_list(self):
+            return [int(c) for c in g["counts"]]
+    net = resnet_cifar.resnet32(num_classes=100, use_norm="None", compute_dtype=torch.float32)
+    net.load_state_dict(ckpt["model"])
+    assert net.load_optimizer_state_dict(ckpt["optimizer"]) == []
+    epoch = ckpt["epoch"] + 1
+    lr = lr_at(args, epoch, 10 ** 9, 10 ** 9)
+    assert abs(lr - float(g["lrs"][2])) < 1e-15 and abs(lr - float(g["lrs"][3])) < 1e-15
+    crit = IIFLoss(DS(), variant="raw")
+    x, y = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["y"]).cuda()
+    net.train()
+    for i, tol in ((2, 1e-6), (3, 1e-5)):
+        loss, _ = net.loss_and_backward(x, y, crit)
+        net.sgd_step(lr, args.momentum, args.weight_decay)
+        assert abs(loss.item() - float(g["losses"][i])) <= tol * abs(float(g["losses"][i])), (i, loss.item(), float(g["losses"][i]))
+    sd = net.state_dict()
+    assert (sd["linear.weight"][:4].cpu() - torch.from_numpy(g["final_linear"])).abs().max().item() <= 1e-5 * np.abs(g["final_linear"]).max()
+    assert (sd["bn1.running_mean"].cpu() - torch.from_numpy(g["final_bn1_rm"])).abs().max().item() <= 1e-5 * max(np.abs(g["final_bn1_rm"]).max(), 1e-3)

@@ -23,6 +23,17 @@ def rel_err(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
 
 
+def row_rel_err(a, b):
+    """Worst row of the per-ROW relative error: every row's deviation against that row's own largest entry (round-5 review:
+    the tensor-wide maximum lets the small gradient rows of rare classes pass unchecked).  Rows whose largest entry is below 1e-3
+    of the tensor's are held to that floor: a row's target entry is softmax - 1, formed in fp32 like the reference's, so its ABSOLUTE
+    error is one fp32 ulp of 1 (6e-8 of the tensor's scale) however small the row is - a nearly saturated row (1 - p_target = 2e-4,
+    measured at [5000, 100]) sits 5e-4 from the float64 closed form relative to itself, and so does PyTorch's."""
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    floor = 1e-3 * b.abs().max().item()
+    return ((a - b).abs().amax(dim=1) / b.abs().amax(dim=1).clamp_min(max(floor, 1e-30))).max().item()
+
+
 class DS:
     def __init__(self, c):
         self.c = list(c)
@@ -101,6 +112,7 @@ def test_full_size_against_oracle(B, C, top, variant):
         loss.backward()
         assert rel_err(loss, ref_l) <= REL, (B, C, red)
         assert rel_err(p.grad, ref_d) <= REL, (B, C, red)
+        assert row_rel_err(p.grad, ref_d) <= REL, (B, C, red, "per row")
     # torch-CPU oracle (the reference's own op sequence) agrees too
     pc = pred.clone().requires_grad_(True)
     lc = O.iif_ce(pc, tgt, table, None, "mean")

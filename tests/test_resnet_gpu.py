@@ -862,3 +862,50 @@ def test_two_weight_gradient_streams_give_the_same_gradients(arch, C, B, hw, mon
         grads.append(g1)
     err = (grads[1] - grads[0]).norm().item() / grads[0].norm().item()
     assert err <= 1e-5, err
+
+
+def test_bf16_gradients_at_a_settled_point():
+    """Round-5 review item 7: bf16 gradients where the network is NOT at its initialisation - ResNet-50, 224 x 224, batch 64,
+    damped init, 20 SGD steps taken in fp32 mode (BN statistics and weights settled), then one bf16 step against the fp32 step of
+    the same engine on a fresh batch (the fp32 step is what the oracle pins to 1e-4 elsewhere in this file).
+    What bf16 STORAGE of activations and gradients costs at such a point was measured (scripts/dbg_bf16_settled.py,
+    profiles/r6_bf16_settled.txt): loss 5e-5 away, but every gradient tensor 0.42-0.45 (relative L2) away, the whole gradient
+    0.30, cosine 0.956 - synthetic noise images give 64 nearly orthogonal per-image gradients, BN backward subtracts their
+    large common part, and the bf16 rounding of the remainder is of its own size; the CPU oracle with bf16 storage shows the
+    same level (test_full_size_step_replication_property).  A tolerance of a few bf16 ulps therefore does not exist on this
+    workload.  What IS asserted is what a wrong kernel would break and rounding noise does not: the loss, the DIRECTION of the
+    whole gradient (cosine, and its length along the fp32 gradient), every tensor's projection on its fp32 counterpart
+    (a missing term or a wrong scale moves it far from 1), and that no tensor is further than the measured noise level."""
+    from iif_amd.custom import IIFLoss
+    arch, C, B, hw = "resnet50", 1000, 64, 224
+    counts = [max(int(1280 * (5 / 1280) ** (i / (C - 1.0))), 1) for i in range(C)]
+    crit = IIFLoss(DS(counts), variant="raw")
+    net, sd = _build(arch, C, torch.float32)
+    net.load_state_dict(damp_residual_branches(sd, arch))
+    net.train()
+    for it in range(20):
+        x, y = _data(B, hw, counts, seed=100 + it)
+        net.loss_and_backward(x.to(DEV), y.to(DEV), crit)
+        net.sgd_step(0.002, 0.9, 1e-4)
+    settled = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    del net
+    x, y = _data(B, hw, counts, seed=999)
+    xd, yd = x.to(DEV), y.to(DEV)
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        n2, _ = _build(arch, C, dt)
+        n2.load_state_dict(settled)
+        n2.train()
+        loss, _ = n2.loss_and_backward(xd, yd, crit)
+        out[dt] = (loss.item(), [v.double().cpu().clone().flatten() for v in n2._grad_views], [k for k, _ in n2.named_parameters()])
+        del n2
+    (l32, g32, names), (l16, g16, _) = out[torch.float32], out[torch.bfloat16]
+    assert abs(l16 - l32) <= 5e-4 * abs(l32)
+    a, b = torch.cat(g16), torch.cat(g32)
+    cos = (a @ b / (a.norm() * b.norm())).item()
+    proj = (a @ b / (b @ b)).item()
+    assert cos >= 0.93 and 0.9 <= proj <= 1.05, (cos, proj)
+    for n_, u, v in zip(names, g16, g32):
+        p = (u @ v / (v @ v).clamp_min(1e-300)).item()
+        e = ((u - v).norm() / v.norm().clamp_min(1e-300)).item()
+        assert 0.7 <= p <= 1.15 and e <= 0.75, (n_, p, e)
