@@ -37,6 +37,7 @@ SIGNATURES = {
     "iif_conv_igemm_bnstats": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "iif_bn_finalize_stats": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _P],
     "iif_bn_finalize_stats_fused": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _P, _P],
+    "iif_bn_finalize_stats_sums": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _P, _P, _I, _I, _P, _P],
     "iif_bn_backward_partials_fused": [_P, _P, _P, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P, _P],
     "iif_bn_partial_sums": [_P, _I, _I, _P, _P],
     "iif_bn_stats_sums": [_P, _I, _L, _I, _P, _P, _L, _P],

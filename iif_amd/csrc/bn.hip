@@ -115,13 +115,24 @@ __device__ __forceinline__ void reduce_partials(const float* partial, int nblk, 
 }
 
 // stats layout: [4][C] = mean, invstd, a (=gamma*invstd), b (=beta-mean*a)
+// Blocks >= nb_main (round 6; partial2 non-null): a SECOND, independent job riding in the same launch - the plain column sums of
+// another set of partial rows [nblk2][2][C2] into sums2[2][C2] (the column sums of a2 that conv3's prologue left behind: one launch
+// and one cross-stream event less per bottleneck than a reduction of its own).
 template <int CB>
 __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partial, int nblk, int C, double count,
                                                           const float* gamma, const float* beta, float eps,
                                                           float momentum, float* running_mean, float* running_var,
-                                                          float* stats) {
+                                                          float* stats, int nb_main = 0x7fffffff, const float* partial2 = nullptr,
+                                                          int nblk2 = 0, int C2 = 0, float* sums2 = nullptr) {
     __shared__ double sh[512];
     const int cl = threadIdx.x % CB, ln = threadIdx.x / CB;
+    if ((int)blockIdx.x >= nb_main) {
+        const int c2 = ((int)blockIdx.x - nb_main) * CB + cl;
+        double s2, q2;
+        reduce_partials<CB>(partial2, nblk2, C2, c2, ln, sh, cl, s2, q2);
+        if (ln == 0 && c2 < C2) { sums2[c2] = (float)s2; sums2[C2 + c2] = (float)q2; }
+        return;
+    }
     const int c = blockIdx.x * CB + cl;
     // per-channel parameters are fetched together with the partial rows, not in a second round trip after them
     float ga = 0.f, be = 0.f, rm = 0.f, rv = 0.f;
@@ -509,12 +520,14 @@ inline int finalize_cb(int nblk) {
 }
 
 inline int launch_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
-                              float eps, float momentum, float* rm, float* rv, float* stats, hipStream_t st) {
-    const int cb = finalize_cb(nblk);
-    const dim3 grid((C + cb - 1) / cb), blk(256);
-    if (cb == 4) hipLaunchKernelGGL(bn_finalize_kernel<4>, grid, blk, 0, st, partial, nblk, C, count, gamma, beta, eps, momentum, rm, rv, stats);
-    else if (cb == 8) hipLaunchKernelGGL(bn_finalize_kernel<8>, grid, blk, 0, st, partial, nblk, C, count, gamma, beta, eps, momentum, rm, rv, stats);
-    else hipLaunchKernelGGL(bn_finalize_kernel<32>, grid, blk, 0, st, partial, nblk, C, count, gamma, beta, eps, momentum, rm, rv, stats);
+                              float eps, float momentum, float* rm, float* rv, float* stats, hipStream_t st,
+                              const float* partial2 = nullptr, int nblk2 = 0, int C2 = 0, float* sums2 = nullptr) {
+    const int cb = finalize_cb(nblk > nblk2 ? nblk : nblk2);
+    const int nb = (C + cb - 1) / cb, nb2 = partial2 ? (C2 + cb - 1) / cb : 0;
+    const dim3 grid(nb + nb2), blk(256);
+    if (cb == 4) hipLaunchKernelGGL(bn_finalize_kernel<4>, grid, blk, 0, st, partial, nblk, C, count, gamma, beta, eps, momentum, rm, rv, stats, nb, partial2, nblk2, C2, sums2);
+    else if (cb == 8) hipLaunchKernelGGL(bn_finalize_kernel<8>, grid, blk, 0, st, partial, nblk, C, count, gamma, beta, eps, momentum, rm, rv, stats, nb, partial2, nblk2, C2, sums2);
+    else hipLaunchKernelGGL(bn_finalize_kernel<32>, grid, blk, 0, st, partial, nblk, C, count, gamma, beta, eps, momentum, rm, rv, stats, nb, partial2, nblk2, C2, sums2);
     IIF_LAUNCH_CHECK();
     return IIF_OK;
 }
@@ -930,6 +943,21 @@ int iif_bn_finalize_stats_fused(const float* partial, int n_partials, int64_t m,
                        n_partials, c, rps, scratch, tickets, (double)m, gamma, beta, eps, momentum, stats, running_mean, running_var);
     IIF_LAUNCH_CHECK();
     return IIF_OK;
+}
+
+int iif_bn_finalize_stats_sums(const float* partial, int n_partials, int64_t m, int c, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var, float* stats,
+                               float* scratch, int64_t scratch_floats, int32_t* tickets, const float* partial2, int n_partials2, int c2,
+                               float* sums2, void* stream) {
+    if (!partial2 || !sums2 || n_partials2 <= 0 || c2 <= 0) return IIF_EINVAL;
+    if (!partial || !gamma || !beta || !stats || n_partials <= 0 || m <= 0 || c <= 0) return IIF_EINVAL;
+    if (n_partials > two_stage_rows() || n_partials2 > two_stage_rows()) {          // (many rows: the two reductions as they were)
+        const int rc = iif_bn_finalize_stats_fused(partial, n_partials, m, c, gamma, beta, eps, momentum, running_mean, running_var, stats,
+                                                   scratch, scratch_floats, tickets, stream);
+        return rc != IIF_OK ? rc : launch_column_sums(partial2, n_partials2, c2, sums2, as_stream(stream));
+    }
+    return launch_bn_finalize(partial, n_partials, c, (double)m, gamma, beta, eps, momentum, running_mean, running_var, stats,
+                              as_stream(stream), partial2, n_partials2, c2, sums2);
 }
 
 int iif_bn_apply(const void* x, int dtype, int64_t m, int c, const float* stats, const void* residual,

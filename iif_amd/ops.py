@@ -49,8 +49,16 @@ def conv_forward_bnstats(x, w, r, s, stride, pad, out, partial, groups=1, w_frag
 
 
 def bn_finalize_stats(partial, n_partials, m, c, gamma, beta, running_mean, running_var, stats, eps=1e-5, momentum=0.1,
-                      scratch=None, tickets=None):
-    """``tickets`` (zeroed int32[64], one per stream): both reduction stages in one launch (iif_bn_finalize_stats_fused)."""
+                      scratch=None, tickets=None, extra_sums=None):
+    """``tickets`` (zeroed int32[64], one per stream): both reduction stages in one launch (iif_bn_finalize_stats_fused).
+    ``extra_sums`` = (rows [n, 2, c2], n, c2, out [2, c2]): a second set of partial rows column-summed by the same launch."""
+    if extra_sums is not None:
+        rows2, n2, c2, out2 = extra_sums
+        check(lib().iif_bn_finalize_stats_sums(ptr(partial), n_partials, m, c, ptr(gamma), ptr(beta), eps, momentum,
+                                               ptr(running_mean), ptr(running_var), ptr(stats), ptr(scratch),
+                                               0 if scratch is None else scratch.numel(), ptr(tickets), ptr(rows2), n2, c2, ptr(out2),
+                                               stream_ptr()), "iif_bn_finalize_stats_sums", tickets)
+        return stats
     if tickets is not None:
         check(lib().iif_bn_finalize_stats_fused(ptr(partial), n_partials, m, c, ptr(gamma), ptr(beta), eps, momentum,
                                                 ptr(running_mean), ptr(running_var), ptr(stats), ptr(scratch),

@@ -858,7 +858,9 @@ class _Plan(object):
                     rows = None
                     if u3 in self.alg3_units:
                         rows = torch.zeros(((u3.n * u3.ho * u3.wo + 127) // 128 + 8) * 2 * cv3.cin, dtype=torch.float32, device=dev)
-                    self.pro_units[u3] = [u2, rows, 0, u3 in self.nostore_units]      # (.., partial rows of the last forward, instance kind)
+                    fin = torch.zeros((2, cv3.cin), dtype=torch.float32, device=dev) if rows is not None else None
+                    # [conv2 unit, partial rows of a2's column sums, their count in the last forward, instance kind, the sums themselves]
+                    self.pro_units[u3] = [u2, rows, 0, u3 in self.nostore_units, fin]
         self.a3 = None
         if self.alg3_units:
             cm = max(u.conv.cin for u in self.alg3_units)
@@ -875,7 +877,8 @@ class _Plan(object):
                         "tickets": torch.zeros(64, dtype=torch.int32, device=dev)}
                        for _ in range(self.wg_lag)]
             self.a3g = [{"gram": F(cm, ldm), "csum": F(2, cm), "ws_gram": torch.empty(64 << 20, dtype=torch.uint8, device=dev),
-                         "ws_sum": ops.bn_workspace(max(u.n * u.ho * u.wo for u in self.alg3_units), cm, dev), "ev": None, "ev_csum": None}
+                         "ws_sum": ops.bn_workspace(max(u.n * u.ho * u.wo for u in self.alg3_units), cm, dev), "ev": None, "ev_csum": None,
+                         "csum_fwd": None}
                         for _ in range(self.wg_lag + 1)]
             self.a3_ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)          # split-K slabs of P on the compute stream
         wmax = max(max(u.conv.cout * (u.dwp.shape[1] if u.dwp is not None else u.conv.ldw) for u in self.units),
@@ -1167,9 +1170,11 @@ class _Plan(object):
             if sync is not None:
                 self._sync_finalize(u, ops.bn_partial_sums(partial, nt, cv.cout, self._sync_sums(cv.cout, side)), m, sync)
                 return x2
+            # (with the prologue's column-sum rows: reduced by this same launch, ops.bn_finalize_stats)
+            extra = (pro[1], nt, pro[0].conv.cout, pro[4]) if (pro is not None and pro[1] is not None) else None
             ops.bn_finalize_stats(partial, nt, m, cv.cout, u.bn.weight, u.bn.bias, u.bn.running_mean,
                                   u.bn.running_var, u.stats, BN_EPS, BN_MOMENTUM, scratch=scratch,
-                                  tickets=self.bn_tickets_side if side else self.bn_tickets)
+                                  tickets=self.bn_tickets_side if side else self.bn_tickets, extra_sums=extra)
             return x2
         # the unfused statistics below use the compute stream's BN workspace: a shortcut convolution on the side stream
         # must have taken the fused-statistics path above (bf16, DMA-addressable source), which needs none
@@ -1263,9 +1268,10 @@ class _Plan(object):
                     pro[2] = nt
                 else:
                     nt = ops.conv_forward_stats_acc(last.src, last.w, self.bn_partial)
+                extra = (pro[1], nt, cv.cin, pro[4]) if (pro is not None and pro[1] is not None) else None
                 ops.bn_finalize_stats(self.bn_partial, nt, m, cv.cout, last.bn.weight, last.bn.bias, last.bn.running_mean,
                                       last.bn.running_var, last.stats, BN_EPS, BN_MOMENTUM, scratch=self.bn_scratch,
-                                      tickets=self.bn_tickets)
+                                      tickets=self.bn_tickets, extra_sums=extra)
                 if "ds" in b:
                     du = b["ds"]
                     if ds_done is not None:
@@ -1547,15 +1553,19 @@ class _Plan(object):
         A = self.a3g[bi % (self.wg_lag + 1)]
         cv = u.conv
         a2 = u.src
+        A["csum_fwd"] = None
+        pro = self.pro_units.get(u) if self.fuse_bwd else None
+        if pro is not None and pro[1] is not None and pro[2] > 0:
+            # the forward pass already left the column sums of a2 (bn2's prologue in conv3's launch, reduced by that unit's
+            # finalisation): nothing to compute, and with the Gram matrix stacked behind P nothing to launch or wait for at all
+            A["csum_fwd"] = pro[4]
+            if self._a3_gram_stacked(u):
+                A["ev"] = A["ev_csum"] = None
+                return
 
         def csum():
-            pro = self.pro_units.get(u) if self.fuse_bwd else None
-            if pro is not None and pro[1] is not None and pro[2] > 0:
-                # the forward pass left the column sums of a2 as partial rows (bn2's prologue in conv3's launch): a [rows, c] reduction
-                # instead of a pass over the tensor
-                ops.bn_partial_sums(pro[1], pro[2], cv.cin, A["csum"].view(-1)[:2 * cv.cin].view(2, cv.cin))
-                return
-            ops.bn_stats_sums(a2.view(-1, cv.cin), A["csum"].view(-1)[:2 * cv.cin].view(2, cv.cin), A["ws_sum"])
+            if A["csum_fwd"] is None:
+                ops.bn_stats_sums(a2.view(-1, cv.cin), A["csum"].view(-1)[:2 * cv.cin].view(2, cv.cin), A["ws_sum"])
 
         def gram():
             if not self._a3_gram_stacked(u):
@@ -1597,11 +1607,12 @@ class _Plan(object):
         coef = A["coef"].view(-1)[:3 * C].view(3, C)
         # colsum(a2) (issued a block ahead with the Gram matrix) keeps the data gradient's column sums at zero through the bf16
         # rounding of the stacked weights (bn3_gm_finish_kernel); the weight gradient needs Gram / colsum too, off the critical path
+        csum_a2 = (Ag["csum_fwd"] if Ag.get("csum_fwd") is not None else Ag["csum"]).view(-1)[:c]
         gram_ev = Ag["ev"]
         if Ag.get("ev_csum") is not None:
             torch.cuda.current_stream().wait_event(Ag["ev_csum"])
         ops.bn3_algebra_prep(P if pure else None, wb, c, rows, nt, u.stats, bn.weight, m, coef, bn._dgamma, bn._dbeta, wt,
-                             A["bias"][:c], A["scr"], A["tickets"], colsum2=Ag["csum"].view(-1)[:c])
+                             A["bias"][:c], A["scr"], A["tickets"], colsum2=csum_a2)
 
         stacked = self._a3_gram_stacked(u)
 
@@ -1613,7 +1624,7 @@ class _Plan(object):
                 gram = ext[C:]
             elif not pure:
                 ops.conv_wgrad(u.src, g4, 1, 1, 1, 0, ldw=cv.ldw, out=P, workspace=ws, splits=sp)
-            ops.bn3_algebra_dw(P, wb, c, gram, Ag["csum"].view(-1)[:c], coef, cv._g2d)
+            ops.bn3_algebra_dw(P, wb, c, gram, csum_a2, coef, cv._g2d)
         if self.wg_stream is None:
             finish_dw(self.a3_ws, 0)
         else:

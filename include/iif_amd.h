@@ -234,6 +234,13 @@ int iif_bn_finalize_stats_fused(const float* partial, int n_partials, int64_t m,
                                 const float* beta, float eps, float momentum, float* running_mean,
                                 float* running_var, float* stats, float* scratch, int64_t scratch_floats,
                                 int32_t* tickets, void* stream);
+/* Round 6: iif_bn_finalize_stats_fused plus a second, independent job in the same launch: sums2[2][c2] = column sums of the partial
+ * rows partial2 [n_partials2][2][c2] (iif_bn_partial_sums' result) - the column sums of a2 that conv3's prologue emits
+ * (iif_conv_igemm_bnstats_pro's act_csum) are reduced by the finalisation that follows that launch anyway. */
+int iif_bn_finalize_stats_sums(const float* partial, int n_partials, int64_t m, int c, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var, float* stats,
+                               float* scratch, int64_t scratch_floats, int32_t* tickets, const float* partial2, int n_partials2,
+                               int c2, float* sums2, void* stream);
 int iif_bn_backward(const void* gy, const void* y_mask, const uint8_t* relu_bits, const void* x,
                     int dtype, int64_t m, int c, const float* stats, const float* gamma, float* dgamma,
                     float* dbeta, void* dx, void* gmasked, void* workspace, int64_t workspace_bytes,
