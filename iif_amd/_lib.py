@@ -91,6 +91,7 @@ SIGNATURES = {
     "iif_bn3_algebra_prep_scratch_floats": [_I, _I],
     "iif_bn3_algebra_dw": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P],
     "iif_conv_pack_fragments": [_P, _P, _I, _I, _P, _P],
+    "iif_conv_pack_fragments_g16": [_P, _P, _I, _I, _P, _P],
     "iif_conv3x3_frag_ok": [_P],
     "iif_mask_gather": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
     "iif_mask_bce_fwd_bwd": [_P, _I, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P],
@@ -114,7 +115,8 @@ SIGNATURES = {
 class ConvDesc(ctypes.Structure):
     """Mirror of ``iif_conv_desc`` (include/iif_amd.h)."""
     _fields_ = [(k, ctypes.c_int32) for k in ("n", "hs", "ws", "cs", "hd", "wd", "cd", "r", "s", "stride", "pad",
-                                               "transposed", "ldw", "dtype", "dst_dtype", "groups")] + [("wgt_frag", ctypes.c_void_p)]
+                                               "transposed", "ldw", "dtype", "dst_dtype", "groups")] + [("wgt_frag", ctypes.c_void_p),
+                                                                                                          ("wgt_frag_kind", ctypes.c_int32)]
 
 
 class PackDesc(ctypes.Structure):

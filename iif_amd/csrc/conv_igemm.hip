@@ -41,6 +41,7 @@ template <> struct ET<float> { static constexpr int PE = 4, KE = 16; };
 struct ConvArgs {
     const unsigned char* src; const unsigned char* wgt; unsigned char* dst; const unsigned char* res;
     const unsigned char* wfrag;      // nullable: the same weights as MFMA fragments (iif_conv_pack_fragments), 3x3 generation-2 kernel
+    int wfrag_kind;                  // 0: [channel tile][tap][32-channel chunk] fragments; 1: the grouped 16-channel format (iif_conv_pack_fragments_g16)
     const float* bias;
     const unsigned char* res_bits;   // nullable: 1 bit per residual element (ReLU decisions); the residual is masked by it
     // nullable: the batch-norm BACKWARD partial sums of the unit whose output gradient this launch writes
@@ -1086,7 +1087,14 @@ __global__ void __launch_bounds__(256) conv3x3_halo128_kernel(ConvArgs a, unsign
 // divisions they were ~4 us of every tile's prologue.
 __device__ __forceinline__ int fdiv(int x, float rd) { return (int)(((float)x + 0.5f) * rd); }
 
-template <int WM, int WN, int TM, int NAP>
+// G16 (round 6): grouped layers whose groups are <= 16 channels wide (ResNeXt 32x4d: 4 / 8 / 16 channels per group at 56 / 28 / 14).
+// A 64-channel chunk's weight matrix is then block-diagonal in 16 x 16 blocks: output tile ci (16 channels) reads the SAME 16 input
+// channels only.  The dense loop spends 15 / 16 (7 / 8, 3 / 4) of its MFMAs on zeros; here K of an MFMA is TWO TAPS x the tile's 16
+// input channels (lanes with K group 0-1 read tap 2p, K group 2-3 tap 2p + 1, each 8 of the 16 channels), 5 MFMAs per output tile
+// and pixel fragment instead of 18: 80 per wave and tile against 288.  The 20 weight fragments of a wave (4 tiles x 5 tap pairs,
+// iif_conv_pack_fragments_g16) stay in registers for the whole tile; pair 4's second tap does not exist: its weights are packed as
+// zeros and its lanes re-read tap 8 (finite values).  Same halo window, same staged drain.
+template <int WM, int WN, int TM, int NAP, bool G16 = false>
 __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_bytes) {
     constexpr int BM = WM * TM, BN = WN * 64, NWV = WM * WN, PJ = TM / 16, CI = 4;
     static_assert(NWV == 4 && BM == 256, "four waves, 256-pixel tiles");
@@ -1116,7 +1124,8 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
     const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src), 0, src_bytes, 0x00020000);
     // (buffer loads: ONE address register per lane = lane * 16, the fragment is selected by the scalar offset)
     const auto rs_wf = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wfrag), 0,
-                                                         (unsigned)a.groups * (unsigned)a.Cd * 9u * (unsigned)a.Cs * 2u, 0x00020000);
+                                                         G16 ? (unsigned)a.groups * 20u * 1024u
+                                                             : (unsigned)a.groups * (unsigned)a.Cd * 9u * (unsigned)a.Cs * 2u, 0x00020000);
     const unsigned wv = (unsigned)lane * 16u;
     const unsigned ci_stride = 9u * (unsigned)nchunks * 1024u;
     int toff[9];
@@ -1202,8 +1211,17 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
     int tile = (int)blockIdx.x;
     if (!set_tile(tile)) return;
     issue_halo(0);
+    u32x4 wg[G16 ? CI : 1][G16 ? 5 : 1];                   // G16: every fragment of the wave's four output tiles
+    if constexpr (G16) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) wload(t, 0, wb[t]);
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int pr = 0; pr < 5; ++pr)
+                wg[ci][pr] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wf, wv, (unsigned)((grp * 4 + ci) * 5 + pr) * 1024u, 0));
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wload(t, 0, wb[t]);
+    }
     for (;;) {
 #ifdef IIF_CONV_STAMPS
         IIF_STAMP(v_a);
@@ -1224,6 +1242,38 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
 #endif
             // buffer (c + 1) & 1 was last read in chunk c - 1, which every wave has left (barrier at its end)
             if (c + 1 < nchunks) issue_halo(c + 1);
+            if constexpr (G16) {
+                // output tiles 2c and 2c + 1 read the two 16-channel halves of this 32-channel chunk
+                const unsigned hbase = smem_base + (unsigned)((c & 1) * ABUF);
+#pragma unroll
+                for (int pr = 0; pr < 5; ++pr) {
+                    const int tl = (fc >> 1) ? (2 * pr + 1 < 9 ? 2 * pr + 1 : 8) : 2 * pr;       // this lane's tap of the pair
+                    const int to = (fc >> 1) ? toff[2 * pr + 1 < 9 ? 2 * pr + 1 : 8] : toff[2 * pr];
+                    (void)tl;
+#pragma unroll
+                    for (int par = 0; par < 2; ++par) {
+                        u32x4 xg[PJ];
+#pragma unroll
+                        for (int q = 0; q < PJ; ++q) {
+                            const unsigned hr = ((hrow_pk[q >> 1] >> ((q & 1) * 16)) & 0xffffu) + (unsigned)to;
+                            const unsigned chk = (unsigned)(par * 2 + (fc & 1)) ^ ((hr >> 1) & 2u);
+                            xg[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(hbase + (hr << 6) + (chk << 4));
+                        }
+                        if (2 * c + par < CI) {
+#pragma unroll
+                            for (int q = 0; q < PJ; ++q)
+                                acc[(2 * c + par) % CI][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, wg[(2 * c + par) % CI][pr]), __builtin_bit_cast(bf16x8, xg[q]), acc[(2 * c + par) % CI][q], 0, 0, 0);
+                        }
+                    }
+                }
+                if (c + 1 < nchunks) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's halo pieces of chunk c + 1
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                continue;
+            }
             const unsigned fcsb = fcs + smem_base + (unsigned)((c & 1) * ABUF);
             // (an opaque zero per chunk: without it the fragment addresses of all nine taps are hoisted out of the chunk loop as
             // loop invariants, 72 registers the weight ring needs)
@@ -1320,6 +1370,9 @@ __device__ __forceinline__ void conv3x3_v2_body(const ConvArgs& a, unsigned src_
     }
 }
 
+__global__ void __launch_bounds__(256, 2) conv3x3_g16_kernel(ConvArgs a, unsigned src_bytes) {
+    conv3x3_v2_body<4, 1, 64, 10, true>(a, src_bytes);
+}
 __global__ void __launch_bounds__(256, 2) conv3x3_v2n64_kernel(ConvArgs a, unsigned src_bytes) {
     conv3x3_v2_body<4, 1, 64, 10>(a, src_bytes);
 }
@@ -1347,6 +1400,34 @@ __global__ void __launch_bounds__(256) pack_fragments_kernel(const unsigned shor
     const int nt = (int)(f / d.taps);
     const int row = nt * 16 + (lane & 15), k0 = kc * 32 + (lane >> 4) * 8;
     const u32x4 v = *reinterpret_cast<const u32x4*>(src_base + d.src_off + (int64_t)row * d.ld + tap * d.k + k0);
+    *reinterpret_cast<u32x4*>(dst_base + d.dst_off + piece * 8) = v;
+}
+
+// The grouped 16-channel format (conv3x3_v2_body<..., G16>): src = the block-diagonal chunk matrix of iif_group_pack, rows [r][taps * 64]
+// (d.k = 64, d.taps = 9, d.ld = row pitch).  Fragment ((chunk * 4 + ci) * 5 + pair): 1 KB; lane l holds output channel
+// chunk * 64 + ci * 16 + (l & 15), K group l >> 4: tap 2 pair + (l >> 5), input channels ci * 16 + ((l >> 4) & 1) * 8 .. + 8 of the chunk
+// (zeros for the tap that does not exist).  One thread per 16-byte piece.
+__global__ void __launch_bounds__(256) pack_fragments_g16_kernel(const unsigned short* src_base, const iif_pack_desc* tab, int n_desc,
+                                                                 unsigned short* dst_base) {
+    const int b = blockIdx.x;
+    int lo = 0, hi = n_desc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].block_start <= b) lo = mid; else hi = mid - 1;
+    }
+    const iif_pack_desc d = tab[lo];
+    const int64_t piece = (int64_t)(b - d.block_start) * 256 + threadIdx.x;
+    const int64_t pieces = (int64_t)(d.rows / 64) * 20 * 64;
+    if (piece >= pieces) return;
+    const int lane = (int)(piece & 63);
+    int64_t f = piece >> 6;
+    const int pr = (int)(f % 5); f /= 5;
+    const int ci = (int)(f % 4);
+    const int chunk = (int)(f / 4);
+    const int row = chunk * 64 + ci * 16 + (lane & 15);
+    const int tap = 2 * pr + (lane >> 5), k0 = ci * 16 + ((lane >> 4) & 1) * 8;
+    u32x4 v{0u, 0u, 0u, 0u};
+    if (tap < d.taps) v = *reinterpret_cast<const u32x4*>(src_base + d.src_off + (int64_t)row * d.ld + tap * d.k + k0);
     *reinterpret_cast<u32x4*>(dst_base + d.dst_off + piece * 8) = v;
 }
 
@@ -1830,6 +1911,12 @@ int launch_one(ConvArgs a, bool utap, int64_t src_bytes, int64_t wgt_bytes, hipS
         if (const int rc = claim_partial_rows(a)) return rc;
         const int64_t blocks2 = (int64_t)((a.mtiles + 7) / 8) * 8 * a.ntiles;
         if (blocks2 > 0x7fffffff) return IIF_EUNSUPPORTED;
+        if (a.wfrag_kind == 1) {
+            if (a.Cs != 64 || a.Cd != 64) return IIF_EINVAL;       // (the 16-channel format describes 64-channel chunks)
+            hipLaunchKernelGGL(conv3x3_g16_kernel, dim3((unsigned)blocks2, (unsigned)a.groups), dim3(256), 0, st, a, (unsigned)src_bytes);
+            IIF_LAUNCH_CHECK();
+            return IIF_OK;
+        }
         hipLaunchKernelGGL(conv3x3_v2n64_kernel, dim3((unsigned)blocks2, (unsigned)a.groups), dim3(256), 0, st, a, (unsigned)src_bytes);
         IIF_LAUNCH_CHECK();
         return IIF_OK;
@@ -2094,6 +2181,16 @@ extern "C" int iif_conv_pack_fragments(const void* src_base, const iif_pack_desc
     return IIF_OK;
 }
 
+extern "C" int iif_conv_pack_fragments_g16(const void* src_base, const iif_pack_desc* table, int n_desc, int total_blocks,
+                                           void* dst_base, void* stream) {
+    if (!src_base || !table || !dst_base || n_desc <= 0 || total_blocks <= 0) return IIF_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(src_base) | reinterpret_cast<uintptr_t>(dst_base)) & 15) return IIF_EUNSUPPORTED;
+    hipLaunchKernelGGL(pack_fragments_g16_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream),
+                       (const unsigned short*)src_base, table, n_desc, (unsigned short*)dst_base);
+    IIF_LAUNCH_CHECK();
+    return IIF_OK;
+}
+
 extern "C" int iif_conv3x3_frag_ok(const iif_conv_desc* d) {
     if (!d || g_sw.no_v2 || g_sw.regstage) return 0;
     if (d->dtype != IIF_BF16 || d->dst_dtype != IIF_BF16 || d->r != 3 || d->s != 3 || d->stride != 1 || d->pad != 1) return 0;
@@ -2271,6 +2368,7 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
     a.src = (const unsigned char*)src; a.wgt = (const unsigned char*)wgt; a.dst = (unsigned char*)dst;
     a.res = (const unsigned char*)res; a.bias = bias;
     a.wfrag = (const unsigned char*)d->wgt_frag;
+    a.wfrag_kind = d->wgt_frag ? d->wgt_frag_kind : 0;
     a.res_bits = res_bits;
     a.bn_partial = nullptr;
     if (n_partials) *n_partials = 0;

@@ -10,8 +10,13 @@ from ._lib import ConvDesc, check, dtype_code, lib, ptr, require_gpu, stream_ptr
 
 
 def _desc(n, hs, ws, cs, hd, wd, cd, r, s, stride, pad, transposed, ldw, dtype, dst_dtype, groups=1, w_frag=None):
+    """``w_frag``: the weights as MFMA fragments - a tensor (iif_conv_pack_fragments' format) or ``(tensor, 1)`` for the grouped
+    16-channel format of iif_conv_pack_fragments_g16."""
+    kind = 0
+    if isinstance(w_frag, tuple):
+        w_frag, kind = w_frag
     return ConvDesc(n, hs, ws, cs, hd, wd, cd, r, s, stride, pad, transposed, ldw, dtype, dst_dtype, groups,
-                    ptr(w_frag) if w_frag is not None else None)
+                    ptr(w_frag) if w_frag is not None else None, kind)
 
 
 def conv_out_hw(h, w, r, s, stride, pad):
@@ -437,6 +442,24 @@ def pack_table(entries, device):
         blob += struct.pack("<qqiiiiii", so, do, rows, taps, k, ld, start, 0)
         start += (rows * taps * k // 8 + 255) // 256
     return torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device), start
+
+
+def pack_table_g16(entries, device):
+    """entries: [(src_off, dst_off, rows, taps, k, ld)] of grouped layers (k = 64, taps = 9) for iif_conv_pack_fragments_g16:
+    20 fragments of 1 KB per 64-channel chunk, four fragments per block."""
+    import struct
+    blob, start = b"", 0
+    for (so, do, rows, taps, k, ld) in entries:
+        blob += struct.pack("<qqiiiiii", so, do, rows, taps, k, ld, start, 0)
+        start += (rows // 64) * 5
+    return torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device), start
+
+
+def pack_fragments_g16(src, table, n_desc, total_blocks, out):
+    require_gpu(src, out, table)
+    check(lib().iif_conv_pack_fragments_g16(ptr(src), ptr(table), n_desc, total_blocks, ptr(out), stream_ptr()),
+          "iif_conv_pack_fragments_g16")
+    return out
 
 
 def pack_fragments(src, table, n_desc, total_blocks, out):

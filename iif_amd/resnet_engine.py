@@ -1015,10 +1015,16 @@ class _Plan(object):
         # grouped 3x3 / stride-1 layers (ResNeXt): the block-diagonal chunk matrices move into ONE arena so that one more pack
         # launch per step turns them into fragments too; the fragment kernel then takes blockIdx.y as the chunk
         self.gfrag = None
+        self.g16frag = None
         gunits = [u for u in self.units if u.groups > 1]
         if gunits and self.dt == torch.bfloat16 and not os.environ.get("IIF_CONV_NO_V2"):
             gw = torch.empty(sum(u.w.numel() + u.wt.numel() for u in gunits), dtype=self.dt, device=self.dev)
             entries, off, foff = [], 0, 0
+            # round 6: groups of <= 16 channels (ResNeXt 32x4d at 56 / 28 / 14: 4 / 8 / 16 per group) take the 16-channel fragment
+            # format - K of an MFMA = two taps x the output tile's own 16 input channels, 80 MFMAs per wave and tile instead of 288
+            # (csrc/conv_igemm.hip, conv3x3_v2_body<..., G16>); 20 KB of fragments per 64-channel chunk and orientation
+            g16_entries, g16_off = [], 0
+            no_g16 = bool(os.environ.get("IIF_NO_G16"))
             for u in gunits:
                 cv = u.conv
                 nw = u.w.numel()
@@ -1027,12 +1033,27 @@ class _Plan(object):
                 u.wt = gw[owt:owt + nw].view(u.wt.shape)
                 off += 2 * nw
                 ok = cv.k == 3 and cv.stride == 1 and cv.pad == 1 and cv.chunk == 64 and cv.cin == cv.cout
+                if (ok and not no_g16 and cv.cg <= 16 and 16 % cv.cg == 0
+                        and ops.conv3x3_frag_ok(u.n, u.hi, u.wi, 64, 64, self.dt, groups=u.groups)):
+                    per = (cv.cout // 64) * 20 * 512                      # bf16 elements of one orientation's fragments
+                    g16_entries.append((ow, g16_off, cv.cout, 9, 64, u.w.shape[1]))
+                    g16_entries.append((owt, g16_off + per, cv.cin, 9, 64, u.wt.shape[1]))
+                    u.wf, u.wtf = ("g16", g16_off), ("g16", g16_off + per)
+                    g16_off += 2 * per
+                    continue
                 if ok and ops.conv3x3_frag_ok(u.n, u.hi, u.wi, 64, 64, self.dt, groups=u.groups):
                     entries.append((ow, foff, cv.cout, 9, 64, u.w.shape[1]))
                     entries.append((owt, foff + nw, cv.cin, 9, 64, u.wt.shape[1]))
                     u.wf, u.wtf = foff, foff + nw
                     foff += 2 * nw
             self.gw_arena = gw
+            self.g16frag = None
+            if g16_entries:
+                self.g16_arena = torch.empty(g16_off, dtype=self.dt, device=self.dev)
+                for u in gunits:
+                    if isinstance(u.wf, tuple) and u.wf[0] == "g16":
+                        u.wf, u.wtf = (self.g16_arena[u.wf[1]:], 1), (self.g16_arena[u.wtf[1]:], 1)
+                self.g16frag = ops.pack_table_g16(g16_entries, self.dev) + (len(g16_entries),)
             if entries:
                 self.gfrag_arena = torch.empty(foff, dtype=self.dt, device=self.dev)
                 for u in gunits:
@@ -1110,11 +1131,13 @@ class _Plan(object):
             ops.pack_fragments(self.lp_arena, self.frag_fwd[0], self.frag_fwd[2], self.frag_fwd[1], self.frag_arena)
         # grouped layers: block-diagonal chunk weights, both orientations, ONE launch (the fragment table packs both, so the
         # transposed chunks are filled in evaluation too)
-        tab = self._group_pack_table(need_transposed or self.gfrag is not None)
+        tab = self._group_pack_table(need_transposed or self.gfrag is not None or getattr(self, "g16frag", None) is not None)
         if tab is not None:
             ops.group_pack_batched(tab)
         if self.gfrag is not None:
             ops.pack_fragments(self.gw_arena, self.gfrag[0], self.gfrag[2], self.gfrag[1], self.gfrag_arena)
+        if getattr(self, "g16frag", None) is not None:
+            ops.pack_fragments_g16(self.gw_arena, self.g16frag[0], self.g16frag[2], self.g16frag[1], self.g16_arena)
         head = net._head
         if self.head_kind == "linear":
             return

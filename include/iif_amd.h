@@ -140,6 +140,9 @@ typedef struct iif_conv_desc {
                              /* (iif_conv_pack_fragments); used by the 3x3 / stride-1   */
                              /* kernel where iif_conv3x3_frag_ok(d) says so, ignored    */
                              /* elsewhere.  wgt must be valid either way.               */
+    int32_t wgt_frag_kind;   /* 0: iif_conv_pack_fragments' format.  1 (round 6): the  */
+                             /* grouped 16-channel format of iif_conv_pack_fragments_g16 */
+                             /* (groups > 1, cs = cd = 64, every group <= 16 channels). */
 } iif_conv_desc;
 
 /* Implicit-GEMM convolution on the matrix cores:
@@ -416,6 +419,13 @@ typedef struct iif_pack_desc {
 int iif_conv_pack_fragments(const void* src_base, const iif_pack_desc* table, int n_desc, int total_blocks, void* dst_base,
                             void* stream);
 int iif_conv3x3_frag_ok(const iif_conv_desc* d);
+/* Round 6, ResNeXt's narrow groups (resnet_pytorch.py:137,141 with groups = 32, base width 4: 4 / 8 / 16 channels per group): the
+ * block-diagonal 64-channel chunk matrices of iif_group_pack re-packed as 20 fragments per chunk (4 output tiles x 5 tap PAIRS:
+ * K of an MFMA = two taps x the tile's own 16 input channels), for iif_conv_desc.wgt_frag with wgt_frag_kind = 1.  Table entries
+ * as for iif_conv_pack_fragments (rows = channels of the layer, taps = 9, k = 64, ld = row pitch of the chunk matrix); one
+ * 256-thread block per 4 fragments: blocks of an entry = ceil(rows / 64 * 20 / 4).  Valid where every group is <= 16 channels wide. */
+int iif_conv_pack_fragments_g16(const void* src_base, const iif_pack_desc* table, int n_desc, int total_blocks, void* dst_base,
+                                void* stream);
 
 /* Batch-norm backward through the expanding 1x1 convolution of a bottleneck (conv3 -> bn3 -> += identity -> relu,
  * classification/resnet_pytorch.py:160-167) WITHOUT re-reading the convolution's output y = a2 W^T.  BN backward is affine per

@@ -1060,7 +1060,8 @@ def test_dgrad_masksum_with_the_upstream_output_recomputed(case, with_res):
     assert torch.equal(p1[:nt1], p2[:nt2])
 
 
-@pytest.mark.parametrize("case", [(4, 128, 14, 14, 32), (2, 256, 28, 28, 32), (1, 512, 7, 7, 32), (3, 64, 9, 11, 8)],
+@pytest.mark.parametrize("case", [(4, 128, 14, 14, 32), (2, 256, 28, 28, 32), (1, 512, 7, 7, 32), (3, 64, 9, 11, 8), (2, 512, 14, 14, 32),
+                                  (1, 128, 56, 56, 32)],
                          ids=lambda c: "n%d_w%d_%dx%d_g%d" % c)
 def test_grouped_conv3x3_on_the_fragment_kernel(case, conv_env):
     """ResNeXt's grouped 3x3 / stride 1 on the fragment-weights kernel (blockIdx.y = 64-channel chunk): forward with fused
@@ -1086,6 +1087,14 @@ def test_grouped_conv3x3_on_the_fragment_kernel(case, conv_env):
     conv_env(IIF_CONV_V2_FORCE="1")
     assert ops.conv3x3_frag_ok(n, h, w, 64, 64, dt, groups=G)
     wf, wtf = _pack_frag(wp, width, 9, 64), _pack_frag(wpt, width, 9, 64)
+    modes = ["tile", "frag"]
+    if cg <= 16 and 16 % cg == 0:
+        # round 6: the 16-channel format (K of an MFMA = two taps x the output tile's own 16 input channels) for narrow groups
+        def pack16(w2d):
+            tab, blocks = ops.pack_table_g16([(0, 0, width, 9, 64, w2d.shape[1])], DEV)
+            return ops.pack_fragments_g16(w2d, tab, 1, blocks, torch.empty(width // 64 * 20 * 512, dtype=w2d.dtype, device=DEV))
+        g16f, g16t = (pack16(wp), 1), (pack16(wpt), 1)
+        modes.append("g16")
     dy = torch.randn(n, h, w, width, generator=g).to(dt).to(DEV)
     res = torch.randn(n, h, w, width, generator=g).to(dt).to(DEV)
     rbits = torch.randint(0, 256, (m * width // 8,), dtype=torch.uint8, generator=g).to(DEV)
@@ -1095,8 +1104,8 @@ def test_grouped_conv3x3_on_the_fragment_kernel(case, conv_env):
     stats[0] = torch.randn(width, generator=g) * 0.1
     stats[1] = torch.rand(width, generator=g) + 0.5
     out = {}
-    for mode in ("tile", "frag"):
-        f, ft = (wf, wtf) if mode == "frag" else (None, None)
+    for mode in modes:
+        f, ft = (wf, wtf) if mode == "frag" else ((g16f, g16t) if mode == "g16" else (None, None))
         y = torch.full((n, h, w, width), float("nan"), dtype=dt, device=DEV)
         p = torch.full(((m + 127) // 128 + 8, 2, width), float("nan"), device=DEV)
         nt = ops.conv_forward_bnstats(x, wp, 3, 3, 1, 1, y, p.view(-1), groups=G, w_frag=f)
@@ -1105,10 +1114,14 @@ def test_grouped_conv3x3_on_the_fragment_kernel(case, conv_env):
         p2 = torch.full(((m + 127) // 128 + 8, 2, width), float("nan"), device=DEV)
         nt2 = ops.conv_dgrad_bnbwd(dy, wpt, 3, 3, 1, 1, (h, w), dx2, upx, ubits, stats.to(DEV), p2.view(-1), groups=G, w_frag=ft)
         out[mode] = (y, p[:nt].sum(0).cpu(), dx, dx2, p2[:nt2].sum(0).cpu())
-    for i in (0, 2, 3):
-        a_, b_ = out["frag"][i].float(), out["tile"][i].float()
-        assert not torch.isnan(a_).any()
-        assert (a_ - b_).abs().max().item() <= 2.0 ** -6 * b_.abs().max().item()
+    for mode in modes[1:]:
+        for i in (0, 2, 3):
+            a_, b_ = out[mode][i].float(), out["tile"][i].float()
+            assert not torch.isnan(a_).any()
+            assert (a_ - b_).abs().max().item() <= 2.0 ** -6 * b_.abs().max().item(), (mode, i)
+        for i in (1, 4):
+            a_, b_ = out[mode][i], out["tile"][i]
+            assert (a_ - b_).abs().max().item() <= 2e-3 * max(1.0, b_.abs().max().item()), (mode, i)
     yf = out["frag"][0].float().cpu().view(m, width)
     s = out["frag"][1]
     assert (s[0] - yf.sum(0)).abs().max().item() <= 1e-3 * max(1.0, yf.sum(0).abs().max().item())
