@@ -12,6 +12,16 @@
 // one XCD and share the activation tile through that L2.  Accumulation order over K is the tile kernel's (K steps of 32,
 // ascending): the stored values are bit-identical to it.
 #include "common.h"
+// Tile stores of the 1x1 kernels: a wave owns CW = 16 / 32 columns, i.e. 32 / 64 bytes of a row - HALF or a QUARTER of a 128-byte
+// line per store, the rest of the line coming from the neighbouring waves a little later.  As nontemporal (streaming) stores those
+// pieces left the L2 before they met: WRITE_SIZE read 1.2x (CW = 32) to 1.5x (CW = 16) the bytes of the tensor, 1.2 GB per step
+// (profiles/r6_e_hbm_per_launch.txt against r6_d); as plain write-back stores the L2 joins them: exact bytes, 5-25 % off the
+// kernels' alone time.  -DIIF_REGW_NT_STORE: the round-5 form.
+#ifdef IIF_REGW_NT_STORE
+#define IIF_REGW_ST(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define IIF_REGW_ST(v, p) (*(p) = (v))
+#endif
 
 namespace {
 typedef __attribute__((address_space(3))) void lds_void;
@@ -313,7 +323,7 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
                     v[q] = pack_bf16x2(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
                 }
                 const size_t ob = ((size_t)row * a.dpitch + chunk * 8) * 2;
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dcol + ob));
+                IIF_REGW_ST(v, reinterpret_cast<u32x4*>(dcol + ob));
                 a.relu_out[(((size_t)tile * MT * a.dpitch + n0) * 2 + ob) >> 4] = (unsigned char)bits;
             } else if constexpr (DG) {                  // (the arithmetic of staged_drain, element for element)
                 if (has_res) {
@@ -336,7 +346,7 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
                         if (!has_bx && !RX) { bs[2 * q] += bf16_bits_to_f32(lo); bs[2 * q + 1] += __uint_as_float(hi); }
                     }
                 }
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dcol + ((size_t)row * a.dpitch + chunk * 8) * 2));
+                IIF_REGW_ST(v, reinterpret_cast<u32x4*>(dcol + ((size_t)row * a.dpitch + chunk * 8) * 2));
                 if constexpr (RX) {
                     gv[k] = v;                          // meets the recomputed x below
                 } else if (has_bx) {
@@ -359,7 +369,7 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
                     }
                 }
             } else {
-                if (!a.no_store) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dcol + ((size_t)row * a.dpitch + chunk * 8) * 2));
+                if (!a.no_store) IIF_REGW_ST(v, reinterpret_cast<u32x4*>(dcol + ((size_t)row * a.dpitch + chunk * 8) * 2));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float lo = bf16_bits_to_f32(v[q] & 0xffffu), hi = __uint_as_float(v[q] & 0xffff0000u);
@@ -489,18 +499,25 @@ static bool regw_plan(int K, int N, bool epi, int* cw, int* mt) {
     if (K == 64 && N == 256 && epi) { *cw = 32; *mt = 64; return true; }
     if (K == 128 && N == 512) { *cw = epi ? 32 : 64; *mt = 64; return true; }
     if (K == 256 && N == 1024) { *cw = 32; *mt = 64; return true; }
-    if (K == 512 && N == 2048 && !epi) { *cw = 16; *mt = 64; return true; }       // (with epilogue operands: 77 against 69 us)
+    // K = 512: 32 columns per wave with 32-row tiles (64-row tiles do not fit the LDS beside the staging buffers): half the
+    // LDS-DMA bytes per flop of the 16-column form, which is what bounds these launches (IIF_REGW_K512_CW16: the round-5 form)
+    static const bool k512_cw16 = getenv("IIF_REGW_K512_CW16") != nullptr;
+    // (with epilogue operands at 7 x 7, M = 12 544: 77 against 69 us with 16 columns, +0.05 ms per step with 32 - the tile kernel keeps it)
+    if (K == 512 && N == 2048 && !epi) { *cw = k512_cw16 ? 16 : 32; *mt = k512_cw16 ? 64 : 32; return true; }
     // (the wide -> narrow shapes are level with the tile kernels alone, 59.3 / 60.1 and 43.1 / 42.8 us, and level to +0.05 ms in the step)
     // ResNeXt's conv3 (width -> 2 x width; resnet_pytorch.py:141-143 with groups 32, base width 4): the same kernels, fewer slices
     static const bool no_x2 = getenv("IIF_REGW_NO_X2") != nullptr;      // read once, like every other switch
     if (!no_x2) {
         if (K == 128 && N == 256) { *cw = 32; *mt = 64; return true; }
         if (K == 256 && N == 512) { *cw = 32; *mt = 64; return true; }
-        if (K == 512 && N == 1024 && !epi) { *cw = 16; *mt = 64; return true; }
+        // (the data-gradient epilogue too - ResNeXt-101's 23 producers at 14 x 14: 21.09 -> 20.94 ms; IIF_REGW_K512_NO_EPI: off)
+        static const bool k512_no_epi = getenv("IIF_REGW_K512_NO_EPI") != nullptr;
+        if (K == 512 && N == 1024 && (!epi || !k512_no_epi)) { *cw = k512_cw16 && !epi ? 16 : 32; *mt = k512_cw16 && !epi ? 64 : 32; return true; }
         if (K == 1024 && N == 2048 && !epi) { *cw = 16; *mt = 32; return true; }
     }
     if (K == 512 && N == 128 && !epi) { *cw = 16; *mt = 64; return true; }
     if (K == 1024 && N == 256 && !epi) { *cw = 16; *mt = 32; return true; }
+    // (1024 -> 512, ResNeXt-101's conv1 / conv3 data gradient at 14 x 14: level forward, +0.1 ms with the epilogue; tile kernels keep them)
     return false;
 }
 
@@ -521,7 +538,7 @@ bool iif_regw1x1_ok(int M, int K, int N, int epi) {
 bool iif_regw1x1_pro_ok(int M, int K, int N) {
     int cw = 0, mt = 0;
     if (!iif_regw1x1_ok(M, K, N, 0) || !regw_plan(K, N, false, &cw, &mt)) return false;
-    return M >= 1024 && ((K == 256 && cw == 32) || (K == 512 && cw == 16)) && mt == 64;
+    return M >= 1024 && ((K == 256 && cw == 32 && mt == 64) || (K == 512 && ((cw == 16 && mt == 64) || (cw == 32 && mt == 32))));
 }
 
 int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
@@ -575,14 +592,17 @@ int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_pa
     } else if (epi) {
         if (K == 64) IIF_REGW(64, 32, 64, 1);
         else if (K == 128) IIF_REGW(128, 32, 64, 1);
-        else IIF_REGW(256, 32, 64, 1);
+        else if (K == 256) IIF_REGW(256, 32, 64, 1);
+        else IIF_REGW(512, 32, 32, 1);
     } else if (pro) {
         if (K == 256) hipLaunchKernelGGL((gemm1x1_regw_kernel<256, 32, 64, 0, 0, true>), g, b, 0, st, a, sb);
+        else if (cw == 32) hipLaunchKernelGGL((gemm1x1_regw_kernel<512, 32, 32, 0, 0, true>), g, b, 0, st, a, sb);
         else hipLaunchKernelGGL((gemm1x1_regw_kernel<512, 16, 64, 0, 0, true>), g, b, 0, st, a, sb);
     } else {
         if (K == 128 && cw == 64) IIF_REGW(128, 64, 64, 0);
         else if (K == 128) IIF_REGW(128, 32, 64, 0);
         else if (K == 256) IIF_REGW(256, 32, 64, 0);
+        else if (K == 512 && cw == 32) IIF_REGW(512, 32, 32, 0);
         else if (K == 512) IIF_REGW(512, 16, 64, 0);
         else IIF_REGW(1024, 16, 32, 0);
     }
@@ -841,7 +861,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_regw64_kernel(Regw3Args a, uns
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(stage + (vrow + 32 * i) * PITCH + vchunk * 16);
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + vo[i]));
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.dst + vo[i]));      // (whole 128-byte lines: streamed)
             if (EPI && has_bx) {
                 const unsigned mb = has_bb ? ob[i] : 0xffu;
                 float bmean[8], bistd[8];

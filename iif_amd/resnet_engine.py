@@ -846,6 +846,10 @@ class _Plan(object):
         # output, normalises each tile in LDS and writes a2 / its ReLU bits / its column sums as by-products: one launch and one pass
         # over a2 less per bottleneck.  pro_units: conv3 unit -> (conv2 unit, rows of column sums or None).  IIF_NO_PROLOGUE=1: off.
         self.pro_units = {}
+        # (K = 512 - the 7 x 7 stage, ResNeXt-101's 14 x 14 one - stays with the separate bn_apply launch: every N slice of the
+        # register-weight kernel normalises the whole [rows x K] tile again, 22 us on top of a 39 us launch against a 10 us bn_apply;
+        # ResNeXt-101 21.28 -> 21.14 ms, ResNet-50 level, profiles/r6_ab.txt ab11)
+        pro_max_k = int(os.environ.get("IIF_PRO_MAX_K", "256"))
         if dt == torch.bfloat16 and net._sync_bn is None and not os.environ.get("IIF_NO_PROLOGUE"):
             for b in self.blocks:
                 if "se" in b or len(b["units"]) != 3:
@@ -853,6 +857,8 @@ class _Plan(object):
                 u2, u3 = b["units"][1], b["units"][2]
                 cv3 = u3.conv
                 if not (cv3.k == 1 and cv3.stride == 1 and cv3.groups == 1 and _dma_ok(u2.x)) or u3 in self.twopass_units:
+                    continue
+                if cv3.cin > pro_max_k:
                     continue
                 if ops.conv_pro_ok(u3.n, u3.ho, u3.wo, cv3.cin, cv3.cout, dt, u3 in self.nostore_units):
                     rows = None

@@ -21,6 +21,7 @@ echo "fetch done" >> $out/progress.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d /tmp/p_w -- python3 $BENCH --steps 4 --warmup 2 > $out/w.log 2>&1
 echo "write done" >> $out/progress.txt
 python3 $root/scripts/rocpd_hbm.py $(find /tmp/p_f -name "*.db" | head -1) $(find /tmp/p_w -name "*.db" | head -1) 6 $out/${tag}_pmc_hbm_traffic.csv
+python3 $root/scripts/rocpd_hbm_listing.py $(find /tmp/p_f -name "*.db" | head -1) $(find /tmp/p_w -name "*.db" | head -1) $out/${tag}_hbm_per_launch.txt
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format rocpd -d /tmp/p_m -- python3 $BENCH --steps 4 --warmup 2 > $out/m.log 2>&1
 python3 $root/scripts/rocpd_mfma.py $(find /tmp/p_m -name "*.db" | head -1) 6 $out/${tag}_pmc_mfma_util.csv
 echo "all done" >> $out/progress.txt

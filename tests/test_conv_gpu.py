@@ -844,7 +844,8 @@ def test_bn3_backward_by_algebra(case, from_p):
 
 @pytest.mark.parametrize("case", [(2, 14, 64, 256), (3, 11, 128, 512),
                                   # M % 64 == 0: the weights-in-registers kernel (conv_regw.hip, EPI), one to sixteen N slices
-                                  (4, 16, 64, 256), (8, 16, 128, 512), (4, 32, 256, 1024), (16, 16, 512, 2048), (33, 32, 128, 512)],
+                                  (4, 16, 64, 256), (8, 16, 128, 512), (4, 32, 256, 1024), (16, 16, 512, 2048), (33, 32, 128, 512),
+                                  (8, 16, 512, 1024), (5, 32, 512, 1024)],      # ResNeXt-101's 14 x 14 producer: the K = 512 instance
                          ids=lambda c: "%dx%dx%d_%d_%d" % (c[0], c[1], c[1], c[2], c[3]))
 def test_dgrad_masked_store_and_column_sums(case):
     """iif_conv_igemm_dgrad_masksum: the conv1 data gradient (+ ReLU-gated residual) stored already gated by the upstream
