@@ -546,6 +546,7 @@ def main():
             timer.active = it % max(args.event_every, 1) == 0
             timer.sampled_steps += 1 if timer.active else 0
         loss = step(args.warmup + it)
+    t_enq = time.perf_counter() - t0          # the host is done enqueueing (close to dt: the step is bound by the host's launch rate)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -570,6 +571,7 @@ def main():
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 3),
+            "host_enqueue_ms_per_step": round(1000.0 * t_enq / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if cdt == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {"workload": "%s + IIF(raw) training step, synthetic long-tailed %dx%d, C=%d (counts %d..5), "
