@@ -71,7 +71,7 @@ class ConvTimer(object):
         orig = {k: getattr(ops, k) for k in ("conv_forward", "conv_dgrad", "conv_wgrad", "conv_forward_bnstats",
                                              "conv_dgrad_bnbwd", "conv_dgrad_masksum", "conv_dgrad2_bnbwd", "wgrad1x1_stacked",
                                              "conv_forward_stats_acc", "conv_forward_bn_relu2", "conv_dgrad_masksum_rx",
-                                             "conv_forward_bnstats_pro")}
+                                             "conv_forward_bnstats_pro", "conv_dgrad_masksum_rx_pg")}
 
         def alg_k(r, s, stride, pad, cin):
             # algorithmic K of one output: the space-to-depth stem (4x4/1 pad 2 on 16 padded channels) is charged
@@ -135,6 +135,15 @@ class ConvTimer(object):
             by = nbytes(dy, wt, kw.get("res"), out, up_a2, up_w3)
             return timer._timed("dgrad", fl, by, orig["conv_dgrad_masksum_rx"], dy, wt, in_hw, out, up_bits, partial, up_a2, up_w3, up_stats, **kw)
 
+        def conv_dgrad_masksum_rx_pg(dy, wt, in_hw, out, up_bits, partial, up_a2, up_w3, up_stats, pg_slabs, pg_ld, **kw):
+            # ... that also leaves P = g~^T a2 (the upstream conv3's weight-gradient GEMM: its FLOPs are charged here, to this
+            # launch's kind) and Gram behind; bytes: as above plus the fp32 slabs it writes (one per resident block)
+            n, ho, wo, cout = dy.shape
+            fl = 2.0 * n * ho * wo * cout * wt.shape[0] + 2.0 * n * ho * wo * up_a2.shape[3] * wt.shape[0]
+            by = nbytes(dy, wt, kw.get("res"), out, up_a2, up_w3) + 256 * (wt.shape[0] + up_a2.shape[3]) * pg_ld * 4
+            return timer._timed("dgrad", fl, by, orig["conv_dgrad_masksum_rx_pg"], dy, wt, in_hw, out, up_bits, partial, up_a2, up_w3, up_stats,
+                                pg_slabs, pg_ld, **kw)
+
         def conv_dgrad2_bnbwd(src, src2, wt, bias, out, *a, **kw):
             # the data gradient of conv3 with BN3's backward folded into the weights: charged the FLOPs of the plain
             # data gradient (K = src's channels); the second K source is overhead of the design, its bytes are counted
@@ -170,6 +179,7 @@ class ConvTimer(object):
         ops.conv_forward_bnstats_pro = conv_forward_bnstats_pro
         ops.conv_forward_stats_acc, ops.conv_forward_bn_relu2 = conv_forward_stats_acc, conv_forward_bn_relu2
         ops.conv_dgrad_masksum_rx = conv_dgrad_masksum_rx
+        ops.conv_dgrad_masksum_rx_pg = conv_dgrad_masksum_rx_pg
         ops.wgrad1x1_stacked = wgrad1x1_stacked
         ops.conv_forward, ops.conv_dgrad, ops.conv_wgrad = conv_forward, conv_dgrad, conv_wgrad
         ops.conv_dgrad_masksum, ops.conv_dgrad2_bnbwd = conv_dgrad_masksum, conv_dgrad2_bnbwd

@@ -86,6 +86,9 @@ SIGNATURES = {
     "iif_conv_igemm_bnstats_pro": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "iif_conv_dgrad_rx_ok": [_P, _I],
     "iif_conv_igemm_dgrad_masksum_rx": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _L, _P, _P],
+    "iif_conv_dgrad_rx_pg_ok": [_P, _I],
+    "iif_conv_igemm_dgrad_masksum_rx_pg": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _L, _P, _P, _L, _I, _P, _P],
+    "iif_slab_sum": [_P, _L, _I, _I, _I, _I, _P, _P],
     "iif_conv_igemm_dgrad2_bnbwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "iif_bn3_algebra_prep": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _P],
     "iif_bn3_algebra_prep_scratch_floats": [_I, _I],

@@ -63,6 +63,9 @@ struct iif_regw_epilogue {
     const void* res; const unsigned char* res_bits; const void* bw_x; const unsigned char* bw_bits; const float* bw_stats; int mask_store;
     // round 6: instead of bw_x, the operands it is recomputed from per tile: the upstream block's a2 [M, rx_k2] and its conv3 weights [N, rx_ldw3]
     const void* rx_src2; const void* rx_w3; int rx_k2, rx_ldw3;
+    // with rx_*: P = dst^T a2 and Gram = a2^T a2 as by-products, one fp32 slab [(N + rx_k2), pg_ld] per tile sequence (pg_cap floats
+    // available, *pg_count receives the slab count; iif_slab_sum adds them up).  nullptr: not produced.
+    float* pg_slab; long long pg_cap; int pg_ld; int* pg_count;
 };
 // round 6: `src` is the raw output of the previous convolution; its BN + ReLU (stats laid out as iif_bn_finalize_stats writes them) is
 // applied to each tile in LDS and the activation written out as a by-product (out [M, K] bf16, bits one byte per 16-byte vector;
@@ -70,6 +73,7 @@ struct iif_regw_epilogue {
 struct iif_regw_prologue { const float* stats; void* out; unsigned char* bits; float* csum; };
 bool iif_regw1x1_ok(int M, int K, int N, int epi);
 bool iif_regw1x1_rx_ok(int M, int K, int N, int k2);
+bool iif_regw1x1_pg_ok(int M, int K, int N, int k2);      // ... with the P / Gram by-product (one N slice, k2 = 64)
 bool iif_regw1x1_pro_ok(int M, int K, int N);
 int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_partial, long long bn_cap, int bn_row0, int* rows_out,
                        int M, int K, int N, int spitch, int ldw, int dpitch, const iif_regw_epilogue* e, int no_store, hipStream_t st,

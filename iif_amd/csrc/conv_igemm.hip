@@ -65,6 +65,8 @@ struct ConvArgs {
     //   rx_* (round 6, register-weight kernel only): the upstream x of the backward sums is recomputed per tile from the upstream
     //   block's a2 (rx_src2, [M, rx_k2]) and conv3 weights (rx_w3, [Cd, rx_ldw3]) instead of being read from bw_x.
     const unsigned char* rx_src2; const unsigned char* rx_w3; int rx_k2, rx_ldw3;
+    //   pg_* (round 6, with rx_*): P = dst^T a2 and Gram = a2^T a2 as by-products, one fp32 slab per tile sequence (iif_regw_epilogue)
+    float* pg_slab; long long pg_cap; int pg_ld; int* pg_count;
     //   pro_* (round 6, register-weight kernel only): src is the previous convolution's RAW output; its BN + ReLU (pro_stats) is applied
     //   per tile in LDS, the activation (pro_out, pro_bits; pro_csum nullable: column-sum rows) is written as a by-product.
     const float* pro_stats; unsigned char* pro_out; unsigned char* pro_bits; float* pro_csum;
@@ -2065,7 +2067,8 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
             a.Hs == a.Hd && a.Ws == a.Wd && !a.bias && !a.src2 && !a.sbias && !a.aff && (!epi || (a.bn_partial && !a.no_store)) &&
             iif_regw1x1_ok(a.M, a.Cs, a.Cd, epi))
         {
-            const iif_regw_epilogue e{a.res, a.res_bits, a.bw_x, a.bw_bits, a.bw_stats, a.mask_store, a.rx_src2, a.rx_w3, a.rx_k2, a.rx_ldw3};
+            const iif_regw_epilogue e{a.res, a.res_bits, a.bw_x, a.bw_bits, a.bw_stats, a.mask_store, a.rx_src2, a.rx_w3, a.rx_k2, a.rx_ldw3,
+                                      a.pg_slab, a.pg_cap, a.pg_ld, a.pg_count};
             const int rc = iif_regw1x1_launch(a.src, a.wgt, a.dst, a.bn_partial, a.bn_cap, a.bn_row0, a.rows_out, a.M, a.Cs, a.Cd, a.spitch,
                                               a.ldw, a.dpitch, epi ? &e : nullptr, a.no_store, st);
             if (rc != IIF_EUNSUPPORTED) return rc;
@@ -2164,7 +2167,8 @@ int launch_conv(const ConvArgs& a0, int64_t src_bytes, int64_t wgt_bytes, hipStr
 namespace {
 struct ConvExtra { int mask_store; const void* src2; int cs2; const float* sbias; int no_store; const float* aff; unsigned char* relu_out; const float* aff2;
                    const void* rx_src2; const void* rx_w3; int rx_k2, rx_ldw3;
-                   const float* pro_stats; void* pro_out; unsigned char* pro_bits; float* pro_csum; };
+                   const float* pro_stats; void* pro_out; unsigned char* pro_bits; float* pro_csum;
+                   float* pg_slab; long long pg_cap; int pg_ld; int* pg_count; };
 int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
                const unsigned char* res_bits, const float* bias, float* bn_partial, int64_t bn_partial_floats,
                int32_t* n_partials, void* stream, const void* bw_x = nullptr, const unsigned char* bw_bits = nullptr,
@@ -2244,6 +2248,27 @@ extern "C" int iif_conv_igemm_dgrad_masksum_rx(const iif_conv_desc* d, const voi
     if (!iif_conv_dgrad_rx_ok(d, up_c2) || ((reinterpret_cast<uintptr_t>(up_a2) | reinterpret_cast<uintptr_t>(up_w3)) & 15)) return IIF_EUNSUPPORTED;
     const ConvExtra ex{1, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, up_a2, up_w3, up_c2, up_ldw3, nullptr, nullptr, nullptr, nullptr};
     return conv_entry(d, src, wgt, dst, res, res_bits, nullptr, partial, partial_floats, n_partials, stream, nullptr, up_bits, up_stats, &ex);
+}
+
+extern "C" int iif_conv_dgrad_rx_pg_ok(const iif_conv_desc* d, int c2) {
+    if (!iif_conv_dgrad_rx_ok(d, c2)) return 0;
+    return iif_regw1x1_pg_ok(d->n * d->hd * d->wd, d->cs, d->cd, c2) ? 1 : 0;
+}
+
+extern "C" int iif_conv_igemm_dgrad_masksum_rx_pg(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                                                  const unsigned char* res_bits, const void* up_a2, int up_c2, const void* up_w3, int up_ldw3,
+                                                  const unsigned char* up_bits, const float* up_stats, float* partial, int64_t partial_floats,
+                                                  int32_t* n_partials, float* pg_slabs, int64_t pg_floats, int pg_ld, int32_t* n_slabs,
+                                                  void* stream) {
+    if (!d || !up_bits || !partial || !n_partials || !d->transposed || !up_a2 || !up_w3 || !up_stats || !pg_slabs || !n_slabs) return IIF_EINVAL;
+    if (res_bits && !res) return IIF_EINVAL;
+    if (!iif_conv_dgrad_rx_pg_ok(d, up_c2) || ((reinterpret_cast<uintptr_t>(up_a2) | reinterpret_cast<uintptr_t>(up_w3)) & 15)) return IIF_EUNSUPPORTED;
+    int count = 0;
+    const ConvExtra ex{1, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, up_a2, up_w3, up_c2, up_ldw3, nullptr, nullptr, nullptr, nullptr,
+                       pg_slabs, (long long)pg_floats, pg_ld, &count};
+    const int rc = conv_entry(d, src, wgt, dst, res, res_bits, nullptr, partial, partial_floats, n_partials, stream, nullptr, up_bits, up_stats, &ex);
+    *n_slabs = count;
+    return rc;
 }
 
 extern "C" int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* src, const void* src2, int cs2, const void* wgt,
@@ -2391,6 +2416,7 @@ int conv_entry(const iif_conv_desc* d, const void* src, const void* wgt, void* d
         a.no_store = ex->no_store; a.aff = ex->aff; a.relu_out = ex->relu_out; a.aff2 = ex->aff2;
         a.rx_src2 = (const unsigned char*)ex->rx_src2; a.rx_w3 = (const unsigned char*)ex->rx_w3; a.rx_k2 = ex->rx_k2; a.rx_ldw3 = ex->rx_ldw3;
         a.pro_stats = ex->pro_stats; a.pro_out = (unsigned char*)ex->pro_out; a.pro_bits = ex->pro_bits; a.pro_csum = ex->pro_csum;
+        a.pg_slab = ex->pg_slab; a.pg_cap = ex->pg_cap; a.pg_ld = ex->pg_ld; a.pg_count = ex->pg_count;
     }
     a.N = d->n; a.Hs = d->hs; a.Ws = d->ws; a.Cs = d->cs; a.Hd = d->hd; a.Wd = d->wd; a.Cd = d->cd;
     a.R = d->r; a.S = d->s; a.sshift = d->stride - 1; a.pad = d->pad; a.transposed = d->transposed ? 1 : 0;

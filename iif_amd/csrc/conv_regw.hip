@@ -46,7 +46,27 @@ struct RegwArgs {
     // out as a by-product (pro_out [M, K] bf16, pro_bits one byte per 16-byte vector) by slice 0: the bn_apply launch and one
     // pass over the activation disappear.  pro_csum (nullable): per sequence one row [2][K] (column sums of the activated tiles, zeros).
     const float* pro_stats; unsigned char* pro_out; unsigned char* pro_bits; float* pro_csum;
+    // PG (round 6, EPI 4 with one N slice and KK2 = 64): the two small matrices the algebraic BN3 backward of the UPSTREAM block needs
+    // come out of this launch - P = g~^T a2 ([Cd, KK2]: the block holds g~'s tile in its staging buffers and a2's in LDS) and
+    // Gram = a2^T a2 ([KK2, KK2]) - one fp32 slab [(Cd + KK2), pg_ld] per tile sequence (P rows first), summed afterwards in
+    // sequence order (iif_slab_sum): the stacked weight-gradient launch that re-read g~ and a2 (0.5 GB at 56 x 56) is not needed.
+    float* pg_slab; int pg_ld;
 };
+
+// transposing LDS read for the PG products (the discipline of conv_wgrad.hip: asm so that the compiler's wait-count pass does not
+// drain the LDS-DMA in flight in front of it; halves joined BEHIND the fence)
+typedef __attribute__((address_space(3))) const unsigned char lds_cu8r;
+__device__ __forceinline__ s16x4 tr_read_r(const unsigned char* p) {
+    s16x4 v;
+    const unsigned a = (unsigned)(unsigned long long)(lds_cu8r*)(p);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+struct TrPairR { s16x4 lo, hi; };
+__device__ __forceinline__ s16x8 tr_join_r(TrPairR& p) {
+    asm volatile("" : "+v"(p.lo), "+v"(p.hi));
+    return s16x8{p.lo.x, p.lo.y, p.lo.z, p.lo.w, p.hi.x, p.hi.y, p.hi.z, p.hi.w};
+}
 
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 2; }      // as conv_igemm.hip's swz: 64-byte LDS rows
 
@@ -57,9 +77,10 @@ __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 2; }      //
 // EPI 0: plain forward (+ sums of the stored tile); 1: the data-gradient epilogue; 2: the forward BN epilogue (pass 2 of the
 // two-pass forward); 3: statistics only, taken from the ACCUMULATORS (pass 1: no staging, no store; sums of the unrounded tile);
 // 4: EPI 1 with the upstream x recomputed from (src2, w3) over KK2 channels
-template <int KK, int CW, int MT, int EPI, int KK2 = 0, bool PRO = false>
+template <int KK, int CW, int MT, int EPI, int KK2 = 0, bool PRO = false, bool PG = false>
 __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsigned src_bytes) {
     constexpr bool RX = EPI == 4, DG = EPI == 1 || EPI == 4;
+    static_assert(!PG || (RX && KK2 == 64 && CW == 32 && MT % 32 == 0), "P / Gram by-product: one 64-channel second source");
     constexpr int VPR = KK / 8, NPV = PRO ? MT * VPR / 512 : 0;         // PRO: vectors per row of the tile, vectors per thread
     static_assert(!PRO || ((MT * VPR) % 512 == 0 && 512 % VPR == 0 && (EPI == 0 || EPI == 3)), "prologue shape");
     constexpr int NK2 = RX ? KK2 / 32 : 1, TILE2 = RX ? NK2 * MT * 64 : 0, NAP2 = RX ? NK2 * (MT / 16) / 8 : 0;
@@ -223,6 +244,15 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
 #pragma unroll
         for (int q = 0; q < 8; ++q) { pa[q] = a.pro_stats[2 * KK + pcv * 8 + q]; pb[q] = a.pro_stats[3 * KK + pcv * 8 + q]; }
     }
+    // PG: P^T tiles of this wave's 32 g~ columns x the 64 a2 channels, and two 16 x 16 tiles of Gram (row block wave & 3, column
+    // blocks 2 (wave >> 2) + {0, 1}); lane holds [column li][rows 4 g4 .. + 3] of a tile, i.e. four consecutive a2 channels of one row
+    f32x4 pacc[PG ? CB : 1][PG ? 4 : 1], gacc[PG ? 2 : 1];
+#pragma unroll
+    for (int cb = 0; cb < (PG ? CB : 1); ++cb)
+#pragma unroll
+        for (int nb = 0; nb < (PG ? 4 : 1); ++nb) pacc[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < (PG ? 2 : 1); ++j) gacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int buf = 0;
     // The first tile (and everything the prologue asked for) has landed; inside the loop the wait for the NEXT tile sits at the
     // bottom of the body, behind the stores it counts over (round 6: at the top behind a `first` flag before - two paths into the
@@ -349,6 +379,7 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
                 IIF_REGW_ST(v, reinterpret_cast<u32x4*>(dcol + ((size_t)row * a.dpitch + chunk * 8) * 2));
                 if constexpr (RX) {
                     gv[k] = v;                          // meets the recomputed x below
+                    if constexpr (PG) *reinterpret_cast<u32x4*>(stg + row * PITCH + chunk * 16) = v;      // g~ as stored, for P (same lane, same slot)
                 } else if (has_bx) {
                     const u32x4 xv = c_x[k];
 #pragma unroll
@@ -376,6 +407,48 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
                     bs[2 * q] += lo; bq[2 * q] = fmaf(lo, lo, bq[2 * q]);
                     bs[2 * q + 1] += hi; bq[2 * q + 1] = fmaf(hi, hi, bq[2 * q + 1]);
                 }
+            }
+        }
+        if constexpr (PG) {
+            // P^T += a2_tile^T g~_tile and Gram += a2_tile^T a2_tile over the tile's MT rows, 32 per MFMA: fragments by transposing
+            // reads (16 lanes fetch 4 rows x 16 columns; lane (q, p) supplies row 4 g4 + q, columns 4 p .. + 3) - g~ from this wave's
+            // staging slot (row-major, pitch PITCH), a2 from the tile's 32-channel slabs (64-byte rows, chunk ^ swz64(row))
+            const unsigned char* A2p = smem2 + buf * TILE2;
+            const int g4 = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+            const int gm = wave & 3, gh = wave >> 2;
+#pragma unroll
+            for (int kk = 0; kk < MT / 32; ++kk) {
+                TrPairR ap[CB], bp[4];
+                const int r0 = kk * 32 + 4 * g4 + tq, r1 = r0 + 16;
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const unsigned char* base = stg + r0 * PITCH + (cb * 16 + 4 * tp) * 2;
+                    ap[cb].lo = tr_read_r(base); ap[cb].hi = tr_read_r(base + 16 * PITCH);
+                }
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const int ch = nb * 16 + 4 * tp, ks = ch >> 5, chunk = (ch & 31) >> 3, within = (ch & 7) * 2;
+                    bp[nb].lo = tr_read_r(A2p + ks * SLAB + r0 * 64 + ((chunk ^ swz64(r0)) << 4) + within);
+                    bp[nb].hi = tr_read_r(A2p + ks * SLAB + r1 * 64 + ((chunk ^ swz64(r1)) << 4) + within);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                s16x8 af[CB], bf[4];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) af[cb] = tr_join_r(ap[cb]);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) bf[nb] = tr_join_r(bp[nb]);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        pacc[cb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[nb]), __builtin_bit_cast(bf16x8, af[cb]),
+                                                                              pacc[cb][nb], 0, 0, 0);
+                // Gram tile (row block gm, column block 2 gh + j): wave-uniform selects of the fragments already read
+                const s16x8 grow = gm == 0 ? bf[0] : (gm == 1 ? bf[1] : (gm == 2 ? bf[2] : bf[3]));
+                const s16x8 gc0 = gh == 0 ? bf[0] : bf[2], gc1 = gh == 0 ? bf[1] : bf[3];
+                gacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gc0), __builtin_bit_cast(bf16x8, grow), gacc[0], 0, 0, 0);
+                gacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gc1), __builtin_bit_cast(bf16x8, grow), gacc[1], 0, 0, 0);
             }
         }
         if constexpr (RX) {
@@ -459,6 +532,22 @@ __global__ void __launch_bounds__(512, 1) gemm1x1_regw_kernel(RegwArgs a, unsign
             }
         }
     }
+    if constexpr (PG) {
+        if (a.pg_slab != nullptr && seq < G) {
+            // lane holds P[n0 + cb 16 + li][nb 16 + 4 g4 .. + 3] and Gram[gm 16 + li][(2 gh + j) 16 + 4 g4 .. + 3]
+            const int g4 = lane >> 4, li = lane & 15;
+            float* const sl = a.pg_slab + (size_t)seq * (size_t)(a.Cd + KK2) * a.pg_ld;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    *reinterpret_cast<f32x4*>(sl + (size_t)(n0 + cb * 16 + li) * a.pg_ld + nb * 16 + 4 * g4) = pacc[cb][nb];
+            const int gm = wave & 3, gh = wave >> 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<f32x4*>(sl + (size_t)(a.Cd + gm * 16 + li) * a.pg_ld + (2 * gh + j) * 16 + 4 * g4) = gacc[j];
+        }
+    }
     if (a.bn_partial == nullptr || seq >= G) return;
     if constexpr (EPI == 3) {
         // rows of a channel sit on the 16 lanes that share fc: butterfly over fr, lane fr == 0 writes its four channels
@@ -528,6 +617,11 @@ bool iif_regw1x1_rx_ok(int M, int K, int N, int k2) {
     return pair && M >= 1024 && iif_regw1x1_ok(M, K, N, 1);
 }
 
+// ... and P / Gram of the upstream block as by-products: the block must hold every column of g~ (one N slice of 8 x 32 columns)
+bool iif_regw1x1_pg_ok(int M, int K, int N, int k2) {
+    return k2 == 64 && N == 256 && (K == 64 || K == 128) && iif_regw1x1_rx_ok(M, K, N, k2);
+}
+
 bool iif_regw1x1_ok(int M, int K, int N, int epi) {
     int cw, mt;
     if (M <= 0 || (int64_t)M * K * 2 >= 0x7f000000LL || !regw_plan(K, N, epi != 0, &cw, &mt)) return false;
@@ -563,6 +657,13 @@ int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_pa
             if ((int64_t)M * k2 * 2 >= 0x7f000000LL) return IIF_EUNSUPPORTED;
             a.src2 = (const unsigned char*)e->rx_src2; a.w3 = (const unsigned char*)e->rx_w3; a.spitch2 = k2; a.ldw3 = e->rx_ldw3;
             a.src2_bytes = (unsigned)((int64_t)M * k2 * 2);
+            if (e->pg_slab) {
+                if (!iif_regw1x1_pg_ok(M, K, N, k2) || e->pg_ld < k2 || (e->pg_ld & 3) || !e->pg_count ||
+                    (reinterpret_cast<uintptr_t>(e->pg_slab) & 15)) return IIF_EUNSUPPORTED;
+                a.pg_slab = e->pg_slab; a.pg_ld = e->pg_ld;
+            }
+        } else if (e->pg_slab) {
+            return IIF_EUNSUPPORTED;
         }
     }
     if (pro) { a.pro_stats = pro->stats; a.pro_out = (unsigned char*)pro->out; a.pro_bits = pro->bits; a.pro_csum = pro->csum; }
@@ -579,11 +680,18 @@ int iif_regw1x1_launch(const void* src, const void* wgt, void* dst, float* bn_pa
         if ((long long)(bn_row0 + G) * 2 * dpitch > bn_cap) return IIF_EINVAL;
         if (rows_out) *rows_out = bn_row0 + G;
     }
+    if (a.pg_slab) {
+        if ((long long)G * (N + k2) * a.pg_ld > e->pg_cap) return IIF_EINVAL;
+        *e->pg_count = G;
+    }
     const unsigned sb = (unsigned)((int64_t)M * spitch * 2);
     const dim3 g((unsigned)grid), b(512);
 #define IIF_REGW(KK, CW, MT, EP) hipLaunchKernelGGL((gemm1x1_regw_kernel<KK, CW, MT, EP>), g, b, 0, st, a, sb)
 #define IIF_REGWX(KK, K2) hipLaunchKernelGGL((gemm1x1_regw_kernel<KK, 32, 64, 4, K2>), g, b, 0, st, a, sb)
-    if (k2) {
+    if (k2 && a.pg_slab) {
+        if (K == 64) hipLaunchKernelGGL((gemm1x1_regw_kernel<64, 32, 64, 4, 64, false, true>), g, b, 0, st, a, sb);
+        else hipLaunchKernelGGL((gemm1x1_regw_kernel<128, 32, 64, 4, 64, false, true>), g, b, 0, st, a, sb);
+    } else if (k2) {
         if (K == 64 && k2 == 64) IIF_REGWX(64, 64);
         else if (K == 128 && k2 == 64) IIF_REGWX(128, 64);
         else if (K == 128 && k2 == 128) IIF_REGWX(128, 128);

@@ -1311,6 +1311,17 @@ extern "C" int iif_wgrad1x1_stacked(const void* x, const void* dy, const void* d
                             (const unsigned char*)dy2, cd2);
 }
 
+// sum of n fp32 slabs [rows, ld] (columns < cols) in slab order into out - the split-K reduction of this file for slabs written by
+// another kernel (the P / Gram by-product of iif_conv_igemm_dgrad_masksum_rx_pg).  slab_floats: floats available behind `slabs`;
+// the two-stage form needs ceil(n / 16) slabs of room behind the n slabs and is used when there is.
+extern "C" int iif_slab_sum(float* slabs, int64_t slab_floats, int n, int rows, int ld, int cols, float* out, void* stream) {
+    if (!slabs || !out || n < 1 || rows < 1 || ld < cols || cols < 1 || (ld & 3)) return IIF_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(out)) & 15) return IIF_EINVAL;
+    const int64_t slab = (int64_t)rows * ld;
+    if ((int64_t)n * slab > slab_floats) return IIF_EINVAL;
+    return reduce_slabs(slabs, slab_floats * 4, n, slab, rows, ld, cols, out, (hipStream_t)stream);
+}
+
 #ifdef IIF_CONV_STAMPS
 extern "C" int iif_debug_set_wgrad_stamps(unsigned long long* buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), &buf, sizeof(buf)) == hipSuccess ? IIF_OK : IIF_ELAUNCH;

@@ -611,6 +611,37 @@ def conv_dgrad_masksum_rx(dy, wt, in_hw, out, up_bits, partial, up_a2, up_w3, up
     return nt.value
 
 
+def conv_dgrad_rx_pg_ok(n, h, w, cs, cd, c2, dtype):
+    """Whether the recomputing producer also has the instance that leaves P = g~^T a2 and Gram = a2^T a2 behind."""
+    if dtype != torch.bfloat16:
+        return False
+    d = _desc(n, h, w, cs, h, w, cd, 1, 1, 1, 0, 1, cs, _lib.IIF_BF16, _lib.IIF_BF16, 1)
+    return bool(lib().iif_conv_dgrad_rx_pg_ok(ctypes.byref(d), c2))
+
+
+def conv_dgrad_masksum_rx_pg(dy, wt, in_hw, out, up_bits, partial, up_a2, up_w3, up_stats, pg_slabs, pg_ld, res=None, res_bits=None):
+    """conv_dgrad_masksum_rx that also writes one fp32 slab [(cd + c2), pg_ld] per tile sequence into ``pg_slabs`` (P = out^T a2
+    rows first, then Gram = a2^T a2); returns (partial row count, slab count).  ``slab_sum`` adds the slabs up."""
+    require_gpu(dy, wt, res, out, up_a2, up_w3, pg_slabs)
+    n, ho, wo, cout = dy.shape
+    cin, ldw = wt.shape
+    h, w_ = in_hw
+    d = _desc(n, ho, wo, cout, h, w_, cin, 1, 1, 1, 0, 1, ldw, dtype_code(dy), dtype_code(out), 1)
+    nt, ns = ctypes.c_int32(0), ctypes.c_int32(0)
+    check(lib().iif_conv_igemm_dgrad_masksum_rx_pg(ctypes.byref(d), ptr(dy), ptr(wt), ptr(out), ptr(res), ptr(res_bits), ptr(up_a2),
+                                                   up_a2.shape[3], ptr(up_w3), up_w3.stride(0), ptr(up_bits), ptr(up_stats), ptr(partial),
+                                                   partial.numel(), ctypes.byref(nt), ptr(pg_slabs), pg_slabs.numel(), pg_ld,
+                                                   ctypes.byref(ns), stream_ptr()), "iif_conv_igemm_dgrad_masksum_rx_pg")
+    return nt.value, ns.value
+
+
+def slab_sum(slabs, n, rows, ld, cols, out):
+    """out[r, c] = sum of the first ``n`` fp32 slabs [rows, ld] of ``slabs`` (columns < cols), in slab order."""
+    require_gpu(slabs, out)
+    check(lib().iif_slab_sum(ptr(slabs), slabs.numel(), n, rows, ld, cols, ptr(out), stream_ptr()), "iif_slab_sum")
+    return out
+
+
 def conv_dgrad2_bnbwd(src, src2, wt, bias, out, up_x=None, up_bits=None, up_stats=None, partial=None):
     """out[m, j] = sum_k [src | src2][m, k] * wt[j, k] + bias[j]  (1x1, bf16); with up_x: the upstream BN-backward sums too."""
     require_gpu(src, src2, wt, out, up_x)

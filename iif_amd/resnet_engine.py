@@ -960,6 +960,20 @@ class _Plan(object):
                     # both branches read them, and the compute stream's next fused data gradient does not overwrite them
                     # (round 5: the copy out of bw_partial was a 65 us blit on the compute stream)
                     self._alg_rows[id(b["units"][-1])] = self.ds_alg[id(du)]["rows"]
+        # P = g~^T a2 and Gram = a2^T a2 of an algebra unit as BY-PRODUCTS of the recomputing producer (round 6,
+        # iif_conv_igemm_dgrad_masksum_rx_pg): the block that forms a tile of g~ holds it in its staging buffers and a2's tile in LDS;
+        # one fp32 slab per tile sequence, summed on the weight-gradient stream (iif_slab_sum).  Replaces the stacked weight-gradient
+        # launch that re-read g~ and a2 (0.5 GB per bottleneck at 56 x 56).  Units: c = 64 (the 56 x 56 stage).  IIF_NO_PG=1: off.
+        self.pg_units = {}
+        if self.rx_units and self.wg_stream is not None and not os.environ.get("IIF_NO_PG"):
+            for bi, b in enumerate(self.blocks[:-1]):
+                u3 = b["units"][-1]
+                f = self.blocks[bi + 1]["units"][0]
+                cv3 = u3.conv
+                if (u3 in self.rx_units and self._a3_gram_stacked(u3) and cv3.ldw % 4 == 0 and cv3.ldw >= cv3.cin
+                        and ops.conv_dgrad_rx_pg_ok(f.n, f.hi, f.wi, f.conv.cout, f.conv.cin, cv3.cin, dt)):
+                    # up to 256 slabs (one per resident block) + the second reduction stage's ceil(256 / 16); [slabs, count of the last launch]
+                    self.pg_units[u3] = [torch.empty((256 + 17) * (cv3.cout + cv3.cin) * cv3.ldw, dtype=torch.float32, device=dev), 0]
 
     def _finish_weight_plan(self):
         """One arena for every dense transposed weight copy ([cin][k*k*cout], the data-gradient operand) and
@@ -1549,8 +1563,13 @@ class _Plan(object):
                 # column sums only (conv3's output is not read)
                 rows = self._alg_rows.get(id(up), self.bw_partial)
                 if up in self.rx_units:
-                    nt = ops.conv_dgrad_masksum_rx(dx4, u.wt, (u.hi, u.wi), dgrad_out, up_bits, rows, up.src, up.w, up.stats,
-                                                   res=dgrad_res, res_bits=dgrad_res_bits)
+                    pg = self.pg_units.get(up)
+                    if pg is not None:
+                        nt, pg[1] = ops.conv_dgrad_masksum_rx_pg(dx4, u.wt, (u.hi, u.wi), dgrad_out, up_bits, rows, up.src, up.w, up.stats,
+                                                                 pg[0], up.conv.ldw, res=dgrad_res, res_bits=dgrad_res_bits)
+                    else:
+                        nt = ops.conv_dgrad_masksum_rx(dx4, u.wt, (u.hi, u.wi), dgrad_out, up_bits, rows, up.src, up.w, up.stats,
+                                                       res=dgrad_res, res_bits=dgrad_res_bits)
                     self._bw_ready = (up, nt, rows)
                     return dgrad_out
                 nt = ops.conv_dgrad_masksum(dx4, u.wt, (u.hi, u.wi), dgrad_out, up_bits, rows, res=dgrad_res,
@@ -1647,7 +1666,14 @@ class _Plan(object):
 
         def finish_dw(ws, sp):
             gram = Ag["gram"].view(-1)[:c * cv.ldw].view(c, cv.ldw)
-            if stacked:
+            pg = self.pg_units.get(u)
+            if stacked and pg is not None and pg[1] > 0:
+                # the producer of g~ left P and Gram behind, one slab per tile sequence: add them up (no pass over g~ and a2)
+                ext = A["P"].view(-1)[:(C + c) * cv.ldw].view(C + c, cv.ldw)
+                ops.slab_sum(pg[0], pg[1], C + c, cv.ldw, c, ext)
+                pg[1] = 0
+                gram = ext[C:]
+            elif stacked:
                 ext = A["P"].view(-1)[:(C + c) * cv.ldw].view(C + c, cv.ldw)
                 ops.wgrad1x1_stacked(u.src.view(m, c), gt.view(m, C), u.src.view(m, c), ext, ws, splits=sp)
                 gram = ext[C:]

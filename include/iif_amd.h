@@ -502,6 +502,23 @@ int iif_conv_igemm_dgrad_masksum_rx(const iif_conv_desc* d, const void* src, con
                                     const unsigned char* res_bits, const void* up_a2, int up_c2, const void* up_w3, int up_ldw3,
                                     const unsigned char* up_bits, const float* up_stats, float* partial, int64_t partial_floats,
                                     int32_t* n_partials, void* stream);
+/* ... and with the two small matrices the algebraic BN3 backward of that upstream block needs as BY-PRODUCTS of the same launch
+ * (classification/resnet_pytorch.py:162-163, conv3 + bn3 backward as autograd derives them): P = dst^T a2 ([cd, up_c2]: what the
+ * conv3 weight-gradient GEMM computes) and Gram = a2^T a2 ([up_c2, up_c2]).  The block that forms a tile of dst holds it in its
+ * staging buffers and the a2 tile in LDS; it accumulates both products over its tiles and writes ONE fp32 slab
+ * [(cd + up_c2), pg_ld] (P rows first) per tile sequence into pg_slabs (pg_floats floats available; *n_slabs receives the slab count).
+ * iif_slab_sum adds the slabs in sequence order (deterministic).  The stacked weight-gradient launch that re-read dst and a2 from
+ * memory (0.5 GB per bottleneck at 56 x 56) is not needed.  iif_conv_dgrad_rx_pg_ok: up_c2 = 64, cd = 256, cs in {64, 128}. */
+int iif_conv_dgrad_rx_pg_ok(const iif_conv_desc* d, int up_c2);
+int iif_conv_igemm_dgrad_masksum_rx_pg(const iif_conv_desc* d, const void* src, const void* wgt, void* dst, const void* res,
+                                       const unsigned char* res_bits, const void* up_a2, int up_c2, const void* up_w3, int up_ldw3,
+                                       const unsigned char* up_bits, const float* up_stats, float* partial, int64_t partial_floats,
+                                       int32_t* n_partials, float* pg_slabs, int64_t pg_floats, int pg_ld, int32_t* n_slabs,
+                                       void* stream);
+/* out[r][c] = sum over the n slabs [rows, ld] of slabs[s][r][c], c < cols, in slab order (the split-K reduction of
+ * iif_conv_wgrad for slabs another kernel wrote).  slab_floats: floats available behind `slabs`; with room for ceil(n / 16)
+ * more slabs behind the n the reduction runs in two parallel stages. */
+int iif_slab_sum(float* slabs, int64_t slab_floats, int n, int rows, int ld, int cols, float* out, void* stream);
 int iif_conv_igemm_dgrad2_bnbwd(const iif_conv_desc* d, const void* src, const void* src2, int cs2, const void* wgt,
                                 const float* bias, void* dst, const void* up_x, const unsigned char* up_bits,
                                 const float* up_stats, float* partial, int64_t partial_floats, int32_t* n_partials,

@@ -53,6 +53,11 @@ for hw, k, C, c2 in ((56, 64, 256, 64), (56, 128, 256, 64), (28, 128, 512, 128),
     t3 = float("nan")
     if ops.conv_dgrad_rx_ok(B, hw, hw, k, C, c2, torch.bfloat16):
         t3 = timeit(lambda: ops.conv_dgrad_masksum_rx(dy, wt, (hw, hw), out, ub, partial, a2, w3, stats, res=res))
+    t4 = float("nan")
+    if ops.conv_dgrad_rx_pg_ok(B, hw, hw, k, C, c2, torch.bfloat16):
+        slabs = torch.empty(273 * (C + c2) * c2, device=dev)
+        t4 = timeit(lambda: ops.conv_dgrad_masksum_rx_pg(dy, wt, (hw, hw), out, ub, partial, a2, w3, stats, slabs, c2, res=res))
     mb = m * (k + 2 * C) * 2 / 1e6
-    print("  %2dx%2d %4d -> %4d (c2 %3d)   sums %6.1f us (%4.0f GB/s)   stored x %6.1f us (%4.0f GB/s)   recomputed x %6.1f us (%4.0f GB/s)" % (
-        hw, hw, k, C, c2, t1, mb / t1 * 1e3, t2, (mb + m * C * 2 / 1e6) / t2 * 1e3, t3, (mb + m * c2 * 2 / 1e6) / t3 * 1e3))
+    print("  %2dx%2d %4d -> %4d (c2 %3d)   sums %6.1f us (%4.0f GB/s)   stored x %6.1f us (%4.0f GB/s)   recomputed x %6.1f us (%4.0f GB/s)"
+          "   + P and Gram %6.1f us" % (
+              hw, hw, k, C, c2, t1, mb / t1 * 1e3, t2, (mb + m * C * 2 / 1e6) / t2 * 1e3, t3, (mb + m * c2 * 2 / 1e6) / t3 * 1e3, t4))

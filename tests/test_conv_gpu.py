@@ -1061,6 +1061,59 @@ def test_dgrad_masksum_with_the_upstream_output_recomputed(case, with_res):
     assert torch.equal(p1[:nt1], p2[:nt2])
 
 
+@pytest.mark.parametrize("case", [(4, 16, 64, 256, 64), (4, 16, 128, 256, 64), (16, 56, 64, 256, 64), (3, 32, 128, 256, 64)],
+                         ids=lambda c: "%dx%dx%d_k%d_n%d_c%d" % (c[0], c[1], c[1], c[2], c[3], c[4]))
+@pytest.mark.parametrize("with_res", [False, True], ids=["plain", "residual"])
+def test_recomputing_producer_leaves_the_algebra_matrices_behind(case, with_res):
+    """Round 6: iif_conv_igemm_dgrad_masksum_rx_pg = iif_conv_igemm_dgrad_masksum_rx (stored tensor and partial rows bit-identical)
+    plus one fp32 slab [(C + c2), ld] per tile sequence; their sum (iif_slab_sum, slab order) is P = g~^T a2 and Gram = a2^T a2
+    of the STORED g~ - compared with the float64 products of the stored tensors (fp32 accumulation error only) and with the
+    weight-gradient GEMM that used to compute them (iif_wgrad1x1_stacked)."""
+    from iif_amd import ops
+    n, hw, k, C, c2 = case
+    m = n * hw * hw
+    dt = torch.bfloat16
+    assert ops.conv_dgrad_rx_pg_ok(n, hw, hw, k, C, c2, dt)
+    g = torch.Generator().manual_seed(11 * k + c2 + hw)
+    a2 = torch.relu(torch.randn(n, hw, hw, c2, generator=g)).to(dt).to(DEV)
+    w3 = (torch.randn(C, c2, generator=g) / c2 ** 0.5).to(dt).to(DEV)
+    dy = torch.randn(n, hw, hw, k, generator=g).to(dt).to(DEV)
+    wt = (torch.randn(C, k, generator=g) / k ** 0.5).to(dt).to(DEV)
+    ubits = torch.randint(0, 256, (m * C // 8,), dtype=torch.uint8, generator=g).to(DEV)
+    res = torch.randn(n, hw, hw, C, generator=g).to(dt).to(DEV) if with_res else None
+    rbits = torch.randint(0, 256, (m * C // 8,), dtype=torch.uint8, generator=g).to(DEV) if with_res else None
+    stats = torch.zeros(4, C)
+    stats[0] = torch.randn(C, generator=g) * 0.1
+    stats[1] = torch.rand(C, generator=g) + 0.5
+    stats = stats.to(DEV)
+    rows = (m + 127) // 128 + 8
+    o1 = torch.full((n, hw, hw, C), float("nan"), dtype=dt, device=DEV)
+    p1 = torch.full((rows, 2, C), float("nan"), device=DEV)
+    nt1 = ops.conv_dgrad_masksum_rx(dy, wt, (hw, hw), o1, ubits, p1.view(-1), a2, w3, stats, res=res, res_bits=rbits)
+    ld = c2
+    cap = 256 + 256 // 16 + 1
+    slabs = torch.full((cap, C + c2, ld), float("nan"), device=DEV)
+    o2 = torch.full((n, hw, hw, C), float("nan"), dtype=dt, device=DEV)
+    p2 = torch.full((rows, 2, C), float("nan"), device=DEV)
+    nt2, ns = ops.conv_dgrad_masksum_rx_pg(dy, wt, (hw, hw), o2, ubits, p2.view(-1), a2, w3, stats, slabs.view(-1), ld, res=res, res_bits=rbits)
+    assert nt1 == nt2 and 0 < ns <= 256
+    assert torch.equal(o1, o2) and torch.equal(p1[:nt1], p2[:nt2])
+    assert not torch.isnan(slabs[:ns]).any() and torch.isnan(slabs[ns:]).all()
+    ext = torch.full((C + c2, ld), float("nan"), device=DEV)
+    ops.slab_sum(slabs.view(-1), ns, C + c2, ld, c2, ext)
+    assert torch.equal(ext, slabs[:ns].sum(0)) or (ext - slabs[:ns].double().sum(0).float()).abs().max().item() <= 1e-5 * ext.abs().max().item()
+    gs, a2d = o2.view(m, C).double().cpu(), a2.view(m, c2).double().cpu()
+    ref_p, ref_g = gs.t() @ a2d, a2d.t() @ a2d
+    got = ext.double().cpu()
+    assert (got[:C] - ref_p).abs().max().item() <= 2e-5 * (gs.abs().t() @ a2d).max().item()
+    assert (got[C:] - ref_g).abs().max().item() <= 2e-5 * ref_g.max().item()
+    # and the weight-gradient GEMM it replaces (the same products, another summation order)
+    old = torch.zeros(C + c2, ld, device=DEV)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    ops.wgrad1x1_stacked(a2.view(m, c2), o2.view(m, C), a2.view(m, c2), old, ws)
+    assert (old - ext).abs().max().item() <= 4e-5 * max(old.abs().max().item(), 1.0)
+
+
 @pytest.mark.parametrize("case", [(4, 128, 14, 14, 32), (2, 256, 28, 28, 32), (1, 512, 7, 7, 32), (3, 64, 9, 11, 8), (2, 512, 14, 14, 32),
                                   (1, 128, 56, 56, 32)],
                          ids=lambda c: "n%d_w%d_%dx%d_g%d" % c)

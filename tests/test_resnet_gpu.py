@@ -798,6 +798,45 @@ def test_bf16_loss_curve_of_the_default_routes_against_the_standard_backward(mon
     assert curves["default"][-1] < curves["default"][0]              # (lr 0.002: the raw IIF recipe descends smoothly)
 
 
+def test_p_and_gram_from_the_producer_inside_the_step(monkeypatch):
+    """Round 6: the 56 x 56 bottlenecks take P = g~^T a2 and Gram = a2^T a2 of the algebraic BN3 backward from the producing data
+    gradient's own launch (iif_conv_igemm_dgrad_masksum_rx_pg + iif_slab_sum) instead of a weight-gradient GEMM over g~ and a2.
+    Same products of the same stored tensors in another summation order: the step with and without (IIF_NO_PG=1) agrees to fp32
+    summation noise in conv3's weight gradients of those blocks and bit for bit everywhere the matrices do not reach."""
+    from iif_amd.custom import IIFLoss
+    arch, C, B, hw = "resnet50", 100, 32, 224
+    counts = [max(int(500 * (5 / 500) ** (i / (C - 1.0))), 1) for i in range(C)]
+    x, y = _data(B, hw, counts, seed=5)
+    xd, yd = x.to(DEV), y.to(DEV)
+    crit = IIFLoss(DS(counts), variant="raw")
+    monkeypatch.setenv("IIF_SIDE_STREAMS", "1")
+    monkeypatch.setenv("IIF_BN3_ALGEBRA_PURE_MIN_ELEMS", "0")
+    out = {}
+    for mode in ("pg", "plain"):
+        if mode == "plain":
+            monkeypatch.setenv("IIF_NO_PG", "1")
+        net, sd = _build(arch, C, torch.bfloat16)
+        net.load_state_dict(damp_residual_branches(sd, arch))
+        net.train()
+        loss, _ = net.loss_and_backward(xd, yd, crit)
+        torch.cuda.synchronize()
+        plan = net._saved
+        assert len(plan.pg_units) == (3 if mode == "pg" else 0), len(plan.pg_units)
+        out[mode] = (float(loss), net.grad_arena.clone(), {id(u.conv) for u in plan.pg_units}, net)
+    assert out["pg"][0] == out["plain"][0]
+    gp, gq, net = out["pg"][1], out["plain"][1], out["pg"][3]
+    touched = 0
+    for (m_, attr, rows, pitch) in net._param_specs():
+        off = net._offsets[(id(m_), attr)][0]
+        a, b = gp[off:off + rows * pitch], gq[off:off + rows * pitch]
+        if torch.equal(a, b):
+            continue
+        touched += 1
+        # conv3 weights of the three blocks (dW = A P + B W Gram + D (x) csum): the summation order of P and Gram only
+        assert attr == "weight" and (a - b).norm().item() <= 2e-5 * b.norm().item(), (attr, rows, pitch, (a - b).norm().item(), b.norm().item())
+    assert 1 <= touched <= 3
+
+
 def test_side_streams_follow_the_size_of_the_step(monkeypatch):
     """Without an override the plan of a CIFAR-size step runs on one stream (host-bound: 3.24 -> 2.52 ms at ResNet32 bs 128)
     and an ImageNet-size one gets the weight-gradient and shortcut streams; both produce the same gradients as the forced
