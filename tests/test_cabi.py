@@ -188,7 +188,7 @@ def _vregs(tok):
     return []
 
 
-@pytest.mark.parametrize("src", ["conv_wgrad.hip", "bn3_algebra.hip"])
+@pytest.mark.parametrize("src", ["conv_wgrad.hip", "bn3_algebra.hip", "conv_regw.hip"])
 def test_tr_read_results_are_waited_for(tmp_path, src):
     """The transposing LDS reads are inline asm (the builtin drains every LDS-DMA in flight, conv_wgrad.hip:51-56), so the
     compiler does not know that their destination registers are still being written.  Pin the emitted gfx950 ISA: between a
