@@ -1058,7 +1058,13 @@ inline int launch_wgrad_halo(const WgArgs& a, float* dw, float* ws, int64_t ws_b
     int splits = splits_req;
     if (splits <= 0) {
         const int per_cu = 2;
-        splits = 256 * per_cu / share_of(splits_req) / tiles;
+        // grouped layers (ResNeXt: the weight gradient is block-diagonal, 8 chunks x 147 KB at 14 x 14 against 51 MB of operands) take
+        // a quarter of a round: ResNeXt-101 20.80 / 20.87 (full) -> 20.37 (half) -> 20.36 / 20.29 (quarter) -> 21.0 (eighth) ms per step;
+        // dense layers keep the full round (ResNet-50: 16.57 -> 16.65 with half)
+        static const int halo_div = [] { const char* e = getenv("IIF_WGRAD_HALO_DIV"); return e ? atoi(e) : 1; }();
+        static const int halo_gdiv = [] { const char* e = getenv("IIF_WGRAD_HALO_GROUPED_DIV"); return e ? atoi(e) : 4; }();
+        const int hdiv = h.grouped ? halo_gdiv : halo_div;
+        splits = 256 * per_cu / share_of(splits_req) / tiles / (hdiv > 0 ? hdiv : 1);
         if (splits < 1) splits = 1;
         const int max_by_work = h.nsteps / 8 > 0 ? h.nsteps / 8 : 1;
         if (splits > max_by_work) splits = max_by_work;
@@ -1153,7 +1159,11 @@ inline int launch_wgrad_1x1(const WgArgs& g, float* dw, float* ws, int64_t ws_by
         static const int small_div = [] { const char* e = getenv("IIF_WGRAD_SMALL_DIV"); return e ? atoi(e) : 2; }();
         static const int gram_div = [] { const char* e = getenv("IIF_WGRAD_GRAM_DIV"); return e ? atoi(e) : 8; }();
         const bool gram = g.x == g.dy && dy2 == nullptr;
-        const int div = gram ? gram_div : (slab * 4 <= (256 << 10) ? small_div : 1);
+        static const int small_kb = [] { const char* e = getenv("IIF_WGRAD_SMALL_KB"); return e ? atoi(e) : 256; }();
+        // (late round 6: outputs up to 4 MB - the 14 x 14 / 7 x 7 1x1 layers - take half a round too: 16.75 / 16.80 / 16.84 -> 16.73 / 16.71 /
+        // 16.78 ms per step in one call, their slabs halved; a quarter round: 17.2.  IIF_WGRAD_MID_DIV=1 restores the full round)
+        static const int mid_div = [] { const char* e = getenv("IIF_WGRAD_MID_DIV"); return e ? atoi(e) : 2; }();
+        const int div = gram ? gram_div : (slab * 4 <= ((int64_t)small_kb << 10) ? small_div : (slab * 4 <= (4 << 20) ? mid_div : 1));
         if (div > 1 && splits > 8) { splits /= div; if (splits < 8) splits = 8; }       // (never more splits than before)
     }
     const int64_t fit = ws ? ws_bytes / (slab * 4) : 0;
