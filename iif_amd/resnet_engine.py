@@ -783,7 +783,7 @@ class _Plan(object):
         # backward, 4 passes over that tensor saved, but P sits on the compute stream before the data gradient) - it wins
         # where the tensor is large (>= 1.5e8 elements: the 56 x 56 stage at batch 256); otherwise the producing data gradient
         # still reads conv3's output once for sum g~ xhat (3 passes saved) and P moves to the weight-gradient stream.
-        self.wg_lag = 2      # blocks the weight-gradient stream may lag (explained where the side streams are created; 3 / 4 / 6 measured level)
+        self.wg_lag = int(os.environ.get("IIF_WG_LAG", "2"))      # blocks the weight-gradient stream may lag (explained where the side streams are created; 3 / 4 / 6 measured level)
         self.alg3_units = set()
         # (round 6: 9e7 = the 56 x 56 and 28 x 28 stages at batch 256 - "sums from P" is what lets the forward pass never store
         # conv3's output, see nostore_units below; 1.5e8 = the 56 x 56 stage only, as in rounds 3-5)
