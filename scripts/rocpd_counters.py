@@ -1,27 +1,34 @@
-"""Generic per-kernel counter table from a rocprofv3 PMC pass (rocpd sqlite): mean of every collected counter per launch.
-    python scripts/rocpd_counters.py results.db [name-filter]
-"""
+"""Per-kernel sums of the counters of one rocprofv3 --pmc pass (rocpd database), per bench step, with the ratio of the first two:
+    python scripts/rocpd_counters.py db STEPS out.csv
+e.g. --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE: the share of LDS-array cycles that are bank-conflict replays."""
+import csv
 import sqlite3
 import sys
 
 
-def main(db_path, filt=""):
+def main(db_path, steps, out_path):
+    steps = float(steps)
     db = sqlite3.connect(db_path)
+    names = [r[0] for r in db.execute("select distinct counter_name from counters_collection order by counter_name")]
     agg = {}
-    for name, cname, val, dur in db.execute("select kernel_name, counter_name, value, duration from counters_collection"):
-        if filt and filt not in name:
-            continue
-        a = agg.setdefault(name, {})
-        c = a.setdefault(cname, [0, 0.0, 0.0])
-        c[0] += 1; c[1] += val; c[2] += dur
-    for name, a in agg.items():
-        short = name.replace("(anonymous namespace)::", "")[:70]
-        n = max(v[0] for v in a.values())
-        dur = max(v[2] for v in a.values()) / n
-        print("%s  launches %d  avg %.1f us" % (short, n, dur / 1e3))
-        for cname in sorted(a):
-            print("    %-32s %16.0f per launch" % (cname, a[cname][1] / a[cname][0]))
+    for kname, cname, val, dur in db.execute("select kernel_name, counter_name, value, duration from counters_collection"):
+        a = agg.setdefault(kname, {"n": {}, "dur": 0.0})
+        a[cname] = a.get(cname, 0.0) + val
+        a["n"][cname] = a["n"].get(cname, 0) + 1
+        if cname == names[0]:
+            a["dur"] += dur
+    rows = []
+    for k, a in agg.items():
+        v = [a.get(c, 0.0) / steps for c in names]
+        ratio = v[0] / v[1] if len(v) > 1 and v[1] else 0.0
+        rows.append([k.replace("(anonymous namespace)::", "")[:120], round(max(a["n"].values()) / steps, 1), round(a["dur"] / steps / 1e6, 3)] +
+                    [round(x, 1) for x in v] + [round(ratio, 4)])
+    rows.sort(key=lambda r: -r[2])
+    with open(out_path, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "launches_per_step", "kernel_ms_per_step"] + names + ["%s / %s" % (names[0], names[1]) if len(names) > 1 else "ratio"])
+        w.writerows(rows)
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:3])
+    main(*sys.argv[1:4])
