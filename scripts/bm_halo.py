@@ -2,7 +2,7 @@
 Run once as is (three taps per hand-over) and once with IIF_CONV_HALO_TPB1=1 (a hand-over per tap).   python scripts/bm_halo.py"""
 import os
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from iif_amd import ops
 dev = "cuda:0"
