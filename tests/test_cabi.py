@@ -85,6 +85,29 @@ def test_host_build_table_rejects_bad_arguments():
     assert lib.iif_build_table(counts.ctypes.data, 4, 9, 0, out.ctypes.data) == -1
 
 
+def test_routing_queries_and_argument_checks_of_the_round6_entries():
+    """Host logic of the late round-6 entry points, no device needed: which (cs, cd, c2) the producer with the P / Gram
+    by-product takes (one N slice of 256 columns, a 64-channel second source, at least 1 024 rows in whole 64-row tiles), and
+    the argument checks of iif_slab_sum (they return before anything is launched)."""
+    import torch
+    from iif_amd import ops
+    ok = lambda n, hw, cs, cd, c2: ops.conv_dgrad_rx_pg_ok(n, hw, hw, cs, cd, c2, torch.bfloat16)   # noqa: E731
+    assert ok(256, 56, 64, 256, 64) and ok(256, 56, 128, 256, 64) and ok(4, 16, 64, 256, 64)
+    assert not ok(256, 28, 128, 512, 128)        # two N slices: no block holds every column of g~
+    assert not ok(256, 56, 64, 256, 128)         # 128-channel second source
+    assert not ok(256, 14, 256, 1024, 256)       # no recomputing instance at all
+    assert not ok(1, 16, 64, 256, 64)            # 256 rows: below the persistent kernel's minimum
+    assert not ops.conv_dgrad_rx_pg_ok(256, 56, 56, 64, 256, 64, torch.float32)
+    L = _lib.lib()
+    raw = (ctypes.c_float * 80)()
+    addr = (ctypes.addressof(raw) + 15) // 16 * 16            # the entry wants 16-byte aligned buffers
+    assert L.iif_slab_sum(None, 64, 1, 4, 4, 4, addr, None) == -1
+    assert L.iif_slab_sum(addr, 64, 0, 4, 4, 4, addr, None) == -1           # no slab
+    assert L.iif_slab_sum(addr, 64, 1, 4, 6, 4, addr, None) == -1           # pitch not a multiple of 4
+    assert L.iif_slab_sum(addr, 64, 1, 4, 4, 8, addr, None) == -1           # more columns than the pitch
+    assert L.iif_slab_sum(addr, 15, 1, 4, 4, 4, addr, None) == -1           # slabs beyond the buffer
+
+
 def test_python_tables_bit_exact_with_golden(golden):
     import torch
     from iif_amd.custom import build_tables
